@@ -1,0 +1,10 @@
+"""fsgm_amd -- MI355X-native (gfx950, hand-written HIP) build of fSGM's matching-cost +
+multi-path SGM aggregation hot path, behind the reference's MEX argument lists.
+
+    from fsgm_amd import calc_cost_sgm            # mirrors calc_cost_sgm.cpp's mexFunction
+    bestD, minC = calc_cost_sgm(I1, I2, dMax, vMax, pixelPosD0, normDir, offset, P1, P2)
+
+Everything computes on the GPU through libfsgm_hip.so (C ABI in include/fsgm.h).
+"""
+from .epi import calc_cost_sgm, calc_cost_sgm_batch, EpiPlan  # noqa: F401
+from ._lib import FsgmError, load as load_library  # noqa: F401

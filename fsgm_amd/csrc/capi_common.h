@@ -1,0 +1,32 @@
+// capi_common.h -- error plumbing shared by the C-ABI translation units
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/fsgm.h"
+
+namespace fsgm {
+
+char* last_error_buf();   // thread-local, 512 bytes
+
+inline fsgm_status fail(fsgm_status st, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return st;
+}
+
+#define FSGM_HIP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return ::fsgm::fail(FSGM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define FSGM_REQUIRE(cond, ...)                                          \
+    do {                                                                 \
+        if (!(cond)) return ::fsgm::fail(FSGM_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+}  // namespace fsgm

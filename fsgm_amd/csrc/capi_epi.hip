@@ -1,0 +1,401 @@
+// capi_epi.hip -- C ABI for the calc_cost_sgm path: device-resident plan + host-pointer entry
+// points (what the calc_cost_sgm mexFunction gateway calls).  See include/fsgm.h.
+#include "capi_common.h"
+#include "epi_kernels.h"
+#include <algorithm>
+#include <mutex>
+#include <string.h>
+#include <vector>
+
+namespace fsgm {
+char* last_error_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+}  // namespace fsgm
+
+using namespace fsgm;
+
+struct fsgm_epi_plan {
+    int W = 0, H = 0, D = 0, batch = 0;
+    fsgm_epi_params prm{};
+    int P1 = 6, P2 = 64;                 // epipolar_sgm_of.m:19
+    double vMax = 0.3;                   // epipolar_sgm_of.m:16
+    size_t NP = 0, N = 0;                // pixels, voxels per frame
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint8_t *dI1 = nullptr, *dI2 = nullptr;
+    uint32_t *dCen1 = nullptr, *dCen2 = nullptr;
+    double *dPd0 = nullptr, *dNd = nullptr, *dOff = nullptr, *dVz = nullptr;
+    uint8_t *dCraw = nullptr, *dC = nullptr, *dL = nullptr;
+    uint32_t *dBestD = nullptr, *dMinC = nullptr, *dS = nullptr;
+    std::vector<int> cmax;               // per frame: upper bound of the cost values in dC
+    bool vz_valid = false;
+    int kernel_kind = AGG_GENERIC;
+    bool packed = false;
+};
+
+static void select_kernel(fsgm_epi_plan* p) {
+    p->packed = agg_packed_lpp(p->D) != 0;
+    if (!p->packed) { p->kernel_kind = AGG_GENERIC; return; }
+    const int cm = *std::max_element(p->cmax.begin(), p->cmax.end());
+    const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + std::max(p->P1, p->P2) <= 255;
+    p->kernel_kind = nowrap ? AGG_PACKED_NOWRAP : AGG_PACKED_WRAP;
+}
+
+extern "C" {
+
+const char* fsgm_last_error(void) { return last_error_buf(); }
+
+int fsgm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+fsgm_status fsgm_device_arch(int device, char* buf, size_t buflen) {
+    FSGM_REQUIRE(buf && buflen > 0, "fsgm_device_arch: null buffer");
+    hipDeviceProp_t prop;
+    FSGM_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return FSGM_OK;
+}
+
+fsgm_epi_params fsgm_epi_params_default(void) {
+    fsgm_epi_params p;
+    p.paths = 4;         // calc_cost_sgm.cpp:104
+    p.subpixel = 1;      // calc_cost_sgm.cpp:560
+    p.vz_to_disp = 1;    // calc_cost_sgm.cpp:4
+    p.device = 0;
+    return p;
+}
+
+void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
+    if (!p) return;
+    hipSetDevice(p->prm.device);
+    void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    if (p->ev0) hipEventDestroy(p->ev0);
+    if (p->ev1) hipEventDestroy(p->ev1);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+}
+
+fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int32_t D, int32_t batch,
+                                 const fsgm_epi_params* prm) {
+    FSGM_REQUIRE(out, "fsgm_epi_plan_create: null plan pointer");
+    *out = nullptr;
+    FSGM_REQUIRE(W >= 1 && H >= 1, "fsgm_epi_plan_create: width/height must be >= 1 (got %d x %d)", W, H);
+    FSGM_REQUIRE(D >= 1, "fsgm_epi_plan_create: dMax must be >= 1 (got %d)", D);
+    FSGM_REQUIRE(batch >= 1, "fsgm_epi_plan_create: batch must be >= 1");
+    const fsgm_epi_params pr = prm ? *prm : fsgm_epi_params_default();
+    FSGM_REQUIRE(pr.paths == 4 || pr.paths == 8, "fsgm_epi_plan_create: paths must be 4 or 8 (got %d)", pr.paths);
+    if (D > FSGM_GENERIC_MAX_D)
+        return fail(FSGM_ERR_UNSUPPORTED, "dMax %d exceeds the supported maximum %d", D, FSGM_GENERIC_MAX_D);
+    if ((double)W * H * D >= 2147483648.0)
+        return fail(FSGM_ERR_UNSUPPORTED, "cost volume %d x %d x %d exceeds 2^31 voxels per frame", W, H, D);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FSGM_ERR_HIP, "no HIP device available (libfsgm_hip has no CPU fallback)");
+    FSGM_REQUIRE(pr.device >= 0 && pr.device < ndev, "device %d out of range (have %d)", pr.device, ndev);
+    FSGM_HIP(hipSetDevice(pr.device));
+
+    fsgm_epi_plan* p = new fsgm_epi_plan;
+    p->W = W; p->H = H; p->D = D; p->batch = batch; p->prm = pr;
+    p->NP = (size_t)W * H; p->N = p->NP * D;
+    p->cmax.assign(batch, 24);           // census 5x5: 24 informative bits
+    const size_t B = batch;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(ptr, bytes); };
+    alloc((void**)&p->dI1, B * p->NP);
+    alloc((void**)&p->dI2, B * p->NP);
+    alloc((void**)&p->dCen1, B * p->NP * 4);
+    alloc((void**)&p->dCen2, B * p->NP * 4);
+    alloc((void**)&p->dPd0, B * p->NP * 16);
+    alloc((void**)&p->dNd, B * p->NP * 16);
+    alloc((void**)&p->dOff, B * p->NP * 8);
+    alloc((void**)&p->dVz, (size_t)D * 8);
+    alloc((void**)&p->dCraw, B * p->N);
+    alloc((void**)&p->dC, B * p->N);
+    alloc((void**)&p->dL, B * p->N * pr.paths);
+    alloc((void**)&p->dBestD, B * p->NP * 4);
+    alloc((void**)&p->dMinC, B * p->NP * 4);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&p->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+    if (e == hipSuccess) e = hipMemsetAsync(p->dOff, 0, B * p->NP * 8, p->stream);
+    if (e != hipSuccess) {
+        fsgm_epi_plan_destroy(p);
+        return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP,
+                    "fsgm_epi_plan_create: %s", hipGetErrorString(e));
+    }
+    select_kernel(p);
+    *out = p;
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* p, int32_t P1, int32_t P2, double vMax) {
+    FSGM_REQUIRE(p, "null plan");
+    p->P1 = P1; p->P2 = P2;
+    if (vMax != p->vMax) p->vz_valid = false;
+    p->vMax = vMax;
+    select_kernel(p);
+    return FSGM_OK;
+}
+
+static fsgm_status ensure_vz(fsgm_epi_plan* p) {
+    if (p->vz_valid) return FSGM_OK;
+    // calc_cost_sgm.cpp:339,360-361 -- depends on d only; same fp64 expressions, host side
+    std::vector<double> vz(p->D);
+    const double n = p->D + 1;
+    for (int d = 0; d < p->D; d++) {
+        const double vzRatio = 1.0 * d / n * p->vMax;
+        vz[d] = vzRatio / (1 - vzRatio);
+    }
+    FSGM_HIP(hipMemcpyAsync(p->dVz, vz.data(), (size_t)p->D * 8, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipStreamSynchronize(p->stream));   // vz is a stack-lifetime host buffer
+    p->vz_valid = true;
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* p, int32_t f, const uint8_t* I1, const uint8_t* I2,
+                                 const double* pd0, const double* nd, const double* off) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
+    FSGM_REQUIRE(I1 && I2 && pd0 && nd && off, "fsgm_epi_plan_upload: null input");
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    const size_t NP = p->NP;
+    FSGM_HIP(hipMemcpyAsync(p->dI1 + f * NP, I1, NP, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipMemcpyAsync(p->dI2 + f * NP, I2, NP, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipMemcpyAsync(p->dPd0 + f * 2 * NP, pd0, NP * 16, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipMemcpyAsync(p->dNd + f * 2 * NP, nd, NP * 16, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipMemcpyAsync(p->dOff + f * NP, off, NP * 8, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipStreamSynchronize(p->stream));   // pageable host memory: keep the caller's buffers free to reuse
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_upload_cost(fsgm_epi_plan* p, int32_t f, const uint8_t* C) {
+    FSGM_REQUIRE(p && C, "fsgm_epi_plan_upload_cost: null argument");
+    FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    int cm = 0;
+    for (size_t i = 0; i < p->N; i++) cm = C[i] > cm ? C[i] : cm;
+    p->cmax[f] = cm;
+    select_kernel(p);
+    FSGM_HIP(hipMemcpyAsync(p->dC + f * p->N, C, p->N, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_upload_offset(fsgm_epi_plan* p, int32_t f, const double* off) {
+    FSGM_REQUIRE(p && off, "fsgm_epi_plan_upload_offset: null argument");
+    FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    FSGM_HIP(hipMemcpyAsync(p->dOff + f * p->NP, off, p->NP * 8, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    return FSGM_OK;
+}
+
+static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
+    if (stages & FSGM_STAGE_COST) {
+        fsgm_status st = ensure_vz(p);
+        if (st != FSGM_OK) return st;
+        launch_census(p->stream, p->dI1, p->dCen1, p->W, p->H, p->batch);
+        launch_census(p->stream, p->dI2, p->dCen2, p->W, p->H, p->batch);
+        EpiCostArgs a;
+        a.cen1 = p->dCen1; a.cen2 = p->dCen2; a.pd0 = p->dPd0; a.nd = p->dNd; a.off = p->dOff;
+        a.vz = p->dVz; a.Craw = p->dCraw; a.W = p->W; a.H = p->H; a.D = p->D;
+        launch_epi_cost(p->stream, a, p->dC, p->batch);
+        bool changed = false;
+        for (int& c : p->cmax) { if (c != 24) changed = true; c = 24; }
+        if (changed) select_kernel(p);
+    }
+    if (stages & FSGM_STAGE_AGGREGATE) {
+        AggArgs a;
+        a.C = p->dC; a.L = p->dL;
+        a.c_frame_stride = p->N; a.l_frame_stride = p->N * p->prm.paths; a.l_dir_stride = p->N;
+        a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
+        launch_aggregate(p->stream, a, p->prm.paths, p->batch, p->kernel_kind);
+    }
+    if (stages & FSGM_STAGE_WTA) {
+        WtaArgs a;
+        a.L = p->dL; a.l_frame_stride = p->N * p->prm.paths; a.l_dir_stride = p->N;
+        a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
+        a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
+        a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
+        launch_wta(p->stream, a, p->batch, p->packed);
+    }
+    FSGM_HIP(hipGetLastError());
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* p, int32_t stages) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_REQUIRE((stages & ~FSGM_STAGE_ALL) == 0 && stages != 0, "bad stage mask %d", stages);
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    return enqueue(p, stages);
+}
+
+fsgm_status fsgm_epi_plan_sync(fsgm_epi_plan* p) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_download(fsgm_epi_plan* p, int32_t f, uint32_t* bestD, uint32_t* minC) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    if (bestD) FSGM_HIP(hipMemcpy(bestD, p->dBestD + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
+    if (minC) FSGM_HIP(hipMemcpy(minC, p->dMinC + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_download_cost(fsgm_epi_plan* p, int32_t f, uint8_t* C) {
+    FSGM_REQUIRE(p && C, "fsgm_epi_plan_download_cost: null argument");
+    FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    FSGM_HIP(hipMemcpy(C, p->dC + f * p->N, p->N, hipMemcpyDeviceToHost));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S) {
+    FSGM_REQUIRE(p && S, "fsgm_epi_plan_download_sum: null argument");
+    FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
+    launch_sum_paths(p->stream, p->dL + (size_t)f * p->N * p->prm.paths, p->dS, p->N, p->N, p->prm.paths);
+    FSGM_HIP(hipGetLastError());
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    FSGM_HIP(hipMemcpy(S, p->dS, p->N * 4, hipMemcpyDeviceToHost));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_time(fsgm_epi_plan* p, int32_t stages, int32_t warmup, int32_t iters, float* ms_avg) {
+    FSGM_REQUIRE(p && ms_avg, "fsgm_epi_plan_time: null argument");
+    FSGM_REQUIRE(iters >= 1 && warmup >= 0, "fsgm_epi_plan_time: iters must be >= 1");
+    FSGM_REQUIRE((stages & ~FSGM_STAGE_ALL) == 0 && stages != 0, "bad stage mask %d", stages);
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    for (int i = 0; i < warmup; i++) {
+        fsgm_status st = enqueue(p, stages);
+        if (st != FSGM_OK) return st;
+    }
+    FSGM_HIP(hipEventRecord(p->ev0, p->stream));
+    for (int i = 0; i < iters; i++) {
+        fsgm_status st = enqueue(p, stages);
+        if (st != FSGM_OK) return st;
+    }
+    FSGM_HIP(hipEventRecord(p->ev1, p->stream));
+    FSGM_HIP(hipEventSynchronize(p->ev1));
+    float ms = 0;
+    FSGM_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    *ms_avg = ms / iters;
+    return FSGM_OK;
+}
+
+void* fsgm_epi_plan_stream(fsgm_epi_plan* p) { return p ? (void*)p->stream : nullptr; }
+
+const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* p) {
+    if (!p) return "";
+    switch (p->kernel_kind) {
+        case AGG_PACKED_NOWRAP: return "packed16/nowrap";
+        case AGG_PACKED_WRAP: return "packed16/wrap";
+        default: return "generic";
+    }
+}
+
+fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps) {
+    FSGM_REQUIRE(gbps && bytes > 0 && iters > 0, "fsgm_measure_copy_bandwidth: bad argument");
+    FSGM_HIP(hipSetDevice(device));
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0, e1;
+    FSGM_HIP(hipMalloc(&a, bytes));
+    if (hipMalloc(&b, bytes) != hipSuccess) { hipFree(a); return fail(FSGM_ERR_NOMEM, "copy probe: out of memory"); }
+    hipMemset(a, 1, bytes);
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; i++) hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
+    hipEventRecord(e1, 0);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    if (e != hipSuccess) return fail(FSGM_ERR_HIP, "copy probe: %s", hipGetErrorString(e));
+    *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+    return FSGM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-pointer entry points (the MEX boundary).  Plans are cached per shape for the lifetime of
+// the process so repeated MEX calls do not re-allocate HBM (SURVEY 8b "ownership").
+// ---------------------------------------------------------------------------------------------
+static std::mutex g_cache_mu;
+static std::vector<fsgm_epi_plan*> g_cache;
+
+static fsgm_status cached_plan(fsgm_epi_plan** out, int W, int H, int D, int batch, const fsgm_epi_params& pr) {
+    for (fsgm_epi_plan* p : g_cache)
+        if (p->W == W && p->H == H && p->D == D && p->batch == batch && p->prm.paths == pr.paths &&
+            p->prm.device == pr.device) {
+            p->prm = pr;
+            *out = p;
+            return FSGM_OK;
+        }
+    fsgm_epi_plan* p = nullptr;
+    fsgm_status st = fsgm_epi_plan_create(&p, W, H, D, batch, &pr);
+    if (st != FSGM_OK) return st;
+    if (g_cache.size() >= 4) {           // bound the HBM held by stale shapes
+        fsgm_epi_plan_destroy(g_cache.front());
+        g_cache.erase(g_cache.begin());
+    }
+    g_cache.push_back(p);
+    *out = p;
+    return FSGM_OK;
+}
+
+void fsgm_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (fsgm_epi_plan* p : g_cache) fsgm_epi_plan_destroy(p);
+    g_cache.clear();
+}
+
+fsgm_status fsgm_calc_cost_sgm_batch_host(int32_t n, const fsgm_epi_in* in, const fsgm_epi_out* out,
+                                          const fsgm_epi_params* prm) {
+    FSGM_REQUIRE(n >= 1 && in && out, "fsgm_calc_cost_sgm: null argument");
+    const fsgm_epi_params pr = prm ? *prm : fsgm_epi_params_default();
+    for (int i = 0; i < n; i++) {
+        FSGM_REQUIRE(in[i].I1 && in[i].I2 && in[i].pixelPosD0 && in[i].normDir && in[i].offset,
+                     "fsgm_calc_cost_sgm: frame %d has a null input", i);
+        FSGM_REQUIRE(out[i].bestD && out[i].minC, "fsgm_calc_cost_sgm: frame %d has a null output", i);
+        FSGM_REQUIRE(in[i].width == in[0].width && in[i].height == in[0].height && in[i].dMax == in[0].dMax &&
+                     in[i].P1 == in[0].P1 && in[i].P2 == in[0].P2 && in[i].vMax == in[0].vMax,
+                     "fsgm_calc_cost_sgm: frames of one batch must share shape and parameters (frame %d differs)", i);
+    }
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    fsgm_epi_plan* p = nullptr;
+    fsgm_status st = cached_plan(&p, in[0].width, in[0].height, in[0].dMax, n, pr);
+    if (st != FSGM_OK) return st;
+    if ((st = fsgm_epi_plan_set_penalties(p, in[0].P1, in[0].P2, in[0].vMax)) != FSGM_OK) return st;
+    for (int i = 0; i < n; i++)
+        if ((st = fsgm_epi_plan_upload(p, i, in[i].I1, in[i].I2, in[i].pixelPosD0, in[i].normDir, in[i].offset)) != FSGM_OK)
+            return st;
+    if ((st = fsgm_epi_plan_run(p, FSGM_STAGE_ALL)) != FSGM_OK) return st;
+    for (int i = 0; i < n; i++) {
+        if ((st = fsgm_epi_plan_download(p, i, out[i].bestD, out[i].minC)) != FSGM_OK) return st;
+        if (out[i].C && (st = fsgm_epi_plan_download_cost(p, i, out[i].C)) != FSGM_OK) return st;
+        if (out[i].S && (st = fsgm_epi_plan_download_sum(p, i, out[i].S)) != FSGM_OK) return st;
+    }
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_calc_cost_sgm_host(const fsgm_epi_in* in, const fsgm_epi_out* out, const fsgm_epi_params* prm) {
+    return fsgm_calc_cost_sgm_batch_host(1, in, out, prm);
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// epi_kernels.h -- launch interface of the calc_cost_sgm-path kernels (epi_kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define FSGM_GENERIC_MAX_D 1024
+
+namespace fsgm {
+
+struct EpiCostArgs {
+    const uint32_t* cen1;   // [frames][NP]
+    const uint32_t* cen2;
+    const double* pd0;      // [frames][2][NP]
+    const double* nd;       // [frames][2][NP]
+    const double* off;      // [frames][NP]
+    const double* vz;       // [D]  vzInd(d), tabulated on the host with the reference's expression
+    uint8_t* Craw;          // [frames][NP][D]
+    int W, H, D;
+};
+
+struct AggArgs {
+    const uint8_t* C;       // [frames] cost volumes
+    uint8_t* L;             // [frames][paths] per-path costs
+    size_t c_frame_stride;  // bytes between frames of C
+    size_t l_frame_stride;  // bytes between frames of L
+    size_t l_dir_stride;    // bytes between path slots of L (= NP*D)
+    int W, H, D;
+    int P1, P2;
+    int ndirs;              // path slots (4 or 8)
+    int blk_begin[9];       // first block of each slot, [8] = total
+    int dir_code[8];        // bits 1:0 = 0 along x, 1 along y, 2 (+1,+1), 3 (-1,+1); bit 2 = point-mirrored (pass 1)
+};
+
+struct WtaArgs {
+    const uint8_t* L;
+    size_t l_frame_stride, l_dir_stride;
+    const double* off;      // [frames][NP]
+    uint32_t* bestD;        // [frames][NP]
+    uint32_t* minC;
+    double vMax;
+    int W, H, D;
+    int ndirs;
+    int subpixel, vz_to_disp;
+};
+
+enum { AGG_PACKED_NOWRAP = 0, AGG_PACKED_WRAP = 1, AGG_GENERIC = 2 };
+
+int  agg_packed_lpp(int D);   // lanes per pixel of the packed kernels, 0 if D is not 16<<k, k<=4
+void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int H, int frames);
+void launch_epi_cost(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frames);
+void launch_aggregate(hipStream_t st, AggArgs a, int paths, int frames, int kernel_kind);
+void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
+void launch_sum_paths(hipStream_t st, const uint8_t* L, uint32_t* S, size_t n, size_t dir_stride, int ndirs);
+
+}  // namespace fsgm

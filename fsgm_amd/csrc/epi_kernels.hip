@@ -1,0 +1,587 @@
+// epi_kernels.hip -- gfx950 kernels for the calc_cost_sgm path
+// (reference: calc_cost_sgm.cpp + common.cpp; citations per kernel).
+//
+// Data layout in HBM (all per frame, frames strided):
+//   images  u8  [H][W]            census u32 [H][W]
+//   maps    f64 [2][H][W] / [H][W]
+//   cost volume C and per-path costs L_r: u8 [H][W][D], d fastest -> one pixel's D costs are
+//   D contiguous bytes (128 B at D=128 = one L2 line), read 16 B per lane.
+//
+// No MFMA anywhere: this is integer stencil / scan work bound by HBM and VALU issue.
+#include "epi_kernels.h"
+#include "fsgm_device.h"
+
+namespace fsgm {
+
+// =============================================================================================
+// census 5x5  (common.cpp:3-27): code = sum over the 25 taps, row-major from (-2,-2), of
+// (nbr >= ctr) << (25 - tap); replicate border.
+// =============================================================================================
+__global__ __launch_bounds__(256) void census5x5_kernel(const uint8_t* __restrict__ img,
+                                                        uint32_t* __restrict__ cen, int W, int H) {
+    const int NP = W * H;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    const uint8_t* im = img + (size_t)blockIdx.y * NP;
+    const int y = p / W, x = p - y * W;
+    const unsigned ctr = im[p];
+    uint32_t code = 0;
+#pragma unroll
+    for (int oy = -2; oy <= 2; oy++) {
+        const int y2 = clampi(y + oy, 0, H - 1);
+#pragma unroll
+        for (int ox = -2; ox <= 2; ox++) {
+            const int x2 = clampi(x + ox, 0, W - 1);
+            code = (code + (im[y2 * W + x2] >= ctr ? 1u : 0u)) << 1;
+        }
+    }
+    cen[(size_t)blockIdx.y * NP + p] = code;
+}
+
+// =============================================================================================
+// raw Hamming cost along the epipolar line  (calc_cost_sgm.cpp:343-381).
+// One thread = one pixel x 4 consecutive d.  fp64 geometry in the reference's association
+// order with explicit round-to-nearest mul/add (no FMA contraction).
+// =============================================================================================
+__global__ __launch_bounds__(256) void epi_rawcost_kernel(EpiCostArgs a) {
+    const int W = a.W, H = a.H, D = a.D;
+    const int NP = W * H;
+    const int Dq = (D + 3) >> 2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)NP * Dq) return;
+    const int p = (int)(gid / Dq), q = (int)(gid - (long long)p * Dq);
+    const size_t f = blockIdx.y;
+    const double* p0 = a.pd0 + f * 2 * (size_t)NP;
+    const double* nd = a.nd + f * 2 * (size_t)NP;
+    const double bx = __dsub_rn(p0[p], 1.0), by = __dsub_rn(p0[NP + p], 1.0);          // :348-349
+    const double ux = nd[p], uy = nd[NP + p];
+    const double off = a.off[f * (size_t)NP + p];
+    const uint32_t* cen1 = a.cen1 + f * (size_t)NP;
+    const uint32_t* cen2 = a.cen2 + f * (size_t)NP;
+    const uint32_t c1 = cen1[p];
+    uint8_t* out = a.Craw + f * (size_t)NP * D + (size_t)p * D + 4 * q;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int d = 4 * q + k;
+        if (d < D) {
+            const double s = __dmul_rn(off, a.vz[d]);                                      // offset * vzInd
+            const double ox = __dmul_rn(s, ux), oy = __dmul_rn(s, uy);                    // :365-366
+            int x2 = f64_to_i32_x86(round(__dadd_rn(bx, ox)));                            // :371
+            int y2 = f64_to_i32_x86(round(__dadd_rn(by, oy)));                            // :372
+            x2 = clampi(x2, 0, W - 1);
+            y2 = clampi(y2, 0, H - 1);
+            const uint32_t cost = __popc(c1 ^ cen2[y2 * W + x2]);                         // :377-378
+            packed |= cost << (8 * k);
+        }
+    }
+    if ((D & 3) == 0) {
+        *(uint32_t*)out = packed;
+    } else {
+        for (int k = 0; k < 4; k++)
+            if (4 * q + k < D) out[k] = (uint8_t)(packed >> (8 * k));
+    }
+}
+
+// =============================================================================================
+// 5x5 box mean, replicate border  (calc_cost_sgm.cpp:387-407).
+// (u8)(1.0*sum/25 + 0.5) == (2*sum + 25) / 50 in integers: the exact value has denominator 50,
+// so it is never within 1/50 of an integer from below except at the integer itself, which
+// needs 2*sum+25 (odd) divisible by 50 -- impossible.
+// One thread = one pixel x 4 consecutive d (SWAR: even/odd bytes summed in 16-bit fields).
+// =============================================================================================
+__global__ __launch_bounds__(256) void box5x5_kernel(const uint8_t* __restrict__ Craw,
+                                                     uint8_t* __restrict__ C, int W, int H, int D) {
+    const int NP = W * H;
+    const int Dq = (D + 3) >> 2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)NP * Dq) return;
+    const int p = (int)(gid / Dq), q = (int)(gid - (long long)p * Dq);
+    const int y = p / W, x = p - y * W;
+    const uint8_t* raw = Craw + (size_t)blockIdx.y * NP * D;
+    uint8_t* out = C + (size_t)blockIdx.y * NP * D + (size_t)p * D + 4 * q;
+    if ((D & 3) == 0) {
+        uint32_t se = 0, so = 0;
+#pragma unroll
+        for (int dy = -2; dy <= 2; dy++) {
+            const int y1 = clampi(y + dy, 0, H - 1);
+#pragma unroll
+            for (int dx = -2; dx <= 2; dx++) {
+                const int x1 = clampi(x + dx, 0, W - 1);
+                const uint32_t w = *(const uint32_t*)(raw + ((size_t)y1 * W + x1) * D + 4 * q);
+                se += w & 0x00FF00FFu;
+                so += (w >> 8) & 0x00FF00FFu;
+            }
+        }
+        const uint32_t b0 = (2 * (se & 0xFFFF) + 25) / 50, b2 = (2 * (se >> 16) + 25) / 50;
+        const uint32_t b1 = (2 * (so & 0xFFFF) + 25) / 50, b3 = (2 * (so >> 16) + 25) / 50;
+        *(uint32_t*)out = (b0 & 0xFF) | ((b1 & 0xFF) << 8) | ((b2 & 0xFF) << 16) | ((b3 & 0xFF) << 24);
+    } else {
+        for (int k = 0; k < 4; k++) {
+            const int d = 4 * q + k;
+            if (d >= D) break;
+            uint32_t s = 0;
+            for (int dy = -2; dy <= 2; dy++) {
+                const int y1 = clampi(y + dy, 0, H - 1);
+                for (int dx = -2; dx <= 2; dx++) {
+                    const int x1 = clampi(x + dx, 0, W - 1);
+                    s += raw[((size_t)y1 * W + x1) * D + d];
+                }
+            }
+            out[k] = (uint8_t)((2 * s + 25) / 50);
+        }
+    }
+}
+
+// =============================================================================================
+// Path aggregation, packed kernel  (calc_cost_sgm.cpp:33-66 sgm_step, :86-257 sgm).
+//
+// One launch covers every path direction of every frame.  A path direction r has lines
+// (rows for the horizontal paths, columns for the vertical ones, wrapped diagonals for the
+// oblique ones); every line is an independent serial recurrence.  Lane layout inside a wave:
+//   LPP = D/16 adjacent lanes own one pixel, 16 consecutive d each (one 16-byte load);
+//   64/LPP adjacent lines advance in lockstep in one wave.
+// The 16 costs of a lane live in 8 VGPRs as packed 2 x u16, split into even/odd bytes of each
+// loaded dword:  E[k] = (d[4k], d[4k+2]),  O[k] = (d[4k+1], d[4k+3]).  With that split the
+// d+1 neighbours of E[k] are O[k] itself and the d-1 neighbours of O[k] are E[k]; the other two
+// neighbour vectors cost one v_alignbit each, and only the two lane-boundary elements need a DPP
+// row shift.  The running minimum over d is a packed min tree + 3 DPP butterflies (LPP = 8).
+//
+// Path start (calc_cost_sgm.cpp:152-180): L = C and the stored minimum is 0 (not min C).
+// A diagonal line that leaves the image re-enters at the opposite border as a new path, so all
+// diagonal lines have H steps and a start wherever x hits the border.
+//
+// Pass 1 of the reference is the point mirror of pass 0 (:115-123), i.e. pixel index
+// NP-1-idx; d is not mirrored.
+//
+// WRAP=false requires 0<=P1, 0<=P2, max(C)+P2+max(P1,P2) <= 255: then none of the reference's
+// u8 narrowings changes a value and 16-bit lanes are exact.  WRAP=true reduces mod 256 at every
+// point where the reference narrows to unsigned char.
+// =============================================================================================
+template <int LPP, bool WRAP, int BASE>
+__device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot, const bool mirror) {
+    constexpr int PXW = 64 / LPP;       // lines per wave
+    constexpr int D = LPP * 16;
+    constexpr int PF = 4;               // prefetch depth (steps of C in flight per lane)
+    constexpr uint32_t SENT = 0xFFFFFFFFu;
+    constexpr uint32_t MASK = 0x00FF00FFu;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / LPP, j = lane % LPP;
+
+    const int W = a.W, H = a.H;
+    const int NP = W * H;
+    const int nlines = BASE == 0 ? H : W;
+    const int len = BASE == 0 ? W : H;
+    const int lg = ((int)blockIdx.x - a.blk_begin[slot]) * 4 + wave;
+    if (lg * PXW >= nlines) return;                         // wave-uniform
+    const int line = lg * PXW + g;
+    const bool valid = line < nlines;
+    const int l = valid ? line : nlines - 1;
+
+    const uint8_t* __restrict__ Cf = a.C + (size_t)blockIdx.y * a.c_frame_stride;
+    uint8_t* __restrict__ Lf = a.L + (size_t)blockIdx.y * a.l_frame_stride + (size_t)slot * a.l_dir_stride;
+
+    // forward-frame cursors: (x, pix) for the compute side, (xl, pixl) PF steps ahead for loads.
+    // pix is the pixel index in the pass-0 frame; pass 1 (mirror) addresses NP-1-pix.
+    int x = BASE >= 2 ? l : 0, pix = BASE == 0 ? l * W : l;
+    int xl = x, pixl = pix;
+
+    auto advance = [&](int& cx, int& cpix) {               // branch-free
+        if (BASE == 0) cpix += 1;
+        if (BASE == 1) cpix += W;
+        if (BASE == 2) { cx += 1; const bool wr = cx == W; cx = wr ? 0 : cx; cpix += wr ? 1 : W + 1; }
+        if (BASE == 3) { cx -= 1; const bool wr = cx < 0; cx = wr ? W - 1 : cx; cpix += wr ? 2 * W - 1 : W - 1; }
+    };
+    auto byte_off = [&](int cpix) -> uint32_t {
+        const int ap = mirror ? NP - 1 - cpix : cpix;
+        return (uint32_t)ap * D + (uint32_t)j * 16;
+    };
+
+    const uint32_t P1pk = WRAP ? (uint32_t)(a.P1 & 0xFF) * 0x10001u : (uint32_t)a.P1 * 0x10001u;
+    const uint32_t P2pk = (uint32_t)a.P2 * 0x10001u;        // NOWRAP only
+    const uint32_t P2b = (uint32_t)(a.P2 & 0xFF);           // WRAP only
+
+    uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};    // previous pixel's path costs
+    uint32_t m = 0;                                          // previous pixel's stored minimum
+
+    uint4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        if (i < len) {
+            ring[i] = *(const uint4*)(Cf + byte_off(pixl));
+            advance(xl, pixl);
+        }
+    }
+
+    for (int t0 = 0; t0 < len; t0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const int t = t0 + i;
+            if (t < len) {
+                const uint4 cw = ring[i];
+                if (t + PF < len) {
+                    ring[i] = *(const uint4*)(Cf + byte_off(pixl));
+                    advance(xl, pixl);
+                }
+                const bool start = (t == 0) || (BASE == 2 && x == 0) || (BASE == 3 && x == W - 1);
+                const uint32_t cv[4] = {cw.x, cw.y, cw.z, cw.w};
+                uint32_t CE[4], CO[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { CE[k] = cv[k] & MASK; CO[k] = (cv[k] >> 8) & MASK; }
+
+                // lane-boundary neighbours
+                uint32_t prevO3 = dpp_mov<DPP_ROW_SHR1>(SENT, LO[3]);
+                uint32_t nextE0 = dpp_mov<DPP_ROW_SHL1>(SENT, LE[0]);
+                if (j == 0) prevO3 = SENT;                   // d = 0 has no d-1      (:47)
+                if (j == LPP - 1) nextE0 = SENT;             // d = D-1 has no d+1    (:48)
+
+                const uint32_t mpk = m | (m << 16);
+                uint32_t NE[4], NO[4];
+                if (!WRAP) {
+                    const uint32_t p2lane = start ? 0u : P2pk;   // min(.,0)=0 -> L = C at a path start
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t nbE = pk_min(align16(LO[k], k ? LO[k - 1] : prevO3), LO[k]);
+                        const uint32_t nbO = pk_min(LE[k], align16(k < 3 ? LE[k + 1] : nextE0, LE[k]));
+                        const uint32_t tE = pk_min(LE[k], pk_add(nbE, P1pk));
+                        const uint32_t tO = pk_min(LO[k], pk_add(nbO, P1pk));
+                        // C + min(t, m+P2) - m  ==  C + min(t-m, P2)   (no wrap: t >= m)
+                        NE[k] = pk_add(CE[k], pk_min(pk_sub(tE, mpk), p2lane));
+                        NO[k] = pk_add(CO[k], pk_min(pk_sub(tO, mpk), p2lane));
+                    }
+                } else {
+                    const uint32_t jump = (m + P2b) & 0xFFu;                       // :46 u8(LpreMin + P2)
+                    const uint32_t jpk = jump | (jump << 16);
+                    // mod-256 adds do not commute with min: narrow each neighbour + P1 first (:47-48),
+                    // and give the two non-existent neighbours the neutral candidate 255.
+                    const uint32_t noL = j == 0 ? 0x000000FFu : 0u;
+                    const uint32_t noR = j == LPP - 1 ? 0x00FF0000u : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t lE = align16(LO[k], k ? LO[k - 1] : prevO3);          // d-1 of E[k]
+                        const uint32_t rO = align16(k < 3 ? LE[k + 1] : nextE0, LE[k]);      // d+1 of O[k]
+                        uint32_t cEl = pk_add(lE, P1pk) & MASK;
+                        uint32_t cOr = pk_add(rO, P1pk) & MASK;
+                        if (k == 0) cEl |= noL;
+                        if (k == 3) cOr |= noR;
+                        const uint32_t cEr = pk_add(LO[k], P1pk) & MASK;                     // d+1 of E[k] = O[k]
+                        const uint32_t cOl = pk_add(LE[k], P1pk) & MASK;                     // d-1 of O[k] = E[k]
+                        const uint32_t tE = pk_min(pk_min(LE[k], jpk), pk_min(cEl, cEr));
+                        const uint32_t tO = pk_min(pk_min(LO[k], jpk), pk_min(cOl, cOr));
+                        const uint32_t e = pk_sub(pk_add(CE[k], tE), mpk) & MASK;  // :60 mod 256
+                        const uint32_t o = pk_sub(pk_add(CO[k], tO), mpk) & MASK;
+                        NE[k] = start ? CE[k] : e;
+                        NO[k] = start ? CO[k] : o;
+                    }
+                }
+                // minimum over d of the new costs (:61,:65); 0 at a path start (:154,:164)
+                uint32_t mm = pk_min(pk_min(pk_min(NE[0], NO[0]), pk_min(NE[1], NO[1])),
+                                     pk_min(pk_min(NE[2], NO[2]), pk_min(NE[3], NO[3])));
+                uint32_t mx = min(mm & 0xFFFFu, mm >> 16);
+                mx = group_min_u32<LPP>(mx);
+                m = start ? 0u : mx;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { LE[k] = NE[k]; LO[k] = NO[k]; }
+
+                if (valid) {
+                    uint4 o;
+                    o.x = NE[0] | (NO[0] << 8); o.y = NE[1] | (NO[1] << 8);
+                    o.z = NE[2] | (NO[2] << 8); o.w = NE[3] | (NO[3] << 8);
+                    *(uint4*)(Lf + byte_off(pix)) = o;
+                }
+                advance(x, pix);
+            }
+        }
+    }
+}
+
+template <int LPP, bool WRAP>
+__global__ __launch_bounds__(256) void agg_packed_kernel(AggArgs a) {
+    // which direction slot does this block belong to (block-uniform)
+    int slot = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++)
+        if (i < a.ndirs && (int)blockIdx.x >= a.blk_begin[i]) slot = i;
+    const int code = a.dir_code[slot];
+    const bool mirror = (code & 4) != 0;
+    switch (code & 3) {                 // 0: along x, 1: along y, 2: x+1,y+1, 3: x-1,y+1
+        case 0: agg_packed_body<LPP, WRAP, 0>(a, slot, mirror); break;
+        case 1: agg_packed_body<LPP, WRAP, 1>(a, slot, mirror); break;
+        case 2: agg_packed_body<LPP, WRAP, 2>(a, slot, mirror); break;
+        default: agg_packed_body<LPP, WRAP, 3>(a, slot, mirror); break;
+    }
+}
+
+// =============================================================================================
+// Path aggregation, generic kernel: any D (<= FSGM_GENERIC_MAX_D), exact u8 semantics.
+// One wave per line, Lpre/Lcur in LDS, lanes stride over d.  Correctness path for disparity
+// ranges the packed kernel does not cover; not tuned.
+// =============================================================================================
+__global__ __launch_bounds__(256) void agg_generic_kernel(AggArgs a) {
+    __shared__ uint8_t sL[4][2][FSGM_GENERIC_MAX_D + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int slot = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++)
+        if (i < a.ndirs && (int)blockIdx.x >= a.blk_begin[i]) slot = i;
+    const int code = a.dir_code[slot];
+    const int base = code & 3;
+    const bool mirror = (code & 4) != 0;
+    const int W = a.W, H = a.H, D = a.D;
+    const int NP = W * H;
+    const int nlines = base == 0 ? H : W;
+    const int len = base == 0 ? W : H;
+    const int line = ((int)blockIdx.x - a.blk_begin[slot]) * 4 + wave;
+    if (line >= nlines) return;                              // wave-uniform
+    const uint8_t* __restrict__ Cf = a.C + (size_t)blockIdx.y * a.c_frame_stride;
+    uint8_t* __restrict__ Lf = a.L + (size_t)blockIdx.y * a.l_frame_stride + (size_t)slot * a.l_dir_stride;
+    int x = base >= 2 ? line : 0, pix = base == 0 ? line * W : line;
+    const int dpix = base == 0 ? 1 : (base == 1 ? W : (base == 2 ? W + 1 : W - 1));
+    uint8_t* pre = sL[wave][0];
+    uint8_t* cur = sL[wave][1];
+    uint32_t m = 0;
+    for (int t = 0; t < len; t++) {
+        const bool start = (t == 0) || (base == 2 && x == 0) || (base == 3 && x == W - 1);
+        const size_t off = (size_t)(mirror ? NP - 1 - pix : pix) * D;
+        uint32_t lo = 255;
+        const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
+        for (int d = lane; d < D; d += 64) {
+            const uint32_t c = Cf[off + d];
+            uint32_t v;
+            if (start) {
+                v = c;
+            } else {
+                uint32_t best = min(jump, (uint32_t)pre[d]);
+                if (d > 0) best = min(best, ((uint32_t)pre[d - 1] + (uint32_t)a.P1) & 0xFF);
+                if (d < D - 1) best = min(best, ((uint32_t)pre[d + 1] + (uint32_t)a.P1) & 0xFF);
+                v = (c + best - m) & 0xFF;
+            }
+            cur[d] = (uint8_t)v;
+            Lf[off + d] = (uint8_t)v;
+            lo = min(lo, v);
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, s));
+        m = start ? 0u : lo;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): LDS writes visible to the wave
+        uint8_t* tmp = pre; pre = cur; cur = tmp;
+        pix += dpix;
+        if (base == 2) { x++; if (x == W) { x = 0; pix -= W; } }
+        else if (base == 3) { x--; if (x < 0) { x = W - 1; pix += W; } }
+    }
+}
+
+// =============================================================================================
+// S = sum over paths (debug tap of the reference's Sp, calc_cost_sgm.cpp:227-232)
+// =============================================================================================
+__global__ __launch_bounds__(256) void sum_paths_kernel(const uint8_t* __restrict__ L, uint32_t* __restrict__ S,
+                                                        size_t n, size_t dir_stride, int ndirs) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = 0;
+    for (int r = 0; r < ndirs; r++) s += L[r * dir_stride + i];
+    S[i] = s;
+}
+
+// =============================================================================================
+// WTA + sub-pixel + vz->disparity  (calc_cost_sgm.cpp:259-308, :414-426), shared tail.
+// c_1, c, c1 are S[best-1], S[best], S[best+1] (u32 in the reference).
+// =============================================================================================
+__device__ __forceinline__ void wta_finish(const WtaArgs& a, size_t f, int p, uint32_t best, uint32_t minc,
+                                           uint32_t c_1, uint32_t c1) {
+    const size_t NP = (size_t)a.W * a.H;
+    uint32_t bd = best;
+    if (a.subpixel) {
+        if (best > 1 && best < (uint32_t)a.D) {                                   // :293
+            const double dc_1 = (double)c_1, dc = (double)minc, dc1 = (double)c1;
+            double sub = (double)best;
+            if (dc1 < dc_1) sub = __dadd_rn(sub, __ddiv_rn(__ddiv_rn(__dsub_rn(dc1, dc_1), __dsub_rn(dc, dc_1)), 2.0));   // :299
+            else            sub = __dadd_rn(sub, __ddiv_rn(__ddiv_rn(__dsub_rn(dc1, dc_1), __dsub_rn(dc, dc1)), 2.0));    // :301
+            bd = f64_to_u32_x86(__dmul_rn(sub, 256.0));                           // :303
+        } else {
+            bd = best * 256u;                                                     // :305
+        }
+    }
+    if (a.vz_to_disp) {                                                           // :414-426
+        const double d = __ddiv_rn((double)bd, 256.0);
+        const double r = __dmul_rn(__ddiv_rn(d, (double)(a.D + 1)), a.vMax);
+        const double vz = __ddiv_rn(r, __dsub_rn(1.0, r));
+        bd = f64_to_u32_x86(__dmul_rn(__dmul_rn(a.off[f * NP + p], vz), 256.0));
+    }
+    a.bestD[f * NP + p] = bd;
+    a.minC[f * NP + p] = minc;
+}
+
+__device__ __forceinline__ uint32_t sum_at(const uint8_t* Lf, size_t dir_stride, int ndirs, size_t idx) {
+    uint32_t s = 0;
+    for (int r = 0; r < ndirs; r++) s += Lf[r * dir_stride + idx];
+    return s;
+}
+
+// packed WTA: LPP lanes per pixel, 16 d per lane; sums kept as 2 x u16 (8 paths x 255 < 65536)
+template <int LPP>
+__global__ __launch_bounds__(256) void wta_packed_kernel(WtaArgs a) {
+    constexpr int D = LPP * 16;
+    constexpr int PPB = 256 / LPP;                           // pixels per block
+    constexpr uint32_t MASK = 0x00FF00FFu;
+    __shared__ uint32_t sS[256 * 8];                         // u16 S[PPB][D]
+    const int tid = threadIdx.x;
+    const int NP = a.W * a.H;
+    const int gp = blockIdx.x * PPB + tid / LPP, j = tid % LPP;
+    const bool valid = gp < NP;
+    const int p = valid ? gp : NP - 1;
+    const size_t f = blockIdx.y;
+    const uint8_t* __restrict__ Lf = a.L + f * a.l_frame_stride;
+    uint32_t E[4] = {0, 0, 0, 0}, O[4] = {0, 0, 0, 0};
+    const size_t off = (size_t)p * D + (size_t)j * 16;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (r < a.ndirs) {
+            const uint4 v = *(const uint4*)(Lf + (size_t)r * a.l_dir_stride + off);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) { E[k] += w[k] & MASK; O[k] += (w[k] >> 8) & MASK; }
+        }
+    }
+    // S to LDS in natural d order; key = (S << 8) | d, minimum key = first minimum (:267)
+    uint32_t key = 0xFFFFFFFFu;
+    uint32_t* row = sS + (size_t)(tid / LPP) * (D / 2) + j * 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t s0 = E[k] & 0xFFFF, s1 = O[k] & 0xFFFF, s2 = E[k] >> 16, s3 = O[k] >> 16;
+        row[2 * k] = s0 | (s1 << 16);
+        row[2 * k + 1] = s2 | (s3 << 16);
+        const uint32_t d0 = (uint32_t)j * 16 + 4 * k;
+        key = min(key, min(min((s0 << 8) | d0, (s1 << 8) | (d0 + 1)), min((s2 << 8) | (d0 + 2), (s3 << 8) | (d0 + 3))));
+    }
+    key = group_min_u32<LPP>(key);
+    __syncthreads();
+    if (j == 0 && valid) {
+        const uint32_t best = key & 0xFF, minc = key >> 8;
+        const uint16_t* srow = (const uint16_t*)(sS + (size_t)(tid / LPP) * (D / 2));
+        uint32_t c_1 = 0, c1 = 0;
+        if (a.subpixel && best > 1) {
+            c_1 = srow[best - 1];
+            if (best + 1 < (uint32_t)D) c1 = srow[best + 1];
+            else if (p + 1 < NP) c1 = sum_at(Lf, a.l_dir_stride, a.ndirs, (size_t)(p + 1) * D);   // next pixel's d=0 (:296)
+            else c1 = 0;                                      // past the end of Sp: defined as 0 here
+        }
+        wta_finish(a, f, p, best, minc, c_1, c1);
+    }
+}
+
+// generic WTA: one wave per pixel, lanes stride over d
+__global__ __launch_bounds__(256) void wta_generic_kernel(WtaArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NP = a.W * a.H, D = a.D;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= NP) return;
+    const size_t f = blockIdx.y;
+    const uint8_t* __restrict__ Lf = a.L + f * a.l_frame_stride;
+    uint32_t key = 0xFFFFFFFFu;
+    for (int d = lane; d < D; d += 64) {
+        const uint32_t s = sum_at(Lf, a.l_dir_stride, a.ndirs, (size_t)p * D + d);
+        key = min(key, (s << 12) | (uint32_t)d);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, s));
+    if (lane == 0) {
+        const uint32_t best = key & 0xFFF, minc = key >> 12;
+        uint32_t c_1 = 0, c1 = 0;
+        if (a.subpixel && best > 1) {
+            c_1 = sum_at(Lf, a.l_dir_stride, a.ndirs, (size_t)p * D + best - 1);
+            if ((size_t)p * D + best + 1 < (size_t)NP * D) c1 = sum_at(Lf, a.l_dir_stride, a.ndirs, (size_t)p * D + best + 1);
+        }
+        wta_finish(a, f, p, best, minc, c_1, c1);
+    }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int H, int frames) {
+    dim3 grid((W * H + 255) / 256, frames);
+    hipLaunchKernelGGL(census5x5_kernel, grid, dim3(256), 0, st, img, cen, W, H);
+}
+
+void launch_epi_cost(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frames) {
+    const long long n = (long long)a.W * a.H * ((a.D + 3) / 4);
+    dim3 grid((unsigned)((n + 255) / 256), frames);
+    hipLaunchKernelGGL(epi_rawcost_kernel, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(box5x5_kernel, grid, dim3(256), 0, st, (const uint8_t*)a.Craw, C, a.W, a.H, a.D);
+}
+
+int agg_packed_lpp(int D) {
+    switch (D) { case 16: return 1; case 32: return 2; case 64: return 4; case 128: return 8; case 256: return 16; }
+    return 0;
+}
+
+// Fill blk_begin / dir_code for `paths` directions.  Long (horizontal) lines first so that the
+// W-step chains start before the H-step ones.
+static void plan_dirs(AggArgs& a, int paths, int lines_per_block) {
+    static const int order8[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    static const int order4[4] = {0, 4, 1, 5};
+    a.ndirs = paths;
+    int acc = 0;
+    for (int i = 0; i < paths; i++) {
+        const int code = paths == 8 ? order8[i] : order4[i];
+        a.dir_code[i] = code;
+        a.blk_begin[i] = acc;
+        const int nlines = (code & 3) == 0 ? a.H : a.W;
+        acc += (nlines + lines_per_block - 1) / lines_per_block;
+    }
+    for (int i = paths; i <= 8; i++) a.blk_begin[i] = acc;
+    for (int i = paths; i < 8; i++) a.dir_code[i] = 0;
+}
+
+template <int LPP>
+static void launch_packed(hipStream_t st, AggArgs& a, int paths, int frames, bool wrap) {
+    plan_dirs(a, paths, 4 * (64 / LPP));
+    dim3 grid(a.blk_begin[8], frames);
+    if (wrap) hipLaunchKernelGGL((agg_packed_kernel<LPP, true>), grid, dim3(256), 0, st, a);
+    else      hipLaunchKernelGGL((agg_packed_kernel<LPP, false>), grid, dim3(256), 0, st, a);
+}
+
+void launch_aggregate(hipStream_t st, AggArgs a, int paths, int frames, int kernel_kind) {
+    if (kernel_kind == AGG_GENERIC) {
+        plan_dirs(a, paths, 4);
+        dim3 grid(a.blk_begin[8], frames);
+        hipLaunchKernelGGL(agg_generic_kernel, grid, dim3(256), 0, st, a);
+        return;
+    }
+    const bool wrap = kernel_kind == AGG_PACKED_WRAP;
+    switch (agg_packed_lpp(a.D)) {
+        case 1: launch_packed<1>(st, a, paths, frames, wrap); break;
+        case 2: launch_packed<2>(st, a, paths, frames, wrap); break;
+        case 4: launch_packed<4>(st, a, paths, frames, wrap); break;
+        case 8: launch_packed<8>(st, a, paths, frames, wrap); break;
+        case 16: launch_packed<16>(st, a, paths, frames, wrap); break;
+        default: break;
+    }
+}
+
+void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed) {
+    const int NP = a.W * a.H;
+    if (packed) {
+        const int lpp = agg_packed_lpp(a.D);
+        dim3 grid((NP + 256 / lpp - 1) / (256 / lpp), frames);
+        switch (lpp) {
+            case 1: hipLaunchKernelGGL(wta_packed_kernel<1>, grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL(wta_packed_kernel<2>, grid, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL(wta_packed_kernel<4>, grid, dim3(256), 0, st, a); break;
+            case 8: hipLaunchKernelGGL(wta_packed_kernel<8>, grid, dim3(256), 0, st, a); break;
+            case 16: hipLaunchKernelGGL(wta_packed_kernel<16>, grid, dim3(256), 0, st, a); break;
+        }
+    } else {
+        dim3 grid((NP + 3) / 4, frames);
+        hipLaunchKernelGGL(wta_generic_kernel, grid, dim3(256), 0, st, a);
+    }
+}
+
+void launch_sum_paths(hipStream_t st, const uint8_t* L, uint32_t* S, size_t n, size_t dir_stride, int ndirs) {
+    hipLaunchKernelGGL(sum_paths_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, L, S, n, dir_stride, ndirs);
+}
+
+}  // namespace fsgm

@@ -1,0 +1,64 @@
+// fsgm_device.h -- shared device-side helpers for the gfx950 kernels.
+// wave = 64 lanes; all lane-group tricks below assume it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fsgm {
+
+// ---- x86-64 gcc double->integer conversions (cvttsd2si).  The reference is C++ built for
+// x86-64; out-of-range and NaN inputs give the "integer indefinite" there, whereas the gfx950
+// v_cvt_* instructions saturate.  Bit-exact parity needs the former.
+__device__ __forceinline__ int32_t f64_to_i32_x86(double v) {
+    return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN;
+}
+__device__ __forceinline__ int64_t f64_to_i64_x86(double v) {
+    return (v >= -9223372036854775808.0 && v < 9223372036854775808.0) ? (int64_t)v : INT64_MIN;
+}
+__device__ __forceinline__ uint32_t f64_to_u32_x86(double v) { return (uint32_t)(uint64_t)f64_to_i64_x86(v); }
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, max(lo, v)); }
+
+// ---- packed 2 x u16 arithmetic (VOP3P v_pk_*_u16) ----
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    u16x2 r = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    u16x2 r = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+    u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+// {hi:lo} >> 16, low 32 bits  ==  (lo >> 16) | (hi << 16)      (v_alignbit_b32)
+__device__ __forceinline__ uint32_t align16(uint32_t hi, uint32_t lo) {
+    return __builtin_amdgcn_alignbit(hi, lo, 16);
+}
+
+// ---- DPP controls (gfx9 encoding) ----
+constexpr int DPP_QUAD_1032 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_2301 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_SHL1 = 0x101;        // lane i <- lane i+1 (within a row of 16)
+constexpr int DPP_ROW_SHR1 = 0x111;        // lane i <- lane i-1
+constexpr int DPP_ROW_MIRROR = 0x140;      // i <-> 15-i
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // i <-> 7-i within each half row
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
+}
+
+// min over a group of G adjacent lanes (G = 1,2,4,8,16, group aligned), result in every lane
+template <int G>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t x) {
+    if (G >= 2)  x = min(x, dpp_mov<DPP_QUAD_1032>(x, x));
+    if (G >= 4)  x = min(x, dpp_mov<DPP_QUAD_2301>(x, x));
+    if (G >= 8)  x = min(x, dpp_mov<DPP_ROW_HALF_MIRROR>(x, x));
+    if (G >= 16) x = min(x, dpp_mov<DPP_ROW_MIRROR>(x, x));
+    return x;
+}
+
+}  // namespace fsgm

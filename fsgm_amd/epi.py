@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's calc_cost_sgm MEX interface (calc_cost_sgm.cpp:539-598,
+called from epipolar_sgm_of.m:45), on top of the C ABI.
+
+Array convention = the MEX's memory order (include/fsgm.h): what MATLAB passes as a
+width x height column-major matrix is here a C-contiguous numpy array of shape (height, width);
+width x height x 2 maps are (2, height, width).
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import EpiParams, EpiIn, EpiOut, check, ptr
+
+
+def _u8img(a, name):
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise TypeError(f"{name} must be a 2-D uint8 array (got {a.dtype}, ndim {a.ndim})")
+    return np.ascontiguousarray(a)
+
+
+def _f64(a, shape, name):
+    a = np.asarray(a)
+    if a.dtype != np.float64 or a.shape != shape:
+        raise TypeError(f"{name} must be float64 of shape {shape} (got {a.dtype} {a.shape})")
+    return np.ascontiguousarray(a)
+
+
+def _params(paths, subpixel, vz_to_disp, device):
+    p = EpiParams()
+    p.paths, p.subpixel, p.vz_to_disp, p.device = int(paths), int(subpixel), int(vz_to_disp), int(device)
+    return p
+
+
+def calc_cost_sgm_batch(frames, dMax, vMax, P1, P2, *, paths=4, subpixel=1, vz_to_disp=1, device=0,
+                        return_volumes=False):
+    """frames: list of (I1, I2, pixelPosD0, normDir, offset) of one shape, processed concurrently."""
+    lib = _lib.load()
+    n = len(frames)
+    if n == 0:
+        return []
+    ins, outs, keep, res = (EpiIn * n)(), (EpiOut * n)(), [], []
+    H, W = np.asarray(frames[0][0]).shape
+    D = int(dMax)
+    for i, (I1, I2, pd0, nd, off) in enumerate(frames):
+        I1, I2 = _u8img(I1, "I1"), _u8img(I2, "I2")
+        if I1.shape != (H, W) or I2.shape != (H, W):
+            raise ValueError("all images of a batch must share one shape")
+        pd0 = _f64(pd0, (2, H, W), "pixelPosD0")
+        nd = _f64(nd, (2, H, W), "normlizeDirection")
+        off = _f64(off, (H, W), "offsetFromPosD0")
+        bestD = np.zeros((H, W), np.uint32)
+        minC = np.zeros((H, W), np.uint32)
+        Cv = np.zeros((H, W, D), np.uint8) if return_volumes else None
+        Sv = np.zeros((H, W, D), np.uint32) if return_volumes else None
+        keep.append((I1, I2, pd0, nd, off))
+        e = ins[i]
+        e.I1, e.I2, e.width, e.height, e.dMax, e.vMax = ptr(I1), ptr(I2), W, H, D, float(vMax)
+        e.pixelPosD0, e.normDir, e.offset, e.P1, e.P2 = ptr(pd0), ptr(nd), ptr(off), int(P1), int(P2)
+        o = outs[i]
+        o.bestD, o.minC, o.C, o.S = ptr(bestD), ptr(minC), ptr(Cv), ptr(Sv)
+        res.append((bestD, minC, Cv, Sv) if return_volumes else (bestD, minC))
+    prm = _params(paths, subpixel, vz_to_disp, device)
+    check(lib.fsgm_calc_cost_sgm_batch_host(n, ins, outs, C.byref(prm)))
+    return res
+
+
+def calc_cost_sgm(I1, I2, dMax, vMax, pixelPosD0, normlizeDirection, offsetFromPosD0, P1, P2, *,
+                  paths=4, subpixel=1, vz_to_disp=1, device=0, return_volumes=False):
+    """[bestD, minC] = calc_cost_sgm(I1, I2, dMax, vMax, pixelPosD0, normlizeDirection,
+    offsetFromPosD0, P1, P2)  -- same argument order and meaning as the MEX.
+
+    Keyword arguments are the reference's compile-time switches (defaults = as shipped).
+    """
+    return calc_cost_sgm_batch([(I1, I2, pixelPosD0, normlizeDirection, offsetFromPosD0)], dMax, vMax, P1, P2,
+                               paths=paths, subpixel=subpixel, vz_to_disp=vz_to_disp, device=device,
+                               return_volumes=return_volumes)[0]
+
+
+class EpiPlan:
+    """Device-resident plan: `batch` frames of width x height x dMax stay in HBM across calls."""
+
+    def __init__(self, width, height, dMax, batch=1, *, paths=4, subpixel=1, vz_to_disp=1, device=0):
+        self.lib = _lib.load()
+        self.W, self.H, self.D, self.batch, self.paths = int(width), int(height), int(dMax), int(batch), int(paths)
+        self._h = C.c_void_p()
+        prm = _params(paths, subpixel, vz_to_disp, device)
+        check(self.lib.fsgm_epi_plan_create(C.byref(self._h), self.W, self.H, self.D, self.batch, C.byref(prm)))
+
+    def close(self):
+        if self._h:
+            self.lib.fsgm_epi_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_penalties(self, P1, P2, vMax=0.3):
+        check(self.lib.fsgm_epi_plan_set_penalties(self._h, int(P1), int(P2), float(vMax)))
+
+    def upload(self, frame, I1, I2, pd0, nd, off):
+        I1, I2 = _u8img(I1, "I1"), _u8img(I2, "I2")
+        pd0 = _f64(pd0, (2, self.H, self.W), "pixelPosD0")
+        nd = _f64(nd, (2, self.H, self.W), "normlizeDirection")
+        off = _f64(off, (self.H, self.W), "offsetFromPosD0")
+        check(self.lib.fsgm_epi_plan_upload(self._h, frame, ptr(I1), ptr(I2), ptr(pd0), ptr(nd), ptr(off)))
+
+    def upload_cost(self, frame, Cvol):
+        Cvol = np.ascontiguousarray(Cvol)
+        if Cvol.dtype != np.uint8 or Cvol.shape != (self.H, self.W, self.D):
+            raise TypeError(f"C must be uint8 of shape {(self.H, self.W, self.D)}")
+        check(self.lib.fsgm_epi_plan_upload_cost(self._h, frame, ptr(Cvol)))
+
+    def upload_offset(self, frame, off):
+        off = _f64(off, (self.H, self.W), "offsetFromPosD0")
+        check(self.lib.fsgm_epi_plan_upload_offset(self._h, frame, ptr(off)))
+
+    def run(self, stages=_lib.STAGE_ALL):
+        check(self.lib.fsgm_epi_plan_run(self._h, int(stages)))
+
+    def sync(self):
+        check(self.lib.fsgm_epi_plan_sync(self._h))
+
+    def download(self, frame):
+        bestD = np.empty((self.H, self.W), np.uint32)
+        minC = np.empty((self.H, self.W), np.uint32)
+        check(self.lib.fsgm_epi_plan_download(self._h, frame, ptr(bestD), ptr(minC)))
+        return bestD, minC
+
+    def download_cost(self, frame):
+        Cv = np.empty((self.H, self.W, self.D), np.uint8)
+        check(self.lib.fsgm_epi_plan_download_cost(self._h, frame, ptr(Cv)))
+        return Cv
+
+    def download_sum(self, frame):
+        S = np.empty((self.H, self.W, self.D), np.uint32)
+        check(self.lib.fsgm_epi_plan_download_sum(self._h, frame, ptr(S)))
+        return S
+
+    def time(self, stages, warmup=2, iters=10):
+        ms = C.c_float()
+        check(self.lib.fsgm_epi_plan_time(self._h, int(stages), int(warmup), int(iters), C.byref(ms)))
+        return float(ms.value)
+
+    @property
+    def kernel_name(self):
+        return self.lib.fsgm_epi_plan_kernel_name(self._h).decode()

@@ -1,0 +1,75 @@
+"""Deterministic synthetic inputs of KITTI shape: the same arrays on every
+machine, no dataset needed.  Counter-based generator (splitmix64 of seed+index) so values do not
+depend on numpy's RNG version.
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed, n, offset=0):
+    """n pseudo-random uint64, element i = splitmix64 finaliser of (seed * 2^32 + offset + i)."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(n, dtype=np.uint64) + np.uint64(offset) + (np.uint64(seed) << np.uint64(32)))
+        z = (z + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform_u8(seed, shape, hi=255):
+    """uint8 uniform in [0, hi]."""
+    n = int(np.prod(shape))
+    return ((splitmix64(seed, n) >> np.uint64(33)) % np.uint64(hi + 1)).astype(np.uint8).reshape(shape)
+
+
+def uniform_f64(seed, shape):
+    """float64 uniform in [0, 1) with 53 random bits."""
+    n = int(np.prod(shape))
+    return ((splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) / float(1 << 53)).reshape(shape)
+
+
+def image_pair(W, H, D, seed=1):
+    """I1 = 3x3 box-smoothed u8 noise, I2[y][x] = I1[y][min(W-1, x + s(x,y))], smooth shift s in [0, D/2)."""
+    noise = uniform_u8(seed, (H, W)).astype(np.int32)
+    pad = np.pad(noise, 1, mode="edge")
+    acc = np.zeros((H, W), np.int32)
+    for dy in range(3):
+        for dx in range(3):
+            acc += pad[dy:dy + H, dx:dx + W]
+    I1 = (acc // 9).astype(np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    s = ((np.sin(xx / 97.0) * np.cos(yy / 61.0) * 0.5 + 0.5) * (D / 2 - 1)).astype(np.int64)
+    xs = np.minimum(W - 1, xx + s)
+    I2 = I1[yy, xs]
+    return np.ascontiguousarray(I1), np.ascontiguousarray(I2)
+
+
+def epi_maps(W, H, kind="axis", seed=7):
+    """pixelPosD0 (2,H,W), normlizeDirection (2,H,W), offsetFromPosD0 (H,W).
+
+    'axis'   : the survey's timing inputs -- Pd0=(x+1,y+1), direction (-1,0), offset 200.
+    'general': fractional start positions, a rotating unit-direction field and a varying offset,
+               so that both coordinates, round-half cases and clamping are exercised.
+    """
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    pd0 = np.stack([xx + 1.0, yy + 1.0])
+    if kind == "axis":
+        nd = np.stack([-np.ones((H, W)), np.zeros((H, W))])
+        off = np.full((H, W), 200.0)
+    elif kind == "general":
+        jit = uniform_f64(seed, (2, H, W)) - 0.5
+        jit[0, ::3, ::5] = 0.5                      # exact .5 cases for round-half-away-from-zero
+        jit[1, ::4, ::7] = -0.5
+        pd0 = pd0 + jit
+        ang = 0.9 * np.sin(xx / 53.0) + 1.3 * np.cos(yy / 37.0) + 2.0 * uniform_f64(seed + 1, (H, W))
+        nd = np.stack([np.cos(ang), np.sin(ang)])
+        off = 40.0 + 400.0 * uniform_f64(seed + 2, (H, W))
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(pd0), np.ascontiguousarray(nd), np.ascontiguousarray(off)
+
+
+def cost_volume(W, H, D, seed=3, cmax=24):
+    """u8 uniform in [0, cmax] of shape (H, W, D): aggregation-only input."""
+    return uniform_u8(seed, (H, W, D), hi=cmax)

@@ -1,0 +1,134 @@
+/*
+ * fsgm.h -- C ABI of libfsgm_hip.so: fSGM's matching-cost + multi-path SGM hot path on
+ * AMD Instinct MI355X (gfx950, hand-written HIP).
+ *
+ * This is the drop-in boundary.  Every entry point below replaces one function of the
+ * reference's MEX layer (file:line cited per function, relative to the fSGM tree).  The four
+ * mexFunction gateways in fsgm_amd/mex/ are thin shims over the *_host entry points: host
+ * pointers in, host pointers out, plain C types only, nothing of torch/HIP in a signature
+ * (streams travel as void*).
+ *
+ * Memory order is the reference's native order, i.e. what MATLAB hands a MEX after the
+ * drivers' permute([2 1 3]) (epipolar_sgm_of.m:33-43, pyramidal_sgm.m:44-46, ng_sgm.m:15-17):
+ *   images  u8  [height][width]        x fastest      (MATLAB: width x height, column-major)
+ *   maps    f64 [plane][height][width] plane 0 = x    (MATLAB: width x height x 2)
+ *   volumes u8  [height][width][D]     d fastest      (calc_cost_sgm.cpp:345,389)
+ *
+ * There is NO CPU fallback in this library: every compute entry point needs a HIP device and
+ * fails with FSGM_ERR_HIP when there is none.
+ */
+#ifndef FSGM_H
+#define FSGM_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSGM_VERSION_MAJOR 0
+#define FSGM_VERSION_MINOR 1
+
+typedef enum {
+    FSGM_OK = 0,
+    FSGM_ERR_INVALID = 1,      /* bad argument (null pointer, size, class) -- the reference validates nothing */
+    FSGM_ERR_HIP = 2,          /* HIP runtime error / no device */
+    FSGM_ERR_NOMEM = 3,
+    FSGM_ERR_UNSUPPORTED = 4
+} fsgm_status;
+
+/* Thread-local text of the last error returned on this thread. */
+const char* fsgm_last_error(void);
+/* Number of HIP devices visible (0 if none / no runtime). */
+int fsgm_device_count(void);
+/* "gfx950"-style arch string of a device, written into buf. */
+fsgm_status fsgm_device_arch(int device, char* buf, size_t buflen);
+/* Free every cached plan / HBM buffer held for the *_host entry points (mexAtExit hook). */
+void fsgm_shutdown(void);
+
+/* ------------------------------------------------------------------------------------------
+ * calc_cost_sgm  (calc_cost_sgm.cpp:539-598, called from epipolar_sgm_of.m:45)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Run-time form of the reference's compile-time switches.  fsgm_epi_params_default() returns
+ * the shipped values. */
+typedef struct {
+    int32_t paths;        /* 4 = as shipped (enableDiagnalPath=false, calc_cost_sgm.cpp:104); 8 = with diagonals */
+    int32_t subpixel;     /* 1 = as shipped (subPixelRefine=true, calc_cost_sgm.cpp:560) */
+    int32_t vz_to_disp;   /* 1 = as shipped (USE_VZIND, calc_cost_sgm.cpp:4,592-594) */
+    int32_t device;       /* HIP device ordinal */
+} fsgm_epi_params;
+
+fsgm_epi_params fsgm_epi_params_default(void);
+
+typedef struct {
+    const uint8_t* I1;            /* prhs[0]  u8 [H][W] */
+    const uint8_t* I2;            /* prhs[1] */
+    int32_t width, height;        /* mxGetM / mxGetN of prhs[0] (calc_cost_sgm.cpp:562-563) */
+    int32_t dMax;                 /* prhs[2] */
+    double  vMax;                 /* prhs[3] */
+    const double* pixelPosD0;     /* prhs[4]  f64 [2][H][W], 1-based coordinates */
+    const double* normDir;        /* prhs[5]  f64 [2][H][W] */
+    const double* offset;         /* prhs[6]  f64 [H][W] */
+    int32_t P1, P2;               /* prhs[7], prhs[8] (truncated to int like mxGetScalar -> int) */
+} fsgm_epi_in;
+
+typedef struct {
+    uint32_t* bestD;              /* plhs[0]  u32 [H][W], disparity * 256 */
+    uint32_t* minC;               /* plhs[1]  u32 [H][W] */
+    /* optional debug taps (NULL = not wanted): the cost volume C (u8 [H][W][D]) and the summed
+     * path costs S (u32 [H][W][D]) -- internal arrays of the reference (calc_cost_sgm.cpp:579,95) */
+    uint8_t*  C;
+    uint32_t* S;
+} fsgm_epi_out;
+
+/* One frame, host pointers in / host pointers out.  This is what the calc_cost_sgm gateway
+ * calls. */
+fsgm_status fsgm_calc_cost_sgm_host(const fsgm_epi_in* in, const fsgm_epi_out* out,
+                                    const fsgm_epi_params* prm);
+
+/* A batch of independent frames of identical shape, processed concurrently on one device. */
+fsgm_status fsgm_calc_cost_sgm_batch_host(int32_t n_frames, const fsgm_epi_in* in,
+                                          const fsgm_epi_out* out, const fsgm_epi_params* prm);
+
+/* ---- device-resident plan: buffers for `batch` frames stay in HBM across calls ---- */
+typedef struct fsgm_epi_plan fsgm_epi_plan;
+
+/* stage bits for fsgm_epi_plan_run / _time */
+#define FSGM_STAGE_COST      1   /* census x2 + Hamming cost fill + 5x5 box   (calc_cost_sgm.cpp:319-412) */
+#define FSGM_STAGE_AGGREGATE 2   /* multi-path DP: C -> per-path L_r          (calc_cost_sgm.cpp:86-257)  */
+#define FSGM_STAGE_WTA       4   /* sum of paths, argmin, parabola, vz->disp  (calc_cost_sgm.cpp:259-308,414-426) */
+#define FSGM_STAGE_ALL       7
+
+fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** plan, int32_t width, int32_t height,
+                                 int32_t dMax, int32_t batch, const fsgm_epi_params* prm);
+void        fsgm_epi_plan_destroy(fsgm_epi_plan* plan);
+fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t P2, double vMax);
+/* host -> HBM (async on the plan's stream) */
+fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* plan, int32_t frame, const uint8_t* I1,
+                                 const uint8_t* I2, const double* pixelPosD0,
+                                 const double* normDir, const double* offset);
+/* aggregation-only use: put a ready cost volume into slot `frame` (skips FSGM_STAGE_COST) */
+fsgm_status fsgm_epi_plan_upload_cost(fsgm_epi_plan* plan, int32_t frame, const uint8_t* C);
+/* offset map only (needed by the vz->disp step when the cost stage is skipped) */
+fsgm_status fsgm_epi_plan_upload_offset(fsgm_epi_plan* plan, int32_t frame, const double* offset);
+fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* plan, int32_t stages);
+fsgm_status fsgm_epi_plan_sync(fsgm_epi_plan* plan);
+/* HBM -> host (synchronous) */
+fsgm_status fsgm_epi_plan_download(fsgm_epi_plan* plan, int32_t frame, uint32_t* bestD, uint32_t* minC);
+fsgm_status fsgm_epi_plan_download_cost(fsgm_epi_plan* plan, int32_t frame, uint8_t* C);
+fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* plan, int32_t frame, uint32_t* S);
+/* Average milliseconds of one fsgm_epi_plan_run(stages) over `iters` back-to-back runs after
+ * `warmup` untimed ones, measured with HIP events on the stream the kernels run on. */
+fsgm_status fsgm_epi_plan_time(fsgm_epi_plan* plan, int32_t stages, int32_t warmup,
+                               int32_t iters, float* ms_avg);
+/* the hipStream_t the plan launches on */
+void*       fsgm_epi_plan_stream(fsgm_epi_plan* plan);
+/* which aggregation kernel the plan selected: "packed16/nowrap", "packed16/wrap", "generic" */
+const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* plan);
+/* device-to-device copy bandwidth probe (GB/s, read+write bytes counted) used by bench.py */
+fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSGM_H */

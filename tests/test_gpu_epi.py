@@ -1,0 +1,184 @@
+"""GPU parity tests for the calc_cost_sgm path: HIP kernels (through the C ABI) vs the CPU oracle
+on the same seeded inputs.  Integer / index outputs must be bit-exact.
+
+Reference semantics under test: calc_cost_sgm.cpp:33-66 (sgm_step), :86-316 (sgm),
+:319-412 (calc_cost), :414-426 (convert_vzInd_to_disp), common.cpp:3-27 (census).
+"""
+import numpy as np
+import pytest
+
+from fsgm_amd import synth, EpiPlan, calc_cost_sgm, calc_cost_sgm_batch
+from fsgm_amd._lib import STAGE_COST, STAGE_AGGREGATE, STAGE_WTA
+
+pytestmark = pytest.mark.gpu
+
+
+def _last_pixel_mask(H, W):
+    m = np.ones((H, W), bool)
+    return m
+
+
+# ---------------------------------------------------------------- cost volume (census+Hamming+box)
+@pytest.mark.parametrize("W,H,D,kind", [
+    (64, 48, 16, "general"), (67, 45, 32, "general"), (40, 30, 64, "axis"),
+    (33, 21, 128, "general"), (31, 17, 20, "general"), (29, 19, 7, "general"),
+])
+def test_cost_volume_bit_exact(gpu_lib, oracle, W, H, D, kind):
+    I1, I2 = synth.image_pair(W, H, D, seed=W + D)
+    pd0, nd, off = synth.epi_maps(W, H, kind, seed=H)
+    want = oracle.epi_cost(I1, I2, D, 0.3, pd0, nd, off)
+    with EpiPlan(W, H, D, 1, paths=8) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        plan.upload(0, I1, I2, pd0, nd, off)
+        plan.run(STAGE_COST)
+        got = plan.download_cost(0)
+    assert got.max() <= 24
+    np.testing.assert_array_equal(got, want)
+
+
+def test_cost_volume_out_of_range_geometry(gpu_lib, oracle):
+    """Sample positions far outside the image / non-finite: the reference's (int) conversion gives
+    INT_MIN on x86-64, which clamps to 0 -- not the saturating GPU conversion."""
+    W, H, D = 48, 32, 16
+    I1, I2 = synth.image_pair(W, H, D, seed=5)
+    pd0, nd, off = synth.epi_maps(W, H, "general", seed=9)
+    off[3, 4] = 1e12
+    off[5, 6] = -1e12
+    off[7, 8] = 1e300
+    pd0[0, 9, 9] = np.inf
+    pd0[1, 10, 10] = np.nan
+    want = oracle.epi_cost(I1, I2, D, 0.3, pd0, nd, off)
+    with EpiPlan(W, H, D, 1) as plan:
+        plan.upload(0, I1, I2, pd0, nd, off)
+        plan.run(STAGE_COST)
+        got = plan.download_cost(0)
+    np.testing.assert_array_equal(got, want)
+
+
+# ---------------------------------------------------------------- aggregation
+AGG_CASES = [
+    # W, H, D, P1, P2, cmax, expected kernel
+    (64, 48, 16, 6, 64, 24, "packed16/nowrap"),
+    (67, 45, 32, 6, 32, 24, "packed16/nowrap"),
+    (41, 29, 64, 6, 64, 24, "packed16/nowrap"),
+    (37, 23, 128, 6, 64, 24, "packed16/nowrap"),
+    (19, 11, 256, 3, 20, 24, "packed16/nowrap"),
+    (64, 48, 16, 100, 200, 255, "packed16/wrap"),
+    (37, 23, 128, 90, 120, 255, "packed16/wrap"),
+    (45, 31, 64, 6, 64, 255, "packed16/wrap"),
+    (33, 21, 20, 6, 64, 24, "generic"),
+    (21, 17, 7, 100, 200, 255, "generic"),
+    (9, 5, 1, 6, 64, 24, "generic"),
+]
+
+
+@pytest.mark.parametrize("paths", [4, 8])
+@pytest.mark.parametrize("W,H,D,P1,P2,cmax,kernel", AGG_CASES)
+def test_aggregate_sum_bit_exact(gpu_lib, oracle, W, H, D, P1, P2, cmax, kernel, paths):
+    Cv = synth.cost_volume(W, H, D, seed=W * 7 + D, cmax=cmax)
+    want = oracle.epi_aggregate(Cv, P1, P2, paths)[:-1].reshape(H, W, D)
+    with EpiPlan(W, H, D, 1, paths=paths) as plan:
+        plan.set_penalties(P1, P2, 0.3)
+        plan.upload_cost(0, Cv)
+        assert plan.kernel_name == kernel
+        plan.run(STAGE_AGGREGATE)
+        got = plan.download_sum(0)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_aggregate_tiny_and_degenerate_shapes(gpu_lib, oracle):
+    """1-pixel-wide / 1-pixel-high images: every diagonal step is a path start."""
+    for (W, H) in [(1, 1), (1, 9), (9, 1), (2, 2), (8, 3), (3, 8)]:
+        for D in (16, 128):
+            Cv = synth.cost_volume(W, H, D, seed=W + 10 * H, cmax=24)
+            want = oracle.epi_aggregate(Cv, 6, 64, 8)[:-1].reshape(H, W, D)
+            with EpiPlan(W, H, D, 1, paths=8) as plan:
+                plan.upload_cost(0, Cv)
+                plan.run(STAGE_AGGREGATE)
+                got = plan.download_sum(0)
+            np.testing.assert_array_equal(got, want, err_msg=f"{W}x{H}x{D}")
+
+
+# ---------------------------------------------------------------- WTA / sub-pixel / vz
+@pytest.mark.parametrize("W,H,D", [(64, 48, 16), (37, 23, 128), (33, 21, 20)])
+@pytest.mark.parametrize("subpixel,vz", [(1, 1), (1, 0), (0, 0)])
+def test_wta_subpixel_bit_exact(gpu_lib, oracle, W, H, D, subpixel, vz):
+    Cv = synth.cost_volume(W, H, D, seed=11, cmax=24)
+    # force the best == D-1 (reads next pixel's d=0), best == 1 (never refined) and best == 0 cases
+    Cv[2, 3, :] = 24; Cv[2, 3, D - 1] = 0
+    Cv[4, 5, :] = 24; Cv[4, 5, 1] = 0
+    Cv[6, 7, :] = 24; Cv[6, 7, 0] = 0
+    Cv[H - 1, W - 1, :] = 24; Cv[H - 1, W - 1, D - 1] = 0      # last pixel: Sp[best+1] is past the array -> 0
+    _, _, off = synth.epi_maps(W, H, "general", seed=3)
+    S = oracle.epi_aggregate(Cv, 6, 64, 8)
+    bd, mc = oracle.epi_wta(S, W, H, D, subpixel)
+    if vz:
+        bd = oracle.epi_vz_to_disp(bd, off, 0.3, D + 1)
+    with EpiPlan(W, H, D, 1, paths=8, subpixel=subpixel, vz_to_disp=vz) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        plan.upload_cost(0, Cv)
+        plan.upload_offset(0, off)
+        plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        gbd, gmc = plan.download(0)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gbd, bd)
+
+
+# ---------------------------------------------------------------- whole MEX
+@pytest.mark.parametrize("paths", [4, 8])
+@pytest.mark.parametrize("W,H,D,kind", [(64, 48, 16, "general"), (320, 240, 64, "axis"), (97, 61, 128, "general"),
+                                        (50, 40, 24, "general")])
+def test_calc_cost_sgm_whole_mex(gpu_lib, oracle, W, H, D, kind, paths):
+    I1, I2 = synth.image_pair(W, H, D, seed=2)
+    pd0, nd, off = synth.epi_maps(W, H, kind, seed=4)
+    bd, mc, Cv, S = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, paths, want_volumes=True)
+    gbd, gmc, gC, gS = calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, paths=paths, return_volumes=True)
+    np.testing.assert_array_equal(gC, Cv)
+    np.testing.assert_array_equal(gS, S)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gbd, bd)
+
+
+def test_calc_cost_sgm_kitti_shape_8_paths(gpu_lib, oracle):
+    """BASELINE config 3: 1242x375, D=128, 8 paths -- full-size bit-exact comparison."""
+    W, H, D = 1242, 375, 128
+    I1, I2 = synth.image_pair(W, H, D, seed=1)
+    pd0, nd, off = synth.epi_maps(W, H, "axis")
+    bd, mc, Cv, S = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, 8, want_volumes=True)
+    gbd, gmc, gC, gS = calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, paths=8, return_volumes=True)
+    np.testing.assert_array_equal(gC, Cv)
+    np.testing.assert_array_equal(gS, S)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gbd, bd)
+
+
+def test_batch_matches_single_frames(gpu_lib, oracle):
+    W, H, D = 96, 64, 64
+    frames = []
+    for s in range(3):
+        I1, I2 = synth.image_pair(W, H, D, seed=20 + s)
+        pd0, nd, off = synth.epi_maps(W, H, "general", seed=30 + s)
+        frames.append((I1, I2, pd0, nd, off))
+    res = calc_cost_sgm_batch(frames, D, 0.3, 6, 64, paths=8)
+    for (I1, I2, pd0, nd, off), (gbd, gmc) in zip(frames, res):
+        bd, mc = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, 8)
+        np.testing.assert_array_equal(gmc, mc)
+        np.testing.assert_array_equal(gbd, bd)
+
+
+def test_full_size_property_mirror_symmetry(gpu_lib):
+    """Size-independent property at full KITTI size: point-mirroring the cost volume in (x,y)
+    mirrors S (pass 1 of the reference is the point mirror of pass 0, calc_cost_sgm.cpp:115-123),
+    and S >= paths * min_d C elementwise lower bound holds."""
+    W, H, D = 1242, 375, 128
+    Cv = synth.cost_volume(W, H, D, seed=99, cmax=24)
+    with EpiPlan(W, H, D, 2, paths=8) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        plan.upload_cost(0, Cv)
+        plan.upload_cost(1, np.ascontiguousarray(Cv[::-1, ::-1, :]))
+        plan.run(STAGE_AGGREGATE)
+        S0 = plan.download_sum(0)
+        S1 = plan.download_sum(1)
+    np.testing.assert_array_equal(S1[::-1, ::-1, :], S0)
+    assert (S0 >= 8 * Cv.astype(np.uint32)).all()           # every L_r(p,d) >= C(p,d) when nothing wraps
+    assert (S0 <= 8 * (Cv.astype(np.uint32) + 64)).all()    # and <= C + P2
