@@ -1,0 +1,84 @@
+"""CPU-side tests of the C-ABI library and the host wrappers (no compute calls: this box has no GPU)."""
+import ctypes
+import os
+import re
+import numpy as np
+import pytest
+
+import fsgm_amd
+from fsgm_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    names = set()
+    for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        txt = open(os.path.join(ROOT, "include", fn)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(fsgm_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared_functions()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/*.h but not exported by libfsgm_hip.so: {missing}"
+
+
+def test_library_is_gfx950_code_object():
+    """The shared object must carry a gfx950 device code object (built by hipcc --offload-arch=gfx950)."""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"agg_packed_kernel" in blob
+
+
+def test_no_cpu_fallback_without_device():
+    lib = _lib.load()
+    if lib.fsgm_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(fsgm_amd.FsgmError) as ei:
+        fsgm_amd.EpiPlan(64, 48, 16)
+    assert ei.value.status == 2 and "no HIP device" in str(ei.value)
+    I1, I2 = synth.image_pair(32, 24, 16)
+    pd0, nd, off = synth.epi_maps(32, 24)
+    with pytest.raises(fsgm_amd.FsgmError):
+        fsgm_amd.calc_cost_sgm(I1, I2, 16, 0.3, pd0, nd, off, 6, 64)
+
+
+def test_default_params_are_the_shipped_switches():
+    p = _lib.load().fsgm_epi_params_default()
+    assert (p.paths, p.subpixel, p.vz_to_disp, p.device) == (4, 1, 1, 0)     # calc_cost_sgm.cpp:104,560,4
+
+
+def test_argument_validation_is_loud():
+    I1, I2 = synth.image_pair(32, 24, 16)
+    pd0, nd, off = synth.epi_maps(32, 24)
+    with pytest.raises(TypeError):
+        fsgm_amd.calc_cost_sgm(I1.astype(np.float32), I2, 16, 0.3, pd0, nd, off, 6, 64)
+    with pytest.raises(TypeError):
+        fsgm_amd.calc_cost_sgm(I1, I2, 16, 0.3, pd0[0], nd, off, 6, 64)
+    with pytest.raises(TypeError):
+        fsgm_amd.calc_cost_sgm(I1, I2, 16, 0.3, pd0, nd, off.astype(np.float32), 6, 64)
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.fsgm_epi_plan_create(ctypes.byref(h), 0, 10, 16, 1, None) == 1          # FSGM_ERR_INVALID
+    assert b"width/height" in lib.fsgm_last_error()
+    prm = lib.fsgm_epi_params_default()
+    prm.paths = 5
+    assert lib.fsgm_epi_plan_create(ctypes.byref(h), 10, 10, 16, 1, ctypes.byref(prm)) == 1
+    assert lib.fsgm_epi_plan_create(ctypes.byref(h), 10, 10, 5000, 1, None) == 4       # FSGM_ERR_UNSUPPORTED
+    assert lib.fsgm_epi_plan_run(None, 7) == 1
+
+
+def test_synthetic_inputs_are_deterministic():
+    I1, I2 = synth.image_pair(64, 48, 16, seed=1)
+    assert int(I1.astype(np.uint64).sum()) > 0
+    a = synth.cost_volume(8, 4, 16, seed=3)
+    b = synth.cost_volume(8, 4, 16, seed=3)
+    np.testing.assert_array_equal(a, b)
+    assert a.max() <= 24
+    assert synth.splitmix64(1, 3).tolist() == synth.splitmix64(1, 3).tolist()
+    assert int(synth.splitmix64(0, 1)[0]) == 0xE220A8397B1DCDAF                 # splitmix64(0) known answer
