@@ -72,14 +72,14 @@ fsgm_epi_params fsgm_epi_params_default(void) {
 
 void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
-    hipSetDevice(p->prm.device);
+    (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
                     p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS};
     for (void* b : bufs)
-        if (b) hipFree(b);
-    if (p->ev0) hipEventDestroy(p->ev0);
-    if (p->ev1) hipEventDestroy(p->ev1);
-    if (p->stream) hipStreamDestroy(p->stream);
+        if (b) (void)hipFree(b);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
 
@@ -315,18 +315,18 @@ fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t it
     void *a = nullptr, *b = nullptr;
     hipEvent_t e0, e1;
     FSGM_HIP(hipMalloc(&a, bytes));
-    if (hipMalloc(&b, bytes) != hipSuccess) { hipFree(a); return fail(FSGM_ERR_NOMEM, "copy probe: out of memory"); }
-    hipMemset(a, 1, bytes);
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
-    hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; i++) hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
-    hipEventRecord(e1, 0);
+    if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); return fail(FSGM_ERR_NOMEM, "copy probe: out of memory"); }
+    (void)hipMemset(a, 1, bytes);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; i++) (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
+    (void)hipEventRecord(e1, 0);
     hipError_t e = hipEventSynchronize(e1);
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(a); hipFree(b);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
     if (e != hipSuccess) return fail(FSGM_ERR_HIP, "copy probe: %s", hipGetErrorString(e));
     *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
     return FSGM_OK;
@@ -359,7 +359,10 @@ static fsgm_status cached_plan(fsgm_epi_plan** out, int W, int H, int D, int bat
     return FSGM_OK;
 }
 
+void fsgm_pyd_shutdown_internal(void);
+
 void fsgm_shutdown(void) {
+    fsgm_pyd_shutdown_internal();
     std::lock_guard<std::mutex> lk(g_cache_mu);
     for (fsgm_epi_plan* p : g_cache) fsgm_epi_plan_destroy(p);
     g_cache.clear();

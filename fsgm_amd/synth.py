@@ -73,3 +73,25 @@ def epi_maps(W, H, kind="axis", seed=7):
 def cost_volume(W, H, D, seed=3, cmax=24):
     """u8 uniform in [0, cmax] of shape (H, W, D): aggregation-only input."""
     return uniform_u8(seed, (H, W, D), hi=cmax)
+
+
+def hint_map(mvW, mvH, kind="zero", seed=21, amp=3.0):
+    """preMv (2, mvH, mvW) for the pyramidal / neighbour-guided variants.
+
+    'zero'   : coarsest pyramid level (pyramidal_sgm.m:34).
+    'even'   : 2*integer values in 2x2 blocks, what 2*imresize(mv,2,'nearest') hands the next
+               level when sub-pixel refinement is off (pyramidal_sgm.m:72).
+    'general': fractional hints (exercise the +0.5 / truncation rules and the (-1,0) -> 0 case).
+    """
+    if kind == "zero":
+        return np.zeros((2, mvH, mvW))
+    if kind == "even":
+        h2, w2 = (mvH + 1) // 2, (mvW + 1) // 2
+        coarse = np.floor(uniform_f64(seed, (2, h2, w2)) * (2 * amp + 1)) - amp
+        return np.ascontiguousarray(2.0 * np.repeat(np.repeat(coarse, 2, axis=1), 2, axis=2)[:, :mvH, :mvW])
+    if kind == "general":
+        mv = (uniform_f64(seed, (2, mvH, mvW)) - 0.5) * 2 * amp
+        mv[:, ::3, ::4] = np.round(mv[:, ::3, ::4] * 2) / 2          # exact halves
+        mv[0, 1::5, 1::6] = -0.75                                     # lands in (-1, 0) near the left border
+        return np.ascontiguousarray(mv)
+    raise ValueError(kind)

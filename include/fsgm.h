@@ -128,6 +128,57 @@ const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* plan);
 /* device-to-device copy bandwidth probe (GB/s, read+write bytes counted) used by bench.py */
 fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps);
 
+/* ------------------------------------------------------------------------------------------
+ * calc_pyd_cost_sgm  (calc_pyd_cost_sgm.cpp:439-510, called from pyramidal_sgm.m:50)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const uint8_t* I1;            /* prhs[0]  u8 [H][W] */
+    const uint8_t* I2;            /* prhs[1] */
+    int32_t width, height;        /* mxGetM / mxGetN of prhs[0] (calc_pyd_cost_sgm.cpp:454-455) */
+    const double* preMv;          /* prhs[2]  f64 [2][mvHeight][mvWidth], plane 0 = x; indexed with its own stride */
+    int32_t mvWidth, mvHeight;    /* mxGetM(prhs[2]), mxGetN(prhs[2])/2 (:493-494); must be >= width, height */
+    int32_t halfSearchWinSizeX;   /* prhs[3] */
+    int32_t halfSearchWinSizeY;   /* prhs[4] */
+    int32_t aggHalfWinSize;       /* prhs[5] */
+    int32_t subPixelRefine;       /* prhs[6] */
+    int32_t P1, P2;               /* prhs[7], prhs[8] */
+    int32_t enableDiagnalPath;    /* prhs[9]  (bool) */
+    int32_t totalPass;            /* prhs[10] */
+    int32_t adpativeP2;           /* prhs[11] (bool) */
+} fsgm_pyd_in;
+
+typedef struct {
+    uint32_t* bestD;              /* plhs[0]  u32 [H][W], 0-based candidate index sx*Sy+sy */
+    uint32_t* minC;               /* plhs[1]  u32 [H][W] */
+    double*   mvSub;              /* plhs[2]  f64 [2][H][W], plane 0 = x; zeros when subPixelRefine == 0 */
+    uint8_t*  C;                  /* optional debug tap: cost volume u8 [H][W][D] (calc_pyd_cost_sgm.cpp:496) */
+    uint32_t* S;                  /* optional debug tap: summed path costs u32 [H][W][D] (:125) */
+} fsgm_pyd_out;
+
+fsgm_status fsgm_calc_pyd_cost_sgm_host(const fsgm_pyd_in* in, const fsgm_pyd_out* out, int32_t device);
+fsgm_status fsgm_calc_pyd_cost_sgm_batch_host(int32_t n_frames, const fsgm_pyd_in* in,
+                                              const fsgm_pyd_out* out, int32_t device);
+
+typedef struct fsgm_pyd_plan fsgm_pyd_plan;
+fsgm_status fsgm_pyd_plan_create(fsgm_pyd_plan** plan, int32_t width, int32_t height,
+                                 int32_t mvWidth, int32_t mvHeight, int32_t halfSearchWinSizeX,
+                                 int32_t halfSearchWinSizeY, int32_t aggHalfWinSize, int32_t batch,
+                                 int32_t device);
+void        fsgm_pyd_plan_destroy(fsgm_pyd_plan* plan);
+fsgm_status fsgm_pyd_plan_set_params(fsgm_pyd_plan* plan, int32_t P1, int32_t P2,
+                                     int32_t enableDiagnalPath, int32_t totalPass,
+                                     int32_t adpativeP2, int32_t subPixelRefine);
+fsgm_status fsgm_pyd_plan_upload(fsgm_pyd_plan* plan, int32_t frame, const uint8_t* I1,
+                                 const uint8_t* I2, const double* preMv);
+fsgm_status fsgm_pyd_plan_upload_cost(fsgm_pyd_plan* plan, int32_t frame, const uint8_t* C);
+fsgm_status fsgm_pyd_plan_run(fsgm_pyd_plan* plan, int32_t stages);   /* FSGM_STAGE_* bits */
+fsgm_status fsgm_pyd_plan_download(fsgm_pyd_plan* plan, int32_t frame, uint32_t* bestD,
+                                   uint32_t* minC, double* mvSub);
+fsgm_status fsgm_pyd_plan_download_cost(fsgm_pyd_plan* plan, int32_t frame, uint8_t* C);
+fsgm_status fsgm_pyd_plan_download_sum(fsgm_pyd_plan* plan, int32_t frame, uint32_t* S);
+fsgm_status fsgm_pyd_plan_time(fsgm_pyd_plan* plan, int32_t stages, int32_t warmup,
+                               int32_t iters, float* ms_avg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,3 +106,101 @@ def calc_cost_sgm(I1, I2, D, vMax, pd0, nd, off, P1, P2, paths=4, want_volumes=F
     if want_volumes:
         return bestD, minC, Cv, S[:-1].reshape(H, W, D)
     return bestD, minC
+
+
+# ---------------------------------------------------------------- calc_pyd_cost_sgm
+def pyd_cost(cen1, cen2, preMv, rAgg, rX, rY):
+    H, W = cen1.shape
+    mvH, mvW = preMv.shape[1:]
+    D = (2 * rX + 1) * (2 * rY + 1)
+    Cv = np.zeros((H, W, D), np.uint8)
+    lib().fsgm_oracle_pyd_cost(_p(Cv), _p(np.ascontiguousarray(cen1)), _p(np.ascontiguousarray(cen2)), W, H,
+                               _p(np.ascontiguousarray(preMv)), mvW, mvH, int(rAgg), int(rX), int(rY))
+    return Cv
+
+
+def pyd_aggregate(I1, Cv, preMv, Sx, Sy, P1, P2, diagonal=1, totalPass=2, adaptiveP2=0):
+    H, W, D = Cv.shape
+    mvH, mvW = preMv.shape[1:]
+    S = np.zeros((H, W, D), np.uint32)
+    lib().fsgm_oracle_pyd_aggregate(_p(S), _p(np.ascontiguousarray(I1)), _p(np.ascontiguousarray(Cv)), W, H,
+                                    _p(np.ascontiguousarray(preMv)), mvW, mvH, int(Sx), int(Sy), int(P1), int(P2),
+                                    int(diagonal), int(totalPass), int(adaptiveP2))
+    return S
+
+
+def pyd_wta(S, Sx, Sy, subpixel):
+    H, W, D = S.shape
+    bestD = np.zeros((H, W), np.uint32)
+    minC = np.zeros((H, W), np.uint32)
+    mvSub = np.zeros((2, H, W), np.float64)
+    lib().fsgm_oracle_pyd_wta(_p(bestD), _p(minC), _p(mvSub), _p(np.ascontiguousarray(S)), W, H, int(Sx), int(Sy), int(subpixel))
+    return bestD, minC, mvSub
+
+
+def calc_pyd_cost_sgm(I1, I2, preMv, rX, rY, rAgg, subpixel, P1, P2, diagonal=1, totalPass=2, adaptiveP2=0,
+                      want_volumes=False):
+    I1 = np.ascontiguousarray(I1, np.uint8)
+    I2 = np.ascontiguousarray(I2, np.uint8)
+    preMv = np.ascontiguousarray(preMv, np.float64)
+    H, W = I1.shape
+    mvH, mvW = preMv.shape[1:]
+    D = (2 * rX + 1) * (2 * rY + 1)
+    bestD = np.zeros((H, W), np.uint32)
+    minC = np.zeros((H, W), np.uint32)
+    mvSub = np.zeros((2, H, W), np.float64)
+    Cv = np.zeros((H, W, D), np.uint8) if want_volumes else None
+    S = np.zeros((H, W, D), np.uint32) if want_volumes else None
+    lib().fsgm_oracle_calc_pyd_cost_sgm(_p(bestD), _p(minC), _p(mvSub), _p(I1), _p(I2), W, H, _p(preMv), mvW, mvH,
+                                        int(rX), int(rY), int(rAgg), int(subpixel), int(P1), int(P2),
+                                        int(diagonal), int(totalPass), int(adaptiveP2), _p(Cv), _p(S))
+    return (bestD, minC, mvSub, Cv, S) if want_volumes else (bestD, minC, mvSub)
+
+
+# ---------------------------------------------------------------- calc_pyd_cost_sgm_ng
+CAND = np.dtype([("mvx", np.int32), ("mvy", np.int32), ("cost", np.int32)])
+
+
+def calc_pyd_cost_sgm_ng(I1, I2, preMv, halfSearchWinSize, aggSize, subpixel, P1, P2, want_volumes=False):
+    I1 = np.ascontiguousarray(I1, np.uint8)
+    I2 = np.ascontiguousarray(I2, np.uint8)
+    preMv = np.ascontiguousarray(preMv, np.float64)
+    H, W = I1.shape
+    mvH, mvW = preMv.shape[1:]
+    r = int(halfSearchWinSize)
+    D = 9 * (2 * r + 1) ** 2
+    minC = np.zeros((H, W), np.uint32)
+    flow = np.zeros((2, H, W), np.float64)
+    Cc = np.zeros((H, W, D), CAND) if want_volumes else None
+    S = np.zeros((H, W, D), np.uint32) if want_volumes else None
+    lib().fsgm_oracle_calc_pyd_cost_sgm_ng(_p(minC), _p(flow), _p(I1), _p(I2), W, H, _p(preMv), mvW, mvH,
+                                           C.c_double(halfSearchWinSize), C.c_double(aggSize), int(subpixel),
+                                           int(P1), int(P2), _p(Cc), _p(S))
+    return (minC, flow, Cc, S) if want_volumes else (minC, flow)
+
+
+# ---------------------------------------------------------------- calc_cost_sgm_ng
+def glibc_rand_stream(n, seed=1):
+    """n values of libc rand() after srand(seed) -- what the reference draws on this platform.
+    (Restores nothing: rand() state is process-global, exactly as in a MATLAB session.)"""
+    libc = C.CDLL(None)
+    libc.srand(C.c_uint(seed))
+    libc.rand.restype = C.c_int
+    return np.array([libc.rand() for _ in range(n)], np.int32)
+
+
+def sgm_ng_rand_draws(W, H):
+    lib().fsgm_oracle_sgm_ng_rand_draws.restype = C.c_int64
+    return int(lib().fsgm_oracle_sgm_ng_rand_draws(W, H))
+
+
+def calc_cost_sgm_ng(I1, I2, P1, P2, rand_stream):
+    I1 = np.ascontiguousarray(I1, np.uint8)
+    I2 = np.ascontiguousarray(I2, np.uint8)
+    H, W = I1.shape
+    rs = np.ascontiguousarray(rand_stream, np.int32)
+    minC = np.zeros((H, W), np.uint32)
+    flow = np.zeros((2, H, W), np.float64)
+    lib().fsgm_oracle_calc_cost_sgm_ng(_p(minC), _p(flow), _p(I1), _p(I2), W, H, int(P1), int(P2), _p(rs),
+                                       C.c_int64(len(rs)))
+    return minC, flow
