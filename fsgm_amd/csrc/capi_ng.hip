@@ -1,0 +1,166 @@
+// capi_ng.hip -- C ABI for the two neighbour-guided variants (include/fsgm.h).
+// Buffers are allocated per call: these variants are correctness paths, not the hot loop of the
+// benchmark.
+#include "capi_common.h"
+#include "epi_kernels.h"
+#include "ng_kernels.h"
+#include <stdlib.h>
+#include <vector>
+
+using namespace fsgm;
+
+namespace {
+struct DevBufs {                       // frees everything on scope exit
+    std::vector<void*> ptrs;
+    hipStream_t stream = nullptr;
+    ~DevBufs() {
+        for (void* p : ptrs) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    hipError_t alloc(void** p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+
+fsgm_status pick_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FSGM_ERR_HIP, "no HIP device available (libfsgm_hip has no CPU fallback)");
+    FSGM_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+    FSGM_HIP(hipSetDevice(device));
+    return FSGM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in, const fsgm_ng_out* out, int32_t device) {
+    FSGM_REQUIRE(n >= 1 && in && out, "fsgm_calc_pyd_cost_sgm_ng: null argument");
+    const fsgm_ng_in& a = in[0];
+    for (int i = 0; i < n; i++) {
+        FSGM_REQUIRE(in[i].I1 && in[i].I2 && in[i].preMv && out[i].minC && out[i].flow,
+                     "fsgm_calc_pyd_cost_sgm_ng: frame %d has a null pointer", i);
+        const fsgm_ng_in& b = in[i];
+        FSGM_REQUIRE(b.width == a.width && b.height == a.height && b.mvWidth == a.mvWidth && b.mvHeight == a.mvHeight &&
+                     b.halfSearchWinSize == a.halfSearchWinSize && b.aggSize == a.aggSize &&
+                     b.subPixelRefine == a.subPixelRefine && b.P1 == a.P1 && b.P2 == a.P2,
+                     "frames of one batch must share shape and parameters (frame %d differs)", i);
+    }
+    const int W = a.width, H = a.height, r = a.halfSearchWinSize, rAgg = a.aggSize / 2;
+    FSGM_REQUIRE(W >= 1 && H >= 1 && a.mvWidth >= 1 && a.mvHeight >= 1, "bad image / hint-map size");
+    FSGM_REQUIRE(r >= 0 && a.aggSize >= 0, "halfSearchWinSize and aggSize must be >= 0");
+    const long long D = 9LL * (2 * r + 1) * (2 * r + 1);
+    if (D > FSGM_NG_MAX_D) return fail(FSGM_ERR_UNSUPPORTED, "%lld candidates per pixel exceed %d", D, FSGM_NG_MAX_D);
+    if ((double)W * H * D >= 2147483648.0) return fail(FSGM_ERR_UNSUPPORTED, "candidate volume exceeds 2^31 entries per frame");
+    fsgm_status st = pick_device(device);
+    if (st != FSGM_OK) return st;
+    const size_t NP = (size_t)W * H, MV = (size_t)a.mvWidth * a.mvHeight, N = NP * D, B = n;
+    DevBufs d;
+    uint8_t *dI1, *dI2; uint32_t *dCen1, *dCen2, *dS, *dMinC; double *dMv, *dFlow; Cand* dC;
+    FSGM_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    FSGM_HIP(d.alloc((void**)&dI1, B * NP));
+    FSGM_HIP(d.alloc((void**)&dI2, B * NP));
+    FSGM_HIP(d.alloc((void**)&dCen1, B * NP * 4));
+    FSGM_HIP(d.alloc((void**)&dCen2, B * NP * 4));
+    FSGM_HIP(d.alloc((void**)&dMv, B * MV * 16));
+    FSGM_HIP(d.alloc((void**)&dC, B * N * sizeof(Cand)));
+    FSGM_HIP(d.alloc((void**)&dS, B * N * 4));
+    FSGM_HIP(d.alloc((void**)&dMinC, B * NP * 4));
+    FSGM_HIP(d.alloc((void**)&dFlow, B * NP * 16));
+    for (int i = 0; i < n; i++) {
+        FSGM_HIP(hipMemcpyAsync(dI1 + i * NP, in[i].I1, NP, hipMemcpyHostToDevice, d.stream));
+        FSGM_HIP(hipMemcpyAsync(dI2 + i * NP, in[i].I2, NP, hipMemcpyHostToDevice, d.stream));
+        FSGM_HIP(hipMemcpyAsync(dMv + i * 2 * MV, in[i].preMv, MV * 16, hipMemcpyHostToDevice, d.stream));
+    }
+    FSGM_HIP(hipMemsetAsync(dS, 0, B * N * 4, d.stream));                       // :111
+    launch_census(d.stream, dI1, dCen1, W, H, n);                               // :485-486
+    launch_census(d.stream, dI2, dCen2, W, H, n);
+    NgCostArgs ca;
+    ca.cen1 = dCen1; ca.cen2 = dCen2; ca.mv = dMv; ca.C = dC; ca.W = W; ca.H = H;
+    ca.mvW = a.mvWidth; ca.mvH = a.mvHeight; ca.rAgg = rAgg; ca.rX = r; ca.rY = r;
+    launch_ng_cost(d.stream, ca, n);
+    NgAggArgs ga;
+    ga.C = dC; ga.S = dS; ga.W = W; ga.H = H; ga.D = (int)D; ga.P1 = a.P1; ga.P2 = a.P2;
+    launch_ng_aggregate(d.stream, ga, n);
+    NgWtaArgs wa;
+    wa.C = dC; wa.S = dS; wa.minC = dMinC; wa.flow = dFlow; wa.W = W; wa.H = H; wa.D = (int)D;
+    launch_ng_wta(d.stream, wa, n);
+    if (a.subPixelRefine) {                                                     // :516-517
+        NgSubpixArgs sa;
+        sa.cen1 = dCen1; sa.cen2 = dCen2; sa.flow = dFlow; sa.W = W; sa.H = H;
+        launch_ng_subpixel(d.stream, sa, n);
+    }
+    FSGM_HIP(hipGetLastError());
+    FSGM_HIP(hipStreamSynchronize(d.stream));
+    for (int i = 0; i < n; i++) {
+        FSGM_HIP(hipMemcpy(out[i].minC, dMinC + i * NP, NP * 4, hipMemcpyDeviceToHost));
+        FSGM_HIP(hipMemcpy(out[i].flow, dFlow + i * 2 * NP, NP * 16, hipMemcpyDeviceToHost));
+        if (out[i].S) FSGM_HIP(hipMemcpy(out[i].S, dS + i * N, N * 4, hipMemcpyDeviceToHost));
+    }
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_calc_pyd_cost_sgm_ng_host(const fsgm_ng_in* in, const fsgm_ng_out* out, int32_t device) {
+    return fsgm_calc_pyd_cost_sgm_ng_batch_host(1, in, out, device);
+}
+
+int64_t fsgm_sgm_ng_rand_draws(int32_t W, int32_t H) { return (int64_t)W * H * 8; }
+
+fsgm_status fsgm_calc_cost_sgm_ng_batch_host(int32_t n, const fsgm_otf_in* in, const fsgm_otf_out* out, int32_t device) {
+    FSGM_REQUIRE(n >= 1 && in && out, "fsgm_calc_cost_sgm_ng: null argument");
+    const int W = in[0].width, H = in[0].height;
+    FSGM_REQUIRE(W >= 1 && H >= 1, "bad image size");
+    for (int i = 0; i < n; i++) {
+        FSGM_REQUIRE(in[i].I1 && in[i].I2 && out[i].minC && out[i].flow, "fsgm_calc_cost_sgm_ng: frame %d has a null pointer", i);
+        FSGM_REQUIRE(in[i].width == W && in[i].height == H && in[i].P1 == in[0].P1 && in[i].P2 == in[0].P2,
+                     "frames of one batch must share shape and parameters (frame %d differs)", i);
+    }
+    fsgm_status st = pick_device(device);
+    if (st != FSGM_OK) return st;
+    const size_t NP = (size_t)W * H, B = n, rowE = (size_t)W * OTF_E;
+    DevBufs d;
+    uint8_t *dI1, *dI2; uint32_t *dCen1, *dCen2, *dMinC; double* dFlow; int32_t* dRnd; Cand* dLrow;
+    FSGM_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    FSGM_HIP(d.alloc((void**)&dI1, B * NP));
+    FSGM_HIP(d.alloc((void**)&dI2, B * NP));
+    FSGM_HIP(d.alloc((void**)&dCen1, B * NP * 4));
+    FSGM_HIP(d.alloc((void**)&dCen2, B * NP * 4));
+    FSGM_HIP(d.alloc((void**)&dRnd, B * NP * 8 * 4));
+    FSGM_HIP(d.alloc((void**)&dLrow, B * 6 * rowE * sizeof(Cand)));
+    FSGM_HIP(d.alloc((void**)&dMinC, B * NP * 4));
+    FSGM_HIP(d.alloc((void**)&dFlow, B * NP * 16));
+    std::vector<int32_t> drawn;
+    for (int i = 0; i < n; i++) {
+        const int32_t* rs = in[i].rand_stream;
+        if (!rs) {                                   // the reference's own source of hints: libc rand()
+            drawn.resize(NP * 8);
+            for (size_t k = 0; k < NP * 8; k++) drawn[k] = rand();
+            rs = drawn.data();
+        }
+        FSGM_HIP(hipMemcpy(dRnd + i * NP * 8, rs, NP * 8 * 4, hipMemcpyHostToDevice));
+        FSGM_HIP(hipMemcpyAsync(dI1 + i * NP, in[i].I1, NP, hipMemcpyHostToDevice, d.stream));
+        FSGM_HIP(hipMemcpyAsync(dI2 + i * NP, in[i].I2, NP, hipMemcpyHostToDevice, d.stream));
+    }
+    FSGM_HIP(hipMemsetAsync(dLrow, 0, B * 6 * rowE * sizeof(Cand), d.stream));  // :205-207
+    launch_census(d.stream, dI1, dCen1, W, H, n);                               // :233-234
+    launch_census(d.stream, dI2, dCen2, W, H, n);
+    OtfArgs oa;
+    oa.I1 = dI1; oa.cen1 = dCen1; oa.cen2 = dCen2; oa.rnd = dRnd; oa.Lrow = dLrow; oa.minC = dMinC; oa.flow = dFlow;
+    oa.W = W; oa.H = H; oa.P1 = in[0].P1; oa.P2 = in[0].P2;
+    launch_otf(d.stream, oa, n);
+    FSGM_HIP(hipGetLastError());
+    FSGM_HIP(hipStreamSynchronize(d.stream));
+    for (int i = 0; i < n; i++) {
+        FSGM_HIP(hipMemcpy(out[i].minC, dMinC + i * NP, NP * 4, hipMemcpyDeviceToHost));
+        FSGM_HIP(hipMemcpy(out[i].flow, dFlow + i * 2 * NP, NP * 16, hipMemcpyDeviceToHost));
+    }
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_calc_cost_sgm_ng_host(const fsgm_otf_in* in, const fsgm_otf_out* out, int32_t device) {
+    return fsgm_calc_cost_sgm_ng_batch_host(1, in, out, device);
+}
+
+}  // extern "C"

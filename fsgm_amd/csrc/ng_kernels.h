@@ -1,0 +1,66 @@
+// ng_kernels.h -- launch interface of the neighbour-guided variants
+// (calc_pyd_cost_sgm_ng.cpp and calc_cost_sgm_ng.cpp)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define FSGM_NG_MAX_D 512        // candidates per pixel of the hint-map variant: 9*(2r+1)^2, r <= 3
+
+namespace fsgm {
+
+struct Cand { int32_t mvx, mvy, cost; };     // calc_pyd_cost_sgm_ng.cpp:32-37
+
+struct NgCostArgs {
+    const uint32_t* cen1;   // [frames][NP]
+    const uint32_t* cen2;
+    const double* mv;       // [frames][2][mvH*mvW]
+    Cand* C;                // [frames][NP][D]
+    int W, H, mvW, mvH;
+    int rAgg, rX, rY;
+};
+
+struct NgAggArgs {
+    const Cand* C;          // [frames][NP][D]
+    uint32_t* S;            // [frames][NP][D], zeroed before the launch; paths add atomically
+    int W, H, D;
+    int P1, P2;
+    int blk_begin[5];
+};
+
+struct NgWtaArgs {
+    const Cand* C;
+    const uint32_t* S;
+    uint32_t* minC;         // [frames][NP]
+    double* flow;           // [frames][2][NP]
+    int W, H, D;
+};
+
+struct NgSubpixArgs {
+    const uint32_t* cen1;
+    const uint32_t* cen2;
+    double* flow;
+    int W, H;
+};
+
+// on-the-fly variant (calc_cost_sgm_ng.cpp): one workgroup walks one frame in raster order
+constexpr int OTF_D = 108;       // DIRECTION_NUM*(N+M)*MV_PER_HINT  (:194)
+constexpr int OTF_E = 110;       // + N best entries                  (:196)
+struct OtfArgs {
+    const uint8_t* I1;      // [frames][NP]
+    const uint32_t* cen1;
+    const uint32_t* cen2;
+    const int32_t* rnd;     // [frames][NP*8]  libc rand() stream, 2 draws per random hint
+    Cand* Lrow;             // [frames][3][2][W][OTF_E]  L2, L3, L4 double row buffers (zeroed)
+    uint32_t* minC;         // [frames][NP]
+    double* flow;           // [frames][2][NP]
+    int W, H, P1, P2;
+};
+
+void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames);
+void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames);
+void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames);
+void launch_ng_subpixel(hipStream_t st, const NgSubpixArgs& a, int frames);
+void launch_otf(hipStream_t st, const OtfArgs& a, int frames);
+
+}  // namespace fsgm

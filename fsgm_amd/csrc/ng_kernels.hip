@@ -1,0 +1,411 @@
+// ng_kernels.hip -- gfx950 kernels for the two neighbour-guided variants.
+//   calc_pyd_cost_sgm_ng.cpp : 9 hints x (2r+1)^2 candidates per pixel as {mvx,mvy,cost}, O(D^2)
+//                              matcher per path step, 2 passes x 2 paths.
+//   calc_cost_sgm_ng.cpp     : candidates come from the path buffers of pixels already visited
+//                              (+ a rand() hint), so the frame is inherently raster-serial.
+#include "ng_kernels.h"
+#include "fsgm_device.h"
+
+namespace fsgm {
+
+__device__ __forceinline__ bool near2(int a, int b) {
+    const long long d = (long long)a - b;                    // abs(int - int) <= 2 without overflow
+    return d >= -2 && d <= 2;
+}
+
+// =============================================================================================
+// candidate list + cost  (calc_pyd_cost_sgm_ng.cpp:370-446).  One thread = one (pixel, candidate).
+// Hint order: dy outer, dx inner over {-8,0,+8} (clamped to the hint map, :390-396); expansion:
+// offx outer, offy inner (:399-400); sample = (int)((off + p1) + mv), no +0.5 (:417-418).
+// =============================================================================================
+__global__ __launch_bounds__(256) void ng_cost_kernel(NgCostArgs a) {
+    const int W = a.W, H = a.H;
+    const int NP = W * H;
+    const int Sy = 2 * a.rY + 1, cph = (2 * a.rX + 1) * Sy, D = 9 * cph;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)NP * D) return;
+    const int p = (int)(gid / D), d = (int)(gid - (long long)p * D);
+    const int y = p / W, x = p - y * W;
+    const int h = d / cph, c = d - h * cph;
+    const int dy = (h / 3 - 1) * 8, dx = (h % 3 - 1) * 8;
+    const int offx = c / Sy - a.rX, offy = c % Sy - a.rY;
+    const size_t f = blockIdx.y;
+    const double* mvxp = a.mv + f * 2 * (size_t)a.mvW * a.mvH;
+    const double* mvyp = mvxp + (size_t)a.mvW * a.mvH;
+    const int yn = clampi(y + dy, 0, a.mvH - 1), xn = clampi(x + dx, 0, a.mvW - 1);
+    const double mvx = mvxp[(size_t)a.mvW * yn + xn], mvy = mvyp[(size_t)a.mvW * yn + xn];
+    const uint32_t* cen1 = a.cen1 + f * (size_t)NP;
+    const uint32_t* cen2 = a.cen2 + f * (size_t)NP;
+    const int r = a.rAgg;
+    uint32_t sum = 0;
+    for (int ay = -r; ay <= r; ay++) {
+        const int y1 = y + ay;
+        const int y2 = f64_to_i32_x86(__dadd_rn((double)(offy + y1), mvy));
+        const bool yok = y1 >= 0 && y1 <= H - 1 && y2 >= 0 && y2 <= H - 1;
+        for (int ax = -r; ax <= r; ax++) {
+            const int x1 = x + ax;
+            const int x2 = f64_to_i32_x86(__dadd_rn((double)(offx + x1), mvx));
+            if (yok && x1 >= 0 && x1 <= W - 1 && x2 >= 0 && x2 <= W - 1)
+                sum += __popc(cen1[(size_t)W * y1 + x1] ^ cen2[(size_t)W * y2 + x2]);
+            else
+                sum += 5;
+        }
+    }
+    const int win = (2 * r + 1) * (2 * r + 1);
+    Cand o;
+    o.cost = f64_to_i32_x86(__dadd_rn(__ddiv_rn(__dmul_rn(1.0, (double)sum), (double)win), 0.5));   // :432
+    o.mvx = f64_to_i32_x86(__dadd_rn(mvx, (double)offx));                                           // :433
+    o.mvy = f64_to_i32_x86(__dadd_rn(mvy, (double)offy));                                           // :434
+    a.C[f * (size_t)NP * D + (size_t)p * D + d] = o;
+}
+
+// One matcher step shared by both variants (calc_pyd_cost_sgm_ng.cpp:39-78 /
+// calc_cost_sgm_ng.cpp:46-83): the caller's lanes stride over the current candidates; Lpre is in
+// LDS.  Returns the int path cost (C.cost + best - m), not narrowed.
+__device__ __forceinline__ int ng_match(const Cand* pre, int D, int mvx, int mvy, int ccost,
+                                        uint32_t m, uint32_t jump, int P1) {
+    uint32_t min1 = jump, min2 = jump;
+    for (int d2 = 0; d2 < D; d2++) {
+        const Cand q = pre[d2];                              // same address in every lane: LDS broadcast
+        if (mvx == q.mvx && mvy == q.mvy) min1 = (uint32_t)q.cost & 0xFF;            // last match wins
+        else if (near2(mvx, q.mvx) && near2(mvy, q.mvy)) min2 = min(min2, (uint32_t)(q.cost + P1) & 0xFF);
+    }
+    const uint32_t best = min(jump, min(min1, min2));
+    return (ccost + (int)best) - (int)m;
+}
+
+// =============================================================================================
+// aggregation of the hint-map variant (calc_pyd_cost_sgm_ng.cpp:101-278): 2 passes x 2 paths
+// (enableDiagnalPath=false :122, adpativeP2=false :120).  One wave per line, S += L atomically
+// (u32 adds commute, so the result does not depend on the order the four paths arrive in).
+// =============================================================================================
+__global__ __launch_bounds__(256) void ng_agg_kernel(NgAggArgs a) {
+    __shared__ Cand sL[4][2][FSGM_NG_MAX_D + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int slot = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if ((int)blockIdx.x >= a.blk_begin[i]) slot = i;
+    const int base = slot & 1;                               // 0: along x, 1: along y
+    const bool mirror = slot >= 2;
+    const int W = a.W, H = a.H, D = a.D;
+    const int NP = W * H;
+    const int nlines = base == 0 ? H : W;
+    const int len = base == 0 ? W : H;
+    const int line = ((int)blockIdx.x - a.blk_begin[slot]) * 4 + wave;
+    if (line >= nlines) return;
+    const size_t f = blockIdx.y;
+    const Cand* __restrict__ Cf = a.C + f * (size_t)NP * D;
+    uint32_t* __restrict__ Sf = a.S + f * (size_t)NP * D;
+    Cand* pre = sL[wave][0];
+    Cand* cur = sL[wave][1];
+    uint32_t m = 0;
+    for (int t = 0; t < len; t++) {
+        int x = base == 0 ? t : line, y = base == 0 ? line : t;
+        if (mirror) { x = W - 1 - x; y = H - 1 - y; }
+        const size_t off = ((size_t)y * W + x) * D;
+        uint32_t lo = 255;
+        const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
+        for (int d = lane; d < D; d += 64) {
+            const Cand c = Cf[off + d];
+            Cand o = c;
+            if (t > 0) {
+                o.cost = ng_match(pre, D, c.mvx, c.mvy, c.cost, m, jump, a.P1);
+                lo = min(lo, (uint32_t)o.cost & 0xFF);                           // :74 narrowed
+            }
+            cur[d] = o;
+            atomicAdd(&Sf[off + d], (uint32_t)o.cost);                          // :249
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, s));
+        m = t > 0 ? lo : 0u;                                                     // :172 / :77
+        __builtin_amdgcn_wave_barrier();
+        Cand* tmp = pre; pre = cur; cur = tmp;
+    }
+}
+
+// WTA -> winning candidate's motion vector (calc_pyd_cost_sgm_ng.cpp:281-299); one wave per pixel
+__global__ __launch_bounds__(256) void ng_wta_kernel(NgWtaArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NP = a.W * a.H, D = a.D;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= NP) return;
+    const size_t f = blockIdx.y;
+    const uint32_t* Sp = a.S + f * (size_t)NP * D + (size_t)p * D;
+    uint32_t lo = 0xFFFFFFFFu, idx = 0xFFFFFFFFu;
+    for (int d = lane; d < D; d += 64) {
+        const uint32_t s = Sp[d];
+        if (s < lo || idx == 0xFFFFFFFFu) { lo = s; idx = d; }
+    }
+    uint32_t glo = lo;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) glo = min(glo, (uint32_t)__shfl_xor((int)glo, s));
+    uint32_t gidx = (lo == glo && idx != 0xFFFFFFFFu) ? idx : 0xFFFFFFFFu;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) gidx = min(gidx, (uint32_t)__shfl_xor((int)gidx, s));
+    if (lane == 0) {
+        const Cand c = a.C[f * (size_t)NP * D + (size_t)p * D + gidx];
+        a.minC[f * NP + p] = glo;
+        a.flow[f * 2 * (size_t)NP + p] = (double)c.mvx;
+        a.flow[f * 2 * (size_t)NP + NP + p] = (double)c.mvy;
+    }
+}
+
+// sub-pixel on raw single-pixel census costs (calc_pyd_cost_sgm_ng.cpp:308-368)
+__device__ __forceinline__ double ng_parab(double cl, double c0, double cr) {
+    return cr < cl ? __ddiv_rn(__ddiv_rn(__dsub_rn(cr, cl), __dsub_rn(c0, cl)), 2.0)
+                   : __ddiv_rn(__ddiv_rn(__dsub_rn(cr, cl), __dsub_rn(c0, cr)), 2.0);
+}
+
+__global__ __launch_bounds__(256) void ng_subpixel_kernel(NgSubpixArgs a) {
+    const int W = a.W, H = a.H, NP = W * H;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    const size_t f = blockIdx.y;
+    const int y = p / W, x = p - y * W;
+    double* fx = a.flow + f * 2 * (size_t)NP;
+    double* fy = fx + NP;
+    const uint32_t* cen2 = a.cen2 + f * (size_t)NP;
+    const uint32_t c1 = a.cen1[f * (size_t)NP + p];
+    const int tx = f64_to_i32_x86(__dadd_rn(fx[p], (double)x)), ty = f64_to_i32_x86(__dadd_rn(fy[p], (double)y));   // :325-326
+    if (!(tx > 1 && tx < W - 1 && ty > 1 && ty < H - 1)) return;                                                  // :328
+    const double c0 = (double)__popc(c1 ^ cen2[(size_t)ty * W + tx]);
+    double cl = (double)__popc(c1 ^ cen2[(size_t)ty * W + tx - 1]);
+    double cr = (double)__popc(c1 ^ cen2[(size_t)ty * W + tx + 1]);
+    if (c0 >= cl || c0 >= cr) return;                                                                             // :337
+    fx[p] = __dadd_rn(fx[p], ng_parab(cl, c0, cr));
+    cl = (double)__popc(c1 ^ cen2[(size_t)(ty - 1) * W + tx]);
+    cr = (double)__popc(c1 ^ cen2[(size_t)(ty + 1) * W + tx]);
+    if (c0 >= cl || c0 >= cr) return;                                                                             // :354
+    fy[p] = __dadd_rn(fy[p], ng_parab(cl, c0, cr));
+}
+
+// =============================================================================================
+// on-the-fly variant (calc_cost_sgm_ng.cpp:188-419).  Raster-serial by construction: the
+// candidates of pixel (x,y) are the two best motion vectors left in the path buffers that are
+// about to be overwritten -- L1's from two pixels earlier in raster order, L2/L3/L4's from two
+// rows earlier (:276-277) -- plus one libc-rand() hint per buffer (:148-149), each expanded 3x3.
+// One 256-thread workgroup walks one frame pixel by pixel: the 108 candidate costs are spread
+// over the threads, then wave k runs path k's O(D^2) matcher + top-2 tracking.  Frames of a
+// batch run on different CUs.  A correctness port, not a throughput kernel.
+// =============================================================================================
+__device__ __forceinline__ void otf_step_wave(Cand* Lout, const Cand* pre, const Cand* Cc, int lane,
+                                              int P1, int P2, Cand* top /*[2] in LDS*/) {
+    // calc_cost_sgm_ng.cpp:46-98 for one path, executed by one wave (64 lanes over 108 candidates)
+    const uint32_t m = (uint32_t)pre[OTF_D].cost & 0xFF;                         // :53
+    const uint32_t jump = (m + (uint32_t)P2) & 0xFF;
+    int cost[2] = {0x7FFFFFFF, 0x7FFFFFFF};
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int d = lane + 64 * i;
+        if (d < OTF_D) {
+            const Cand c = Cc[d];
+            Cand o = c;
+            o.cost = ng_match(pre, OTF_D, c.mvx, c.mvy, c.cost, m, jump, P1);
+            Lout[d] = o;
+            cost[i] = o.cost;
+        }
+    }
+    // top-2 by insertion in ascending d with strict '<' (:84-96): entry j precedes entry k when
+    // cost_j < cost_k, or cost_j == cost_k and j < k.  Slots start at cost 255 (:54-55) and an
+    // entry that is not < 255 never enters; the motion vectors of untouched slots stay as they are.
+    // key = (cost biased to unsigned) << 8 | d  gives exactly that order.
+    auto key_of = [](int c, int d) -> unsigned long long {
+        return ((unsigned long long)(uint32_t)(c ^ 0x80000000) << 8) | (unsigned)d;
+    };
+    const unsigned long long KMAX = ~0ull;
+    unsigned long long k0 = cost[0] != 0x7FFFFFFF ? key_of(cost[0], lane) : KMAX;
+    unsigned long long k1 = cost[1] != 0x7FFFFFFF ? key_of(cost[1], lane + 64) : KMAX;
+    unsigned long long best = k0 < k1 ? k0 : k1;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long o = __shfl_xor(best, s);
+        best = o < best ? o : best;
+    }
+    // second best: smallest key different from best
+    unsigned long long c0 = k0 == best ? KMAX : k0, c1 = k1 == best ? KMAX : k1;
+    unsigned long long second = c0 < c1 ? c0 : c1;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long o = __shfl_xor(second, s);
+        second = o < second ? o : second;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        // Slot costs reset to 255, slot motion vectors keep whatever the buffer held (:54-55).  The
+        // first insertion shifts old slot 0 (cost 255, old mv) down into slot 1 (:92-95).
+        Cand t0 = Lout[OTF_D], t1 = Lout[OTF_D + 1];
+        t0.cost = 255; t1.cost = 255;
+        const int bc = (int)((uint32_t)(best >> 8) ^ 0x80000000), bd = (int)(best & 0xFF);
+        const int sc = (int)((uint32_t)(second >> 8) ^ 0x80000000), sd = (int)(second & 0xFF);
+        if (best != KMAX && bc < 255) {
+            t1 = t0;
+            t0 = Lout[bd];
+            if (second != KMAX && sc < 255) t1 = Lout[sd];
+        }
+        Lout[OTF_D] = t0;
+        Lout[OTF_D + 1] = t1;
+    }
+    (void)top;
+}
+
+__global__ __launch_bounds__(256) void otf_kernel(OtfArgs a) {
+    __shared__ Cand sC[OTF_D];                    // candidates of the current pixel
+    __shared__ Cand sL1[2][OTF_E];                // L1 double buffer (:197)
+    __shared__ Cand sPre[4][OTF_E];               // predecessor entries staged per path
+    __shared__ Cand sOut[4][OTF_E];               // new entries per path
+    __shared__ int sHint[4][3][2];                // [buffer][hint][mvx,mvy]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = a.W, H = a.H, NP = W * H;
+    const size_t f = blockIdx.x;
+    const uint8_t* If = a.I1 + f * (size_t)NP;
+    const uint32_t* cen1 = a.cen1 + f * (size_t)NP;
+    const uint32_t* cen2 = a.cen2 + f * (size_t)NP;
+    const int32_t* rnd = a.rnd + f * (size_t)NP * 8;
+    const size_t rowE = (size_t)W * OTF_E;
+    Cand* Lrow = a.Lrow + f * 6 * rowE;           // [L2,L3,L4][2][W][OTF_E]
+    for (int i = tid; i < 2 * OTF_E; i += 256) { Cand z = {0, 0, 0}; sL1[i / OTF_E][i % OTF_E] = z; }   // :204
+    __syncthreads();
+    int l1cur = 1, rowcur = 1;                    // :248, :250-254
+    for (int y = 0; y < H; y++) {
+        const int rowpre = rowcur ^ 1;
+        for (int x = 0; x < W; x++) {
+            const int p = y * W + x;
+            const int l1pre = l1cur ^ 1;
+            Cand* L2c = Lrow + (0 * 2 + rowcur) * rowE + (size_t)x * OTF_E;
+            Cand* L3c = Lrow + (1 * 2 + rowcur) * rowE + (size_t)x * OTF_E;
+            Cand* L4c = Lrow + (2 * 2 + rowcur) * rowE + (size_t)x * OTF_E;
+            // ---- hints: top-N entries of the buffers about to be overwritten (:276-277) + rand
+            if (tid < 12) {
+                const int l = tid / 3, i = tid % 3;
+                int mvx, mvy;
+                if (i < 2) {
+                    const Cand* src = l == 0 ? &sL1[l1cur][OTF_D] : (l == 1 ? L2c + OTF_D : (l == 2 ? L3c + OTF_D : L4c + OTF_D));
+                    mvx = src[i].mvx; mvy = src[i].mvy;
+                } else {
+                    mvx = rnd[(size_t)p * 8 + 2 * l] % 256 - 128;                // :148
+                    mvy = rnd[(size_t)p * 8 + 2 * l + 1] % 128 - 64;             // :149
+                }
+                sHint[l][i][0] = mvx; sHint[l][i][1] = mvy;
+            }
+            __syncthreads();
+            // ---- candidate costs (:122-186): clamp-border 5x5 mean of Hamming costs
+            if (tid < OTF_D) {
+                const int hi = tid / 9, k = tid % 9;
+                const int offy = k / 3 - 1, offx = k % 3 - 1;                    // :153-154 offy outer
+                const int mvx = sHint[hi / 3][hi % 3][0], mvy = sHint[hi / 3][hi % 3][1];
+                uint32_t sum = 0;
+#pragma unroll
+                for (int ay = -2; ay <= 2; ay++) {
+                    const int y1 = clampi(y + ay, 0, H - 1);
+                    const int y2 = clampi((offy + y1) + mvy, 0, H - 1);
+#pragma unroll
+                    for (int ax = -2; ax <= 2; ax++) {
+                        const int x1 = clampi(x + ax, 0, W - 1);
+                        const int x2 = clampi((offx + x1) + mvx, 0, W - 1);
+                        sum += __popc(cen1[(size_t)W * y1 + x1] ^ cen2[(size_t)W * y2 + x2]);
+                    }
+                }
+                Cand c;
+                c.cost = f64_to_i32_x86(__dadd_rn(__ddiv_rn(__dmul_rn(1.0, (double)sum), 25.0), 0.5));   // :177
+                c.mvx = mvx + offx; c.mvy = mvy + offy;
+                sC[tid] = c;
+            }
+            __syncthreads();
+            // ---- per path (wave k = path buffer k): start copy or matcher step
+            {
+                const bool s1 = x == 0, s2 = x == 0 || y == 0, s3 = y == 0, s4 = y == 0 || x == W - 1;
+                const bool is_start = wave == 0 ? s1 : (wave == 1 ? s2 : (wave == 2 ? s3 : s4));
+                Cand* out = sOut[wave];
+                // current content of the slot being overwritten (its top-N mvs survive a start copy)
+                const Cand* curbuf = wave == 0 ? sL1[l1cur] : (wave == 1 ? L2c : (wave == 2 ? L3c : L4c));
+                if (lane < 2) out[OTF_D + lane] = curbuf[OTF_D + lane];
+                __builtin_amdgcn_wave_barrier();
+                if (is_start) {
+                    for (int d = lane; d < OTF_D; d += 64) out[d] = sC[d];      // :280,284,290,294,297,304
+                    if (lane == 0) out[OTF_D].cost = 0;
+                } else {
+                    const Cand* psrc;
+                    int pp;
+                    if (wave == 0) { psrc = sL1[l1pre]; pp = If[p - 1]; }
+                    else if (wave == 1) { psrc = Lrow + (0 * 2 + rowpre) * rowE + (size_t)(x - 1) * OTF_E; pp = If[p - W - 1]; }
+                    else if (wave == 2) { psrc = Lrow + (1 * 2 + rowpre) * rowE + (size_t)x * OTF_E; pp = If[p - W]; }
+                    else { psrc = Lrow + (2 * 2 + rowpre) * rowE + (size_t)(x + 1) * OTF_E; pp = If[p - W + 1]; }
+                    Cand* pre = sPre[wave];
+                    for (int d = lane; d < OTF_E; d += 64) pre[d] = psrc[d];
+                    __builtin_amdgcn_wave_barrier();
+                    const int P2 = abs((int)If[p] - pp) > 50 ? a.P2 / 8 : a.P2;  // :101-105 adaptive P2
+                    otf_step_wave(out, pre, sC, lane, a.P1, P2, nullptr);
+                }
+            }
+            __syncthreads();
+            // ---- S = L1+L3+L2+L4 (:357-362) and WTA for this pixel (:389-407); wave 0 only
+            if (wave == 0) {
+                unsigned long long key = ~0ull;
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int d = lane + 64 * i;
+                    if (d < OTF_D) {
+                        const uint32_t s = (uint32_t)(sOut[0][d].cost + sOut[2][d].cost) + (uint32_t)(sOut[1][d].cost + sOut[3][d].cost);
+                        const unsigned long long k = ((unsigned long long)s << 8) | (unsigned)d;
+                        key = k < key ? k : key;
+                    }
+                }
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) {
+                    const unsigned long long o = __shfl_xor(key, s);
+                    key = o < key ? o : key;
+                }
+                if (lane == 0) {
+                    const int idx = (int)(key & 0xFF);
+                    a.minC[f * NP + p] = (uint32_t)(key >> 8);
+                    a.flow[f * 2 * (size_t)NP + p] = (double)sC[idx].mvx;
+                    a.flow[f * 2 * (size_t)NP + NP + p] = (double)sC[idx].mvy;
+                }
+            }
+            // ---- write the new entries back into the buffers
+            {
+                Cand* dst = wave == 0 ? sL1[l1cur] : (wave == 1 ? L2c : (wave == 2 ? L3c : L4c));
+                for (int d = lane; d < OTF_E; d += 64) dst[d] = sOut[wave][d];
+            }
+            __threadfence_block();
+            __syncthreads();
+            l1cur ^= 1;                                                          // :365-367
+        }
+        rowcur ^= 1;                                                             // :371-384
+    }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames) {
+    const long long n = (long long)a.W * a.H * 9 * (2 * a.rX + 1) * (2 * a.rY + 1);
+    dim3 grid((unsigned)((n + 255) / 256), frames);
+    hipLaunchKernelGGL(ng_cost_kernel, grid, dim3(256), 0, st, a);
+}
+
+void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
+    // slots: 0 along x, 1 along y, 2/3 their point mirrors (pass 1)
+    int acc = 0;
+    for (int i = 0; i < 4; i++) {
+        a.blk_begin[i] = acc;
+        acc += (((i & 1) == 0 ? a.H : a.W) + 3) / 4;
+    }
+    a.blk_begin[4] = acc;
+    hipLaunchKernelGGL(ng_agg_kernel, dim3(acc, frames), dim3(256), 0, st, a);
+}
+
+void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames) {
+    hipLaunchKernelGGL(ng_wta_kernel, dim3((a.W * a.H + 3) / 4, frames), dim3(256), 0, st, a);
+}
+
+void launch_ng_subpixel(hipStream_t st, const NgSubpixArgs& a, int frames) {
+    hipLaunchKernelGGL(ng_subpixel_kernel, dim3((a.W * a.H + 255) / 256, frames), dim3(256), 0, st, a);
+}
+
+void launch_otf(hipStream_t st, const OtfArgs& a, int frames) {
+    hipLaunchKernelGGL(otf_kernel, dim3(frames), dim3(256), 0, st, a);
+}
+
+}  // namespace fsgm

@@ -179,6 +179,56 @@ fsgm_status fsgm_pyd_plan_download_sum(fsgm_pyd_plan* plan, int32_t frame, uint3
 fsgm_status fsgm_pyd_plan_time(fsgm_pyd_plan* plan, int32_t stages, int32_t warmup,
                                int32_t iters, float* ms_avg);
 
+/* ------------------------------------------------------------------------------------------
+ * calc_pyd_cost_sgm_ng  (calc_pyd_cost_sgm_ng.cpp:448-523; same 8-argument list as the call in
+ * ng_sgm.m:20, no caller in the reference tree)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const uint8_t* I1;            /* prhs[0] */
+    const uint8_t* I2;            /* prhs[1] */
+    int32_t width, height;
+    const double* preMv;          /* prhs[2]  f64 [2][mvHeight][mvWidth]; hints are clamped to the map (:392-393) */
+    int32_t mvWidth, mvHeight;
+    int32_t halfSearchWinSize;    /* prhs[3] */
+    int32_t aggSize;              /* prhs[4]  aggregation radius = (int)aggSize/2 (:490) */
+    int32_t subPixelRefine;       /* prhs[5] */
+    int32_t P1, P2;               /* prhs[6], prhs[7] */
+} fsgm_ng_in;
+
+typedef struct {
+    uint32_t* minC;               /* plhs[0]  u32 [H][W] */
+    double*   flow;               /* plhs[1]  f64 [2][H][W], plane 0 = x */
+    uint32_t* S;                  /* optional debug tap: summed path costs u32 [H][W][D], D = 9*(2r+1)^2 */
+} fsgm_ng_out;
+
+fsgm_status fsgm_calc_pyd_cost_sgm_ng_host(const fsgm_ng_in* in, const fsgm_ng_out* out, int32_t device);
+fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n_frames, const fsgm_ng_in* in,
+                                                 const fsgm_ng_out* out, int32_t device);
+
+/* ------------------------------------------------------------------------------------------
+ * calc_cost_sgm_ng  (calc_cost_sgm_ng.cpp:484-526, called from ng_sgm.m:20; prhs[2..5] ignored)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const uint8_t* I1;            /* prhs[0] */
+    const uint8_t* I2;            /* prhs[1] */
+    int32_t width, height;
+    int32_t P1, P2;               /* prhs[6], prhs[7] */
+    /* The reference draws 2 x rand() per random hint in raster order (:148-149): 8 per pixel.
+     * rand_stream = those draws (fsgm_sgm_ng_rand_draws(width,height) values); NULL makes the
+     * library call libc rand() itself, which is what the reference does (process-global state). */
+    const int32_t* rand_stream;
+} fsgm_otf_in;
+
+typedef struct {
+    uint32_t* minC;               /* plhs[0]  u32 [H][W] */
+    double*   flow;               /* plhs[1]  f64 [2][H][W] */
+} fsgm_otf_out;
+
+int64_t     fsgm_sgm_ng_rand_draws(int32_t width, int32_t height);
+fsgm_status fsgm_calc_cost_sgm_ng_host(const fsgm_otf_in* in, const fsgm_otf_out* out, int32_t device);
+fsgm_status fsgm_calc_cost_sgm_ng_batch_host(int32_t n_frames, const fsgm_otf_in* in,
+                                             const fsgm_otf_out* out, int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,52 @@
+"""GPU parity tests for the two neighbour-guided variants vs the CPU oracle.
+calc_pyd_cost_sgm_ng.cpp:39-78 (sgm_step), :101-299 (sgm2d), :308-368 (subpixel_refine),
+:370-446 (calc_cost); calc_cost_sgm_ng.cpp:46-98, :122-186, :188-419."""
+import numpy as np
+import pytest
+
+from fsgm_amd import synth, calc_pyd_cost_sgm_ng, calc_cost_sgm_ng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("W,H,mvW,mvH,r,agg,sub,P1,P2,kind", [
+    (40, 30, 40, 30, 1, 2, 0, 6, 32, "zero"),          # ng_sgm.m:20 argument values
+    (37, 23, 30, 20, 1, 5, 1, 6, 32, "general"),       # hint map smaller than the image: clamped (:392-393)
+    (33, 21, 40, 25, 1, 2, 1, 90, 120, "general"),     # wrapping penalties
+    (21, 15, 21, 15, 2, 3, 0, 6, 32, "even"),          # D = 225
+    (12, 1, 12, 1, 1, 2, 0, 6, 32, "general"), (1, 12, 1, 12, 1, 2, 1, 6, 32, "general"),
+])
+def test_calc_pyd_cost_sgm_ng_bit_exact(gpu_lib, oracle, W, H, mvW, mvH, r, agg, sub, P1, P2, kind):
+    I1, I2 = synth.image_pair(W, H, 16, seed=W + r)
+    mv = synth.hint_map(mvW, mvH, kind, seed=H, amp=6.0)
+    mc, fl, _, S = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, r, agg, sub, P1, P2, want_volumes=True)
+    gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv, r, agg, sub, P1, P2, return_sum=True)
+    np.testing.assert_array_equal(gS, S)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gfl, fl)
+
+
+@pytest.mark.parametrize("W,H,P1,P2", [(40, 30, 6, 32), (33, 17, 6, 32), (24, 20, 100, 200), (7, 3, 6, 32), (2, 2, 6, 32),
+                                        (1, 5, 6, 32), (5, 1, 6, 32)])
+def test_calc_cost_sgm_ng_bit_exact(gpu_lib, oracle, W, H, P1, P2):
+    I1, I2 = synth.image_pair(W, H, 16, seed=W * H)
+    I1 = (I1.astype(np.int32) * 5 % 256).astype(np.uint8)        # strong gradients: adaptive P2 both ways
+    rs = oracle.glibc_rand_stream(oracle.sgm_ng_rand_draws(W, H))
+    mc, fl = oracle.calc_cost_sgm_ng(I1, I2, P1, P2, rs)
+    gmc, gfl = calc_cost_sgm_ng(I1, I2, None, 1, 2, 0, P1, P2, rand_stream=rs)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gfl, fl)
+
+
+def test_calc_cost_sgm_ng_draws_libc_rand_like_the_reference(gpu_lib, oracle):
+    """With no stream given the library consumes libc rand() itself (process-global state, as in a
+    MATLAB session): after srand(1) it must reproduce the explicit-stream result."""
+    import ctypes
+    W, H = 20, 12
+    I1, I2 = synth.image_pair(W, H, 16, seed=4)
+    rs = oracle.glibc_rand_stream(oracle.sgm_ng_rand_draws(W, H), seed=1)
+    want = calc_cost_sgm_ng(I1, I2, None, 1, 2, 0, 6, 32, rand_stream=rs)
+    ctypes.CDLL(None).srand(ctypes.c_uint(1))
+    got = calc_cost_sgm_ng(I1, I2, None, 1, 2, 0, 6, 32)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
