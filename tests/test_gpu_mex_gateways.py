@@ -1,0 +1,62 @@
+"""The mexFunction gateways called the way the MATLAB drivers call them, vs the CPU oracle.
+epipolar_sgm_of.m:45, pyramidal_sgm.m:50, ng_sgm.m:20."""
+import ctypes
+import numpy as np
+import pytest
+
+from fsgm_amd import synth
+from tests import mexharness as mh
+
+pytestmark = pytest.mark.gpu
+
+
+def test_calc_cost_sgm_gateway_as_epipolar_sgm_of_calls_it(gpu_lib, oracle):
+    W, H, D = 96, 64, 64
+    I1, I2 = synth.image_pair(W, H, D, seed=3)
+    pd0, nd, off = synth.epi_maps(W, H, "general", seed=6)
+    (bestD, minC), _ = mh.call("calc_cost_sgm", 2, I1, I2, D, 0.3, pd0, nd, off, 6, 64)
+    rbd, rmc = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, 4)      # as shipped: 4 paths
+    assert bestD.dtype == np.uint32 and bestD.shape == (H, W)
+    np.testing.assert_array_equal(bestD, rbd)
+    np.testing.assert_array_equal(minC, rmc)
+    outs, _ = mh.call("calc_cost_sgm", 4, I1, I2, D, 0.3, pd0, nd, off, 6, 64)
+    assert outs[2].dtype == np.uint8 and not outs[2].any() and outs[3].dtype == np.uint32 and not outs[3].any()
+    (only,), _ = mh.call("calc_cost_sgm", 0, I1, I2, D, 0.3, pd0, nd, off, 6, 64)
+    np.testing.assert_array_equal(only, rbd)
+
+
+def test_calc_pyd_cost_sgm_gateway_as_pyramidal_sgm_calls_it(gpu_lib, oracle):
+    W, H = 72, 40
+    I1, I2 = synth.image_pair(W, H, 16, seed=8)
+    mv = synth.hint_map(W, H, "even", seed=1)
+    (minIdx, minC, mvSub), printed = mh.call("calc_pyd_cost_sgm", 3, I1, I2, mv, 5, 5, 2, 1, 6, 32, 1, 2, 0)
+    bd, mc, ms = oracle.calc_pyd_cost_sgm(I1, I2, mv, 5, 5, 2, 1, 6, 32, 1, 2, 0)
+    assert printed == f"width: {W}, height: {H}, dMax: 121, winRadiusAgg: 2\n"   # calc_pyd_cost_sgm.cpp:491
+    assert mvSub.shape == (2, H, W)
+    np.testing.assert_array_equal(minIdx, bd)
+    np.testing.assert_array_equal(minC, mc)
+    np.testing.assert_array_equal(mvSub, ms)
+
+
+def test_ng_gateways_as_ng_sgm_calls_them(gpu_lib, oracle):
+    W, H = 36, 24
+    I1, I2 = synth.image_pair(W, H, 16, seed=5)
+    hints = np.zeros((2, H, W))                             # ng_sgm.m:17 passes zeros(row, col): one plane only ...
+    (minC, flow), printed = mh.call("calc_pyd_cost_sgm_ng", 2, I1, I2, hints, 1, 2, 0, 6, 32)
+    rmc, rfl = oracle.calc_pyd_cost_sgm_ng(I1, I2, hints, 1, 2, 0, 6, 32)
+    assert "dMax: 81" in printed
+    np.testing.assert_array_equal(minC, rmc)
+    np.testing.assert_array_equal(flow, rfl)
+    # the single-plane W x H hint ng_sgm.m really passes: mvHeight = H/2, lower half = y plane
+    (minC1, flow1), _ = mh.call("calc_pyd_cost_sgm_ng", 2, I1, I2, hints[0], 1, 2, 0, 6, 32)
+    r1mc, r1fl = oracle.calc_pyd_cost_sgm_ng(I1, I2, hints[0].reshape(2, H // 2, W), 1, 2, 0, 6, 32)
+    np.testing.assert_array_equal(minC1, r1mc)
+    np.testing.assert_array_equal(flow1, r1fl)
+
+    ctypes.CDLL(None).srand(ctypes.c_uint(1))
+    (minC, flow), printed = mh.call("calc_cost_sgm_ng", 2, I1, I2, hints[0], 1, 2, 0, 6, 32)   # ... which this MEX ignores
+    rs = oracle.glibc_rand_stream(oracle.sgm_ng_rand_draws(W, H), seed=1)
+    rmc, rfl = oracle.calc_cost_sgm_ng(I1, I2, 6, 32, rs)
+    assert printed == "dMax : 108\n"
+    np.testing.assert_array_equal(minC, rmc)
+    np.testing.assert_array_equal(flow, rfl)
