@@ -182,3 +182,19 @@ def test_full_size_property_mirror_symmetry(gpu_lib):
     np.testing.assert_array_equal(S1[::-1, ::-1, :], S0)
     assert (S0 >= 8 * Cv.astype(np.uint32)).all()           # every L_r(p,d) >= C(p,d) when nothing wraps
     assert (S0 <= 8 * (Cv.astype(np.uint32) + 64)).all()    # and <= C + P2
+
+
+def test_run_sharded_with_the_hip_compute(gpu_lib, oracle):
+    """fsgm_amd.batch.run_sharded on one rank with the real (HIP) per-shard compute."""
+    from fsgm_amd import batch
+    W, H, D = 64, 40, 32
+    frames = []
+    for s in range(3):
+        I1, I2 = synth.image_pair(W, H, D, seed=70 + s)
+        pd0, nd, off = synth.epi_maps(W, H, "general", seed=80 + s)
+        frames.append((I1, I2, pd0, nd, off))
+    res = batch.run_sharded(frames, lambda fs: calc_cost_sgm_batch(fs, D, 0.3, 6, 64, paths=8, device=0), rank=0, world=1)
+    for (I1, I2, pd0, nd, off), (gbd, gmc) in zip(frames, res):
+        bd, mc = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, 8)
+        np.testing.assert_array_equal(gbd, bd)
+        np.testing.assert_array_equal(gmc, mc)
