@@ -175,9 +175,10 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
     const int len = BASE == 0 ? W : H;
     const int lg = ((int)blockIdx.x - a.blk_begin[slot]) * 4 + wave;
     if (lg * PXW >= nlines) return;                         // wave-uniform
-    const int line = lg * PXW + g;
-    const bool valid = line < nlines;
-    const int l = valid ? line : nlines - 1;
+    // Lanes past the last line redo the last line: they load the same bytes and store the same
+    // bytes to the same addresses as its real lanes (which sit in this same wave), so the loop
+    // needs no per-lane predicate.
+    const int l = min(lg * PXW + g, nlines - 1);
 
     const uint8_t* __restrict__ Cf = a.C + (size_t)blockIdx.y * a.c_frame_stride;
     uint8_t* __restrict__ Lf = a.L + (size_t)blockIdx.y * a.l_frame_stride + (size_t)slot * a.l_dir_stride;
@@ -197,6 +198,8 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
         const int ap = mirror ? NP - 1 - cpix : cpix;
         return (uint32_t)ap * D + (uint32_t)j * 16;
     };
+    // the load cursor runs PF steps ahead of the line's end: keep its address inside the volume
+    auto load_c = [&](int cpix) -> uint4 { return *(const uint4*)(Cf + byte_off(min(cpix, NP - 1))); };
 
     const uint32_t P1pk = WRAP ? (uint32_t)(a.P1 & 0xFF) * 0x10001u : (uint32_t)a.P1 * 0x10001u;
     const uint32_t P2pk = (uint32_t)a.P2 * 0x10001u;        // NOWRAP only
@@ -205,93 +208,101 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
     uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};    // previous pixel's path costs
     uint32_t m = 0;                                          // previous pixel's stored minimum
 
+    // one DP step on the 16 costs of this lane; returns the packed output dwords
+    auto step = [&](const uint4 cw, const bool start) -> uint4 {
+        const uint32_t cv[4] = {cw.x, cw.y, cw.z, cw.w};
+        uint32_t CE[4], CO[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            CE[k] = __builtin_amdgcn_perm(0u, cv[k], 0x0C020C00u);     // bytes 0,2 -> 2 x u16
+            CO[k] = __builtin_amdgcn_perm(0u, cv[k], 0x0C030C01u);     // bytes 1,3 -> 2 x u16
+        }
+        // lane-boundary neighbours
+        uint32_t prevO3 = dpp_mov<DPP_ROW_SHR1>(SENT, LO[3]);
+        uint32_t nextE0 = dpp_mov<DPP_ROW_SHL1>(SENT, LE[0]);
+        if (j == 0) prevO3 = SENT;                   // d = 0 has no d-1      (:47)
+        if (j == LPP - 1) nextE0 = SENT;             // d = D-1 has no d+1    (:48)
+
+        const uint32_t mpk = m | (m << 16);
+        uint32_t NE[4], NO[4];
+        if (!WRAP) {
+            const uint32_t p2lane = start ? 0u : P2pk;   // min(.,0)=0 -> L = C at a path start
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t nbE = pk_min(align16(LO[k], k ? LO[k - 1] : prevO3), LO[k]);
+                const uint32_t nbO = pk_min(LE[k], align16(k < 3 ? LE[k + 1] : nextE0, LE[k]));
+                const uint32_t tE = pk_min(LE[k], pk_add(nbE, P1pk));
+                const uint32_t tO = pk_min(LO[k], pk_add(nbO, P1pk));
+                // C + min(t, m+P2) - m  ==  C + min(t-m, P2)   (no wrap: t >= m)
+                NE[k] = pk_add(CE[k], pk_min(pk_sub(tE, mpk), p2lane));
+                NO[k] = pk_add(CO[k], pk_min(pk_sub(tO, mpk), p2lane));
+            }
+        } else {
+            const uint32_t jump = (m + P2b) & 0xFFu;                       // :46 u8(LpreMin + P2)
+            const uint32_t jpk = jump | (jump << 16);
+            // mod-256 adds do not commute with min: narrow each neighbour + P1 first (:47-48),
+            // and give the two non-existent neighbours the neutral candidate 255.
+            const uint32_t noL = j == 0 ? 0x000000FFu : 0u;
+            const uint32_t noR = j == LPP - 1 ? 0x00FF0000u : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t lE = align16(LO[k], k ? LO[k - 1] : prevO3);          // d-1 of E[k]
+                const uint32_t rO = align16(k < 3 ? LE[k + 1] : nextE0, LE[k]);      // d+1 of O[k]
+                uint32_t cEl = pk_add(lE, P1pk) & MASK;
+                uint32_t cOr = pk_add(rO, P1pk) & MASK;
+                if (k == 0) cEl |= noL;
+                if (k == 3) cOr |= noR;
+                const uint32_t cEr = pk_add(LO[k], P1pk) & MASK;                     // d+1 of E[k] = O[k]
+                const uint32_t cOl = pk_add(LE[k], P1pk) & MASK;                     // d-1 of O[k] = E[k]
+                const uint32_t tE = pk_min(pk_min(LE[k], jpk), pk_min(cEl, cEr));
+                const uint32_t tO = pk_min(pk_min(LO[k], jpk), pk_min(cOl, cOr));
+                const uint32_t e = pk_sub(pk_add(CE[k], tE), mpk) & MASK;  // :60 mod 256
+                const uint32_t o = pk_sub(pk_add(CO[k], tO), mpk) & MASK;
+                NE[k] = start ? CE[k] : e;
+                NO[k] = start ? CO[k] : o;
+            }
+        }
+        // minimum over d of the new costs (:61,:65); 0 at a path start (:154,:164)
+        uint32_t mm = pk_min(pk_min(pk_min(NE[0], NO[0]), pk_min(NE[1], NO[1])),
+                             pk_min(pk_min(NE[2], NO[2]), pk_min(NE[3], NO[3])));
+        uint32_t mx = min(mm & 0xFFFFu, mm >> 16);
+        mx = group_min_u32<LPP>(mx);
+        m = start ? 0u : mx;
+        uint4 o;
+        uint32_t* ov = &o.x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            LE[k] = NE[k]; LO[k] = NO[k];
+            ov[k] = __builtin_amdgcn_perm(NO[k], NE[k], 0x06020400u);   // bytes E.lo, O.lo, E.hi, O.hi
+        }
+        return o;
+    };
+    auto is_start = [&](int t) -> bool { return (t == 0) || (BASE == 2 && x == 0) || (BASE == 3 && x == W - 1); };
+
     uint4 ring[PF];
 #pragma unroll
-    for (int i = 0; i < PF; i++) {
-        if (i < len) {
-            ring[i] = *(const uint4*)(Cf + byte_off(pixl));
-            advance(xl, pixl);
-        }
-    }
+    for (int i = 0; i < PF; i++) { ring[i] = load_c(pixl); advance(xl, pixl); }
 
-    for (int t0 = 0; t0 < len; t0 += PF) {
+    // steady state: no branches inside, so the PF loads stay in flight across iterations
+    int t0 = 0;
+    for (; t0 + PF <= len; t0 += PF) {
 #pragma unroll
         for (int i = 0; i < PF; i++) {
-            const int t = t0 + i;
-            if (t < len) {
-                const uint4 cw = ring[i];
-                if (t + PF < len) {
-                    ring[i] = *(const uint4*)(Cf + byte_off(pixl));
-                    advance(xl, pixl);
-                }
-                const bool start = (t == 0) || (BASE == 2 && x == 0) || (BASE == 3 && x == W - 1);
-                const uint32_t cv[4] = {cw.x, cw.y, cw.z, cw.w};
-                uint32_t CE[4], CO[4];
+            const uint4 cw = ring[i];
+            ring[i] = load_c(pixl);
+            advance(xl, pixl);
+            const uint4 o = step(cw, is_start(t0 + i));
+            *(uint4*)(Lf + byte_off(pix)) = o;
+            advance(x, pix);
+        }
+    }
+    // tail (len % PF steps): costs already in the ring
 #pragma unroll
-                for (int k = 0; k < 4; k++) { CE[k] = cv[k] & MASK; CO[k] = (cv[k] >> 8) & MASK; }
-
-                // lane-boundary neighbours
-                uint32_t prevO3 = dpp_mov<DPP_ROW_SHR1>(SENT, LO[3]);
-                uint32_t nextE0 = dpp_mov<DPP_ROW_SHL1>(SENT, LE[0]);
-                if (j == 0) prevO3 = SENT;                   // d = 0 has no d-1      (:47)
-                if (j == LPP - 1) nextE0 = SENT;             // d = D-1 has no d+1    (:48)
-
-                const uint32_t mpk = m | (m << 16);
-                uint32_t NE[4], NO[4];
-                if (!WRAP) {
-                    const uint32_t p2lane = start ? 0u : P2pk;   // min(.,0)=0 -> L = C at a path start
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t nbE = pk_min(align16(LO[k], k ? LO[k - 1] : prevO3), LO[k]);
-                        const uint32_t nbO = pk_min(LE[k], align16(k < 3 ? LE[k + 1] : nextE0, LE[k]));
-                        const uint32_t tE = pk_min(LE[k], pk_add(nbE, P1pk));
-                        const uint32_t tO = pk_min(LO[k], pk_add(nbO, P1pk));
-                        // C + min(t, m+P2) - m  ==  C + min(t-m, P2)   (no wrap: t >= m)
-                        NE[k] = pk_add(CE[k], pk_min(pk_sub(tE, mpk), p2lane));
-                        NO[k] = pk_add(CO[k], pk_min(pk_sub(tO, mpk), p2lane));
-                    }
-                } else {
-                    const uint32_t jump = (m + P2b) & 0xFFu;                       // :46 u8(LpreMin + P2)
-                    const uint32_t jpk = jump | (jump << 16);
-                    // mod-256 adds do not commute with min: narrow each neighbour + P1 first (:47-48),
-                    // and give the two non-existent neighbours the neutral candidate 255.
-                    const uint32_t noL = j == 0 ? 0x000000FFu : 0u;
-                    const uint32_t noR = j == LPP - 1 ? 0x00FF0000u : 0u;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t lE = align16(LO[k], k ? LO[k - 1] : prevO3);          // d-1 of E[k]
-                        const uint32_t rO = align16(k < 3 ? LE[k + 1] : nextE0, LE[k]);      // d+1 of O[k]
-                        uint32_t cEl = pk_add(lE, P1pk) & MASK;
-                        uint32_t cOr = pk_add(rO, P1pk) & MASK;
-                        if (k == 0) cEl |= noL;
-                        if (k == 3) cOr |= noR;
-                        const uint32_t cEr = pk_add(LO[k], P1pk) & MASK;                     // d+1 of E[k] = O[k]
-                        const uint32_t cOl = pk_add(LE[k], P1pk) & MASK;                     // d-1 of O[k] = E[k]
-                        const uint32_t tE = pk_min(pk_min(LE[k], jpk), pk_min(cEl, cEr));
-                        const uint32_t tO = pk_min(pk_min(LO[k], jpk), pk_min(cOl, cOr));
-                        const uint32_t e = pk_sub(pk_add(CE[k], tE), mpk) & MASK;  // :60 mod 256
-                        const uint32_t o = pk_sub(pk_add(CO[k], tO), mpk) & MASK;
-                        NE[k] = start ? CE[k] : e;
-                        NO[k] = start ? CO[k] : o;
-                    }
-                }
-                // minimum over d of the new costs (:61,:65); 0 at a path start (:154,:164)
-                uint32_t mm = pk_min(pk_min(pk_min(NE[0], NO[0]), pk_min(NE[1], NO[1])),
-                                     pk_min(pk_min(NE[2], NO[2]), pk_min(NE[3], NO[3])));
-                uint32_t mx = min(mm & 0xFFFFu, mm >> 16);
-                mx = group_min_u32<LPP>(mx);
-                m = start ? 0u : mx;
-#pragma unroll
-                for (int k = 0; k < 4; k++) { LE[k] = NE[k]; LO[k] = NO[k]; }
-
-                if (valid) {
-                    uint4 o;
-                    o.x = NE[0] | (NO[0] << 8); o.y = NE[1] | (NO[1] << 8);
-                    o.z = NE[2] | (NO[2] << 8); o.w = NE[3] | (NO[3] << 8);
-                    *(uint4*)(Lf + byte_off(pix)) = o;
-                }
-                advance(x, pix);
-            }
+    for (int i = 0; i < PF - 1; i++) {
+        if (t0 + i < len) {
+            const uint4 o = step(ring[i], is_start(t0 + i));
+            *(uint4*)(Lf + byte_off(pix)) = o;
+            advance(x, pix);
         }
     }
 }

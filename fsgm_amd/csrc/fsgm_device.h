@@ -38,6 +38,18 @@ __device__ __forceinline__ uint32_t align16(uint32_t hi, uint32_t lo) {
     return __builtin_amdgcn_alignbit(hi, lo, 16);
 }
 
+// 16-byte streaming store / load (written once, read once by a later kernel: keep it out of the
+// way of lines that are re-read)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nt(void* p, const uint4 v) {
+    u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (u32x4*)p);
+}
+__device__ __forceinline__ uint4 load_nt(const void* p) {
+    const u32x4 t = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
 // ---- DPP controls (gfx9 encoding) ----
 constexpr int DPP_QUAD_1032 = 0xB1;        // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_2301 = 0x4E;        // quad_perm:[2,3,0,1]
