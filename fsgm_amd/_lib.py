@@ -58,6 +58,7 @@ def load():
     lib.fsgm_epi_plan_destroy.argtypes = [vp]
     lib.fsgm_epi_plan_destroy.restype = None
     lib.fsgm_epi_plan_set_penalties.argtypes = [vp, i32, i32, C.c_double]
+    lib.fsgm_epi_plan_set_agg_mode.argtypes = [vp, i32]
     lib.fsgm_epi_plan_upload.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.fsgm_epi_plan_upload_cost.argtypes = [vp, i32, vp]
     lib.fsgm_epi_plan_upload_offset.argtypes = [vp, i32, vp]

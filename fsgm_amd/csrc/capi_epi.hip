@@ -29,8 +29,12 @@ struct fsgm_epi_plan {
     double *dPd0 = nullptr, *dNd = nullptr, *dOff = nullptr, *dVz = nullptr;
     uint8_t *dCraw = nullptr, *dC = nullptr, *dL = nullptr;
     uint32_t *dBestD = nullptr, *dMinC = nullptr, *dS = nullptr;
+    // fused-sweep aggregation (epi_sweep.hip): horizontal path costs, u16 sums, block-boundary states
+    uint8_t *dLh = nullptr, *dS16 = nullptr, *dState = nullptr;
+    size_t state_stride = 0;
     std::vector<int> cmax;               // per frame: upper bound of the cost values in dC
     bool vz_valid = false;
+    int agg_mode = 0;                    // 0 auto, 1 per-direction line kernels, 2 fused sweeps (if eligible)
     int kernel_kind = AGG_GENERIC;
     bool packed = false;
 };
@@ -41,6 +45,8 @@ static void select_kernel(fsgm_epi_plan* p) {
     const int cm = *std::max_element(p->cmax.begin(), p->cmax.end());
     const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + std::max(p->P1, p->P2) <= 255;
     p->kernel_kind = nowrap ? AGG_PACKED_NOWRAP : AGG_PACKED_WRAP;
+    // the fused sweeps cover the 8-path no-wrap case; everything else stays on the line kernels
+    if (nowrap && p->prm.paths == 8 && p->agg_mode != 1 && p->dS16) p->kernel_kind = AGG_SWEEP;
 }
 
 extern "C" {
@@ -74,7 +80,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dLh, p->dS16, p->dState};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -122,6 +128,12 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
     alloc((void**)&p->dL, B * p->N * pr.paths);
     alloc((void**)&p->dBestD, B * p->NP * 4);
     alloc((void**)&p->dMinC, B * p->NP * 4);
+    if (pr.paths == 8 && agg_packed_lpp(D)) {
+        p->state_stride = sweep_state_bytes(W, D);
+        alloc((void**)&p->dLh, B * p->N * 2);
+        alloc((void**)&p->dS16, B * p->N * 2);
+        alloc((void**)&p->dState, 2 * B * p->state_stride);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -212,14 +224,35 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         for (int& c : p->cmax) { if (c != 24) changed = true; c = 24; }
         if (changed) select_kernel(p);
     }
-    if (stages & FSGM_STAGE_AGGREGATE) {
+    if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_SWEEP) {
+        AggArgs a;                                   // the two horizontal paths: per-direction kernel, 2 slots
+        a.C = p->dC; a.L = p->dLh;
+        a.c_frame_stride = p->N; a.l_frame_stride = p->N * 2; a.l_dir_stride = p->N;
+        a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
+        launch_aggregate(p->stream, a, 2, p->batch, AGG_PACKED_NOWRAP);
+        SweepArgs w;
+        w.C = p->dC; w.c_frame_stride = p->N;
+        w.S = p->dS16; w.s_frame_stride = p->N * 2;
+        w.Lh = p->dLh; w.lh_frame_stride = p->N * 2; w.lh_dir_stride = p->N;
+        w.state_in = p->dState; w.state_out = p->dState; w.state_frame_stride = p->state_stride;
+        w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
+        launch_sweep(p->stream, w, p->batch, false);     // pass-0 paths from above
+        launch_sweep(p->stream, w, p->batch, true);      // their point mirrors + the horizontal pair
+    } else if (stages & FSGM_STAGE_AGGREGATE) {
         AggArgs a;
         a.C = p->dC; a.L = p->dL;
         a.c_frame_stride = p->N; a.l_frame_stride = p->N * p->prm.paths; a.l_dir_stride = p->N;
         a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
         launch_aggregate(p->stream, a, p->prm.paths, p->batch, p->kernel_kind);
     }
-    if (stages & FSGM_STAGE_WTA) {
+    if ((stages & FSGM_STAGE_WTA) && p->kernel_kind == AGG_SWEEP) {
+        WtaArgs a;
+        a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
+        a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
+        a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
+        a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
+        launch_wta_s16(p->stream, a, (const uint16_t*)p->dS16, p->N * 2, nullptr, p->batch);
+    } else if (stages & FSGM_STAGE_WTA) {
         WtaArgs a;
         a.L = p->dL; a.l_frame_stride = p->N * p->prm.paths; a.l_dir_stride = p->N;
         a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
@@ -236,6 +269,14 @@ fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* p, int32_t stages) {
     FSGM_REQUIRE((stages & ~FSGM_STAGE_ALL) == 0 && stages != 0, "bad stage mask %d", stages);
     FSGM_HIP(hipSetDevice(p->prm.device));
     return enqueue(p, stages);
+}
+
+fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* p, int32_t mode) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_REQUIRE(mode >= 0 && mode <= 2, "agg mode must be 0 (auto), 1 (per-direction kernels) or 2 (fused sweeps)");
+    p->agg_mode = mode;
+    select_kernel(p);
+    return FSGM_OK;
 }
 
 fsgm_status fsgm_epi_plan_sync(fsgm_epi_plan* p) {
@@ -268,6 +309,19 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
     FSGM_REQUIRE(p && S, "fsgm_epi_plan_download_sum: null argument");
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_HIP(hipSetDevice(p->prm.device));
+    if (p->kernel_kind == AGG_SWEEP) {               // re-run the S16 WTA of that frame with its debug tap on
+        if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
+        WtaArgs a;
+        a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
+        a.off = p->dOff + f * p->NP; a.bestD = p->dBestD + f * p->NP; a.minC = p->dMinC + f * p->NP; a.vMax = p->vMax;
+        a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
+        a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
+        launch_wta_s16(p->stream, a, (const uint16_t*)(p->dS16 + (size_t)f * p->N * 2), p->N * 2, p->dS, 1);
+        FSGM_HIP(hipGetLastError());
+        FSGM_HIP(hipStreamSynchronize(p->stream));
+        FSGM_HIP(hipMemcpy(S, p->dS, p->N * 4, hipMemcpyDeviceToHost));
+        return FSGM_OK;
+    }
     if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
     launch_sum_paths(p->stream, p->dL + (size_t)f * p->N * p->prm.paths, p->dS, p->N, p->N, p->prm.paths);
     FSGM_HIP(hipGetLastError());
@@ -305,6 +359,7 @@ const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* p) {
     switch (p->kernel_kind) {
         case AGG_PACKED_NOWRAP: return "packed16/nowrap";
         case AGG_PACKED_WRAP: return "packed16/wrap";
+        case AGG_SWEEP: return "sweep16/nowrap";
         default: return "generic";
     }
 }

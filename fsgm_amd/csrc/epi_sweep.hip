@@ -1,0 +1,345 @@
+// epi_sweep.hip -- fused-sweep aggregation for the 8-path calc_cost_sgm case (gfx950).
+//
+// Why: the per-direction kernel (epi_kernels.hip, agg_packed_kernel) moves 24 B per voxel through
+// HBM (8 reads of C, 8 writes + 8 reads of L_r) and is bandwidth-bound at ~1/5 of the algorithmic
+// roofline.  Here the three paths that advance row by row -- from above (0,+1), from above-left
+// (+1,+1) and from above-right (-1,+1), calc_cost_sgm.cpp:193-226 -- are computed TOGETHER for the
+// same pixel, so C is read once per sweep and only their sum leaves the chip:
+//
+//   horizontal kernel  (existing agg_packed_kernel, 2 slots)   C -> L_left, L_right      (u8)
+//   down sweep         C             -> S_dn = L_v + L_dl + L_dr                           (u16)
+//   up sweep (mirror)  C, S_dn, L_left, L_right -> S = all 8 paths                         (u16, in place)
+//   wta_s16_kernel     S -> bestD, minC
+//
+// = 16 B per voxel instead of 24.
+//
+// The diagonal paths couple neighbouring columns, so a workgroup that owns a strip of columns needs
+// its neighbours' boundary values every row.  Instead of in-kernel neighbour synchronisation the
+// sweep is cut into blocks of T rows (one launch per block) and every workgroup recomputes a halo
+// of T columns on each side (only the one diagonal direction that flows inwards): a value that is
+// wrong because ITS predecessor lay outside the halo moves one column per row and therefore cannot
+// reach the strip within T rows.  At block boundaries the three path states of every column go
+// through a small global buffer.  No spin-waits, no co-residency assumption.
+//
+// Workgroup = 4 waves; wave w owns PXW = 64/LPP adjacent columns (same lane layout as
+// agg_packed_kernel: LPP lanes x 16 d per pixel); strip = 4*PXW columns; T = 2*PXW, so the halo is
+// exactly 2 pixel groups per side = one extra unit of work per wave per row (balanced).
+// Per row every wave runs 4 DP steps: vertical / both diagonals for its own columns + 1 halo step.
+// The diagonal states shift one column per row through LDS (double buffered, one barrier per row).
+//
+// Path states are kept NORMALISED: L' = L - m, with m the stored minimum of that pixel (0 at a path
+// start, calc_cost_sgm.cpp:154).  Then  L_new = C + min( min(L'[d], min(L'[d-1],L'[d+1]) + P1), P2 )
+// needs no separate m.  Valid under the same no-wrap precondition as agg_packed_kernel<.,false>
+// (max C + P2 + max(P1,P2) <= 255, P1,P2 >= 0); other parameters use the per-direction kernels.
+#include "epi_kernels.h"
+#include "fsgm_device.h"
+#include "epi_wta_tail.h"
+
+namespace fsgm {
+
+namespace {
+
+constexpr uint32_t SEL_E = 0x0C020C00u;     // v_perm: bytes 0,2 -> 2 x u16
+constexpr uint32_t SEL_O = 0x0C030C01u;     // v_perm: bytes 1,3 -> 2 x u16
+constexpr uint32_t SEL_PACK = 0x06020400u;  // v_perm(O, E): bytes E.lo, O.lo, E.hi, O.hi
+
+__device__ __forceinline__ void unpack16(const uint4 v, uint32_t (&E)[4], uint32_t (&O)[4]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        E[k] = __builtin_amdgcn_perm(0u, w[k], SEL_E);
+        O[k] = __builtin_amdgcn_perm(0u, w[k], SEL_O);
+    }
+}
+__device__ __forceinline__ uint4 pack16(const uint32_t (&E)[4], const uint32_t (&O)[4]) {
+    uint4 o;
+    o.x = __builtin_amdgcn_perm(O[0], E[0], SEL_PACK);
+    o.y = __builtin_amdgcn_perm(O[1], E[1], SEL_PACK);
+    o.z = __builtin_amdgcn_perm(O[2], E[2], SEL_PACK);
+    o.w = __builtin_amdgcn_perm(O[3], E[3], SEL_PACK);
+    return o;
+}
+
+// One DP step on normalised state (calc_cost_sgm.cpp:33-66).  LE/LO: previous pixel's L - m;
+// on return they hold the new pixel's normalised state and NE/NO its true path costs.
+template <int LPP>
+__device__ __forceinline__ void step_norm(uint32_t (&LE)[4], uint32_t (&LO)[4], const uint32_t (&CE)[4],
+                                          const uint32_t (&CO)[4], uint32_t (&NE)[4], uint32_t (&NO)[4],
+                                          const bool start, const uint32_t P1pk, const uint32_t P2pk, const int j) {
+    constexpr uint32_t SENT = 0xFFFFFFFFu;
+    uint32_t prevO3 = dpp_mov<DPP_ROW_SHR1>(SENT, LO[3]);
+    uint32_t nextE0 = dpp_mov<DPP_ROW_SHL1>(SENT, LE[0]);
+    if (j == 0) prevO3 = SENT;                       // d = 0 has no d-1     (:47)
+    if (j == LPP - 1) nextE0 = SENT;                 // d = D-1 has no d+1   (:48)
+    const uint32_t p2lane = start ? 0u : P2pk;       // min(., 0) = 0  ->  L = C at a path start (:152-180)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t nbE = pk_min(align16(LO[k], k ? LO[k - 1] : prevO3), LO[k]);
+        const uint32_t nbO = pk_min(LE[k], align16(k < 3 ? LE[k + 1] : nextE0, LE[k]));
+        NE[k] = pk_add(CE[k], pk_min(pk_min(LE[k], pk_add(nbE, P1pk)), p2lane));
+        NO[k] = pk_add(CO[k], pk_min(pk_min(LO[k], pk_add(nbO, P1pk)), p2lane));
+    }
+    const uint32_t mm = pk_min(pk_min(pk_min(NE[0], NO[0]), pk_min(NE[1], NO[1])),
+                               pk_min(pk_min(NE[2], NO[2]), pk_min(NE[3], NO[3])));
+    uint32_t mx = min(mm & 0xFFFFu, mm >> 16);
+    mx = group_min_u32<LPP>(mx);
+    mx = start ? 0u : mx;                            // stored minimum 0 at a path start (:154,:164)
+    const uint32_t mpk = mx | (mx << 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { LE[k] = pk_sub(NE[k], mpk); LO[k] = pk_sub(NO[k], mpk); }
+}
+
+}  // namespace
+
+// =============================================================================================
+// sweep kernel: rows [y0, y0+rows) of the pass-0 frame (UP: of the point-mirrored frame).
+// =============================================================================================
+template <int LPP, bool UP>
+__global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
+    constexpr int PXW = 64 / LPP;            // columns per wave
+    constexpr int D = LPP * 16;
+    constexpr int STRIP = 4 * PXW;           // own columns per workgroup
+    constexpr int T = 2 * PXW;               // halo width = max rows per launch
+    constexpr int NCOL = STRIP + 2 * T + 2;  // LDS columns: forward column x  <->  index x - (a0 - T - 1)
+    constexpr int PF = 2;                    // rows of C in flight per lane
+    __shared__ uint4 sDiag[2][2][NCOL * LPP];    // [row parity][0: from above-left, 1: from above-right][column][lane-of-pixel]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane / LPP, j = lane % LPP;
+    const int W = a.W, H = a.H, NP = W * H;
+    const int a0 = (int)blockIdx.x * STRIP;                      // first own column of the strip
+    const size_t f = blockIdx.y;
+    const uint8_t* __restrict__ Cf = a.C + f * a.c_frame_stride;
+    uint4* __restrict__ Sf = (uint4*)(a.S + f * a.s_frame_stride);
+    const uint8_t* __restrict__ StIn = a.state_in + f * a.state_frame_stride;    // [3][W][D] u8, written by the previous launch
+    uint8_t* __restrict__ StOut = a.state_out + f * a.state_frame_stride;        // other buffer: no launch reads what it writes
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
+    const int y0 = a.y0, rows = min(a.rows, H - y0);
+    const bool first_block = y0 == 0;
+
+    // columns in the (possibly mirrored) sweep frame
+    const int gx = a0 + wave * PXW + g;                          // own column
+    const bool own_ok = gx < W;
+    const int gxc = min(gx, W - 1);
+    // halo unit of this wave: waves 0,1 -> from-above-left on the T columns left of the strip,
+    //                         waves 2,3 -> from-above-right on the T columns right of it
+    const int hdir = wave >> 1;
+    const int hx = hdir == 0 ? a0 - T + wave * PXW + g : a0 + STRIP + (wave - 2) * PXW + g;
+    const int hxc = min(max(hx, 0), W - 1);
+    const int lbase = a0 - T - 1;                                // forward column of LDS index 0
+
+    auto vox_off = [&](int x, int y) -> uint32_t {               // byte offset of (x,y)'s 16 costs of this lane
+        const int p = y * W + x;
+        return (uint32_t)(UP ? NP - 1 - p : p) * D + (uint32_t)j * 16;
+    };
+
+    // ---- block prologue: path states of the row above (from the previous launch) ----
+    uint32_t VE[4] = {0, 0, 0, 0}, VO[4] = {0, 0, 0, 0};          // vertical path state of the own column
+    if (!first_block) {
+        unpack16(*(const uint4*)(StIn + (size_t)gxc * D + j * 16), VE, VO);
+        for (int i = tid; i < 2 * NCOL * LPP; i += 256) {
+            const int dir = i / (NCOL * LPP), r = i - dir * (NCOL * LPP);
+            const int c = r / LPP, jj = r - c * LPP;
+            const int x = min(max(lbase + c, 0), W - 1);
+            sDiag[0][dir][r] = *(const uint4*)(StIn + ((size_t)(1 + dir) * W + x) * D + jj * 16);
+        }
+    }
+    __syncthreads();
+
+    uint4 ringOwn[PF], ringHalo[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        const int y = min(y0 + i, H - 1);
+        ringOwn[i] = *(const uint4*)(Cf + vox_off(gxc, y));
+        ringHalo[i] = *(const uint4*)(Cf + vox_off(hxc, y));
+    }
+
+    // one row of the block: 4 DP steps per wave, one barrier
+    auto do_row = [&](const int k, const uint4 cOwn, const uint4 cHalo) {
+        const int y = y0 + k, par = k & 1;
+        const bool top = y == 0;
+        uint32_t CE[4], CO[4], NE[4], NO[4], SE[4], SO[4];
+        unpack16(cOwn, CE, CO);
+
+        // from above (0,+1)                                            calc_cost_sgm.cpp:193-202
+        step_norm<LPP>(VE, VO, CE, CO, NE, NO, top, P1pk, P2pk, j);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { SE[q] = NE[q]; SO[q] = NO[q]; }
+
+        // from above-left (+1,+1): predecessor column gx-1                        :205-213
+        {
+            uint32_t LE[4], LO[4];
+            unpack16(sDiag[par][0][(gx - 1 - lbase) * LPP + j], LE, LO);
+            step_norm<LPP>(LE, LO, CE, CO, NE, NO, top || gx == 0, P1pk, P2pk, j);
+            sDiag[par ^ 1][0][(gx - lbase) * LPP + j] = pack16(LE, LO);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { SE[q] += NE[q]; SO[q] += NO[q]; }
+        }
+        // from above-right (-1,+1): predecessor column gx+1                       :215-225
+        {
+            uint32_t LE[4], LO[4];
+            unpack16(sDiag[par][1][(gx + 1 - lbase) * LPP + j], LE, LO);
+            step_norm<LPP>(LE, LO, CE, CO, NE, NO, top || gx == W - 1, P1pk, P2pk, j);
+            sDiag[par ^ 1][1][(gx - lbase) * LPP + j] = pack16(LE, LO);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { SE[q] += NE[q]; SO[q] += NO[q]; }
+        }
+        // halo unit: keeps the inward-flowing diagonal correct for the next rows
+        {
+            uint32_t HE[4], HO[4], LE[4], LO[4];
+            unpack16(cHalo, HE, HO);
+            const int px = hdir == 0 ? hx - 1 : hx + 1;
+            unpack16(sDiag[par][hdir][(px - lbase) * LPP + j], LE, LO);
+            const bool st = top || (hdir == 0 ? hx == 0 : hx == W - 1);
+            step_norm<LPP>(LE, LO, HE, HO, NE, NO, st, P1pk, P2pk, j);
+            sDiag[par ^ 1][hdir][(hx - lbase) * LPP + j] = pack16(LE, LO);
+        }
+        // sum of this sweep's three paths (+ the other five in the up sweep)        :227-232
+        if (own_ok) {
+            const size_t so = (size_t)vox_off(gx, y) >> 3;                 // uint4 index: 32 B per lane
+            if (UP) {
+                const uint4 s0 = Sf[so], s1 = Sf[so + 1];
+                SE[0] += s0.x; SO[0] += s0.y; SE[1] += s0.z; SO[1] += s0.w;
+                SE[2] += s1.x; SO[2] += s1.y; SE[3] += s1.z; SO[3] += s1.w;
+                const uint8_t* Lh = a.Lh + f * a.lh_frame_stride;
+                uint32_t E2[4], O2[4];
+                // slot 0 = from the left, slot 1 = from the right: both stored at ACTUAL pixel addresses
+                const int p = y * W + gx;
+                const uint32_t act = (uint32_t)(NP - 1 - p) * D + (uint32_t)j * 16;
+                unpack16(*(const uint4*)(Lh + act), E2, O2);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
+                unpack16(*(const uint4*)(Lh + a.lh_dir_stride + act), E2, O2);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
+            }
+            Sf[so] = make_uint4(SE[0], SO[0], SE[1], SO[1]);
+            Sf[so + 1] = make_uint4(SE[2], SO[2], SE[3], SO[3]);
+        }
+        __syncthreads();                                         // diagonal states of row y visible to row y+1
+    };
+
+    // steady state without branches so the prefetched rows stay in flight; then the tail
+    int k0 = 0;
+    for (; k0 + PF <= rows; k0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const uint4 cOwn = ringOwn[i], cHalo = ringHalo[i];
+            const int yn = min(y0 + k0 + i + PF, H - 1);
+            ringOwn[i] = *(const uint4*)(Cf + vox_off(gxc, yn));
+            ringHalo[i] = *(const uint4*)(Cf + vox_off(hxc, yn));
+            do_row(k0 + i, cOwn, cHalo);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PF - 1; i++)
+        if (k0 + i < rows) do_row(k0 + i, ringOwn[i], ringHalo[i]);   // block-uniform
+
+    // ---- block epilogue: states of the last row for the next launch ----
+    if (y0 + rows < H && own_ok) {
+        const int par = rows & 1;                                // buffer the last row wrote into
+        *(uint4*)(StOut + (size_t)gx * D + j * 16) = pack16(VE, VO);
+        *(uint4*)(StOut + ((size_t)W + gx) * D + j * 16) = sDiag[par][0][(gx - lbase) * LPP + j];
+        *(uint4*)(StOut + ((size_t)2 * W + gx) * D + j * 16) = sDiag[par][1][(gx - lbase) * LPP + j];
+    }
+}
+
+// =============================================================================================
+// WTA on the summed volume S (u16, lane-private layout written by the sweeps:
+// per pixel and lane j: {E0,O0,E1,O1},{E2,O2,E3,O3}, E[k] = (d[4k], d[4k+2]), O[k] = (d[4k+1], d[4k+3]))
+// calc_cost_sgm.cpp:259-308 + :414-426, same tail as wta_packed_kernel.
+// =============================================================================================
+template <int LPP>
+__global__ __launch_bounds__(256) void wta_s16_kernel(WtaArgs a, const uint16_t* __restrict__ S, size_t s_frame_stride,
+                                                       uint32_t* __restrict__ Sdbg) {
+    constexpr int D = LPP * 16;
+    constexpr int PPB = 256 / LPP;
+    __shared__ uint32_t sS[256 * 8];
+    const int tid = threadIdx.x;
+    const int NP = a.W * a.H;
+    const int gp = blockIdx.x * PPB + tid / LPP, j = tid % LPP;
+    const bool valid = gp < NP;
+    const int p = valid ? gp : NP - 1;
+    const size_t f = blockIdx.y;
+    const uint4* Sf = (const uint4*)((const uint8_t*)S + f * s_frame_stride);
+    const size_t so = ((size_t)p * D + (size_t)j * 16) >> 3;
+    const uint4 s0 = Sf[so], s1 = Sf[so + 1];
+    const uint32_t E[4] = {s0.x, s0.z, s1.x, s1.z}, O[4] = {s0.y, s0.w, s1.y, s1.w};
+    uint32_t key = 0xFFFFFFFFu;
+    uint32_t* row = sS + (size_t)(tid / LPP) * (D / 2) + j * 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t v0 = E[k] & 0xFFFF, v1 = O[k] & 0xFFFF, v2 = E[k] >> 16, v3 = O[k] >> 16;
+        row[2 * k] = v0 | (v1 << 16);
+        row[2 * k + 1] = v2 | (v3 << 16);
+        const uint32_t d0 = (uint32_t)j * 16 + 4 * k;
+        key = min(key, min(min((v0 << 8) | d0, (v1 << 8) | (d0 + 1)), min((v2 << 8) | (d0 + 2), (v3 << 8) | (d0 + 3))));
+        if (Sdbg && valid) {
+            uint32_t* o = Sdbg + f * (size_t)NP * D + (size_t)p * D + d0;
+            o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
+        }
+    }
+    key = group_min_u32<LPP>(key);
+    __syncthreads();
+    if (j == 0 && valid) {
+        const uint32_t best = key & 0xFF, minc = key >> 8;
+        const uint16_t* srow = (const uint16_t*)(sS + (size_t)(tid / LPP) * (D / 2));
+        uint32_t c_1 = 0, c1 = 0;
+        if (a.subpixel && best > 1) {
+            c_1 = srow[best - 1];
+            if (best + 1 < (uint32_t)D) c1 = srow[best + 1];
+            else if (p + 1 < NP) c1 = ((const uint16_t*)Sf)[(size_t)(p + 1) * D];       // next pixel's d=0 (:296)
+            else c1 = 0;
+        }
+        wta_finish(a, f, p, best, minc, c_1, c1);
+    }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+int sweep_rows_per_launch(int D) { const int lpp = agg_packed_lpp(D); return lpp ? 2 * (64 / lpp) : 0; }
+size_t sweep_state_bytes(int W, int D) { return (size_t)3 * W * D; }
+
+template <int LPP>
+static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, bool up) {
+    constexpr int STRIP = 4 * (64 / LPP), T = 2 * (64 / LPP);
+    dim3 grid((a.W + STRIP - 1) / STRIP, frames);
+    uint8_t* const buf0 = a.state_out;                     // caller passes the base of 2 x frames x state buffers
+    uint8_t* const buf1 = a.state_out + (size_t)frames * a.state_frame_stride;
+    int b = 0;
+    for (int y0 = 0; y0 < a.H; y0 += T, b ^= 1) {
+        a.y0 = y0;
+        a.rows = T;
+        a.state_in = b ? buf0 : buf1;
+        a.state_out = b ? buf1 : buf0;
+        if (up) hipLaunchKernelGGL((sweep_kernel<LPP, true>), grid, dim3(256), 0, st, a);
+        else    hipLaunchKernelGGL((sweep_kernel<LPP, false>), grid, dim3(256), 0, st, a);
+    }
+}
+
+void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, bool up) {
+    switch (agg_packed_lpp(a.D)) {
+        case 1: launch_sweep_t<1>(st, a, frames, up); break;
+        case 2: launch_sweep_t<2>(st, a, frames, up); break;
+        case 4: launch_sweep_t<4>(st, a, frames, up); break;
+        case 8: launch_sweep_t<8>(st, a, frames, up); break;
+        case 16: launch_sweep_t<16>(st, a, frames, up); break;
+        default: break;
+    }
+}
+
+void launch_wta_s16(hipStream_t st, const WtaArgs& a, const uint16_t* S, size_t s_frame_stride, uint32_t* Sdbg, int frames) {
+    const int NP = a.W * a.H;
+    const int lpp = agg_packed_lpp(a.D);
+    dim3 grid((NP + 256 / lpp - 1) / (256 / lpp), frames);
+    switch (lpp) {
+        case 1: hipLaunchKernelGGL(wta_s16_kernel<1>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
+        case 2: hipLaunchKernelGGL(wta_s16_kernel<2>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
+        case 4: hipLaunchKernelGGL(wta_s16_kernel<4>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
+        case 8: hipLaunchKernelGGL(wta_s16_kernel<8>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
+        case 16: hipLaunchKernelGGL(wta_s16_kernel<16>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
+    }
+}
+
+}  // namespace fsgm

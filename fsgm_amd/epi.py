@@ -106,6 +106,10 @@ class EpiPlan:
     def set_penalties(self, P1, P2, vMax=0.3):
         check(self.lib.fsgm_epi_plan_set_penalties(self._h, int(P1), int(P2), float(vMax)))
 
+    def set_agg_mode(self, mode):
+        """0 auto, 1 per-direction line kernels, 2 fused sweeps when eligible."""
+        check(self.lib.fsgm_epi_plan_set_agg_mode(self._h, int(mode)))
+
     def upload(self, frame, I1, I2, pd0, nd, off):
         I1, I2 = _u8img(I1, "I1"), _u8img(I2, "I2")
         pd0 = _f64(pd0, (2, self.H, self.W), "pixelPosD0")

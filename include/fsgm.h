@@ -103,6 +103,9 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** plan, int32_t width, int32_t he
                                  int32_t dMax, int32_t batch, const fsgm_epi_params* prm);
 void        fsgm_epi_plan_destroy(fsgm_epi_plan* plan);
 fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t P2, double vMax);
+/* Aggregation strategy: 0 = auto (fused sweeps when eligible: 8 paths, D = 16<<k, no-wrap
+ * penalties), 1 = per-direction line kernels, 2 = same as 0.  Results are identical. */
+fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* plan, int32_t mode);
 /* host -> HBM (async on the plan's stream) */
 fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* plan, int32_t frame, const uint8_t* I1,
                                  const uint8_t* I2, const double* pixelPosD0,
@@ -123,7 +126,7 @@ fsgm_status fsgm_epi_plan_time(fsgm_epi_plan* plan, int32_t stages, int32_t warm
                                int32_t iters, float* ms_avg);
 /* the hipStream_t the plan launches on */
 void*       fsgm_epi_plan_stream(fsgm_epi_plan* plan);
-/* which aggregation kernel the plan selected: "packed16/nowrap", "packed16/wrap", "generic" */
+/* which aggregation kernel the plan selected: "sweep16/nowrap", "packed16/nowrap", "packed16/wrap", "generic" */
 const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* plan);
 /* device-to-device copy bandwidth probe (GB/s, read+write bytes counted) used by bench.py */
 fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps);

@@ -80,10 +80,35 @@ def test_aggregate_sum_bit_exact(gpu_lib, oracle, W, H, D, P1, P2, cmax, kernel,
     with EpiPlan(W, H, D, 1, paths=paths) as plan:
         plan.set_penalties(P1, P2, 0.3)
         plan.upload_cost(0, Cv)
+        # auto mode: the fused sweeps take the 8-path no-wrap case, the line kernels everything else
+        assert plan.kernel_name == ("sweep16/nowrap" if (paths == 8 and kernel == "packed16/nowrap") else kernel)
+        plan.run(STAGE_AGGREGATE)
+        got = plan.download_sum(0)
+        np.testing.assert_array_equal(got, want)
+        plan.set_agg_mode(1)                                # per-direction line kernels
         assert plan.kernel_name == kernel
         plan.run(STAGE_AGGREGATE)
         got = plan.download_sum(0)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("W,H,D", [(70, 40, 128), (200, 53, 64), (33, 100, 128), (130, 35, 32), (50, 20, 256), (257, 19, 16)])
+def test_sweep_blocks_and_strips(gpu_lib, oracle, W, H, D):
+    """Fused sweeps across several row blocks and column strips (block / halo / state hand-over paths)."""
+    Cv = synth.cost_volume(W, H, D, seed=W + H, cmax=24)
+    Cv[:, ::7, :] = 0                                        # strong structure so diagonals carry information far
+    want = oracle.epi_aggregate(Cv, 6, 64, 8)[:-1].reshape(H, W, D)
+    with EpiPlan(W, H, D, 2, paths=8) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        plan.upload_cost(0, Cv)
+        plan.upload_cost(1, np.ascontiguousarray(Cv[::-1]))
+        assert plan.kernel_name == "sweep16/nowrap"
+        plan.run(STAGE_AGGREGATE)
+        got = plan.download_sum(0)
+        got1 = plan.download_sum(1)
+    np.testing.assert_array_equal(got, want)
+    want1 = oracle.epi_aggregate(np.ascontiguousarray(Cv[::-1]), 6, 64, 8)[:-1].reshape(H, W, D)
+    np.testing.assert_array_equal(got1, want1)
 
 
 def test_aggregate_tiny_and_degenerate_shapes(gpu_lib, oracle):
