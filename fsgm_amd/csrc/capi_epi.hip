@@ -30,8 +30,11 @@ struct fsgm_epi_plan {
     uint8_t *dCraw = nullptr, *dC = nullptr, *dL = nullptr;
     uint32_t *dBestD = nullptr, *dMinC = nullptr, *dS = nullptr;
     // fused-sweep aggregation (epi_sweep.hip): horizontal path costs, u16 sums, block-boundary states
-    uint8_t *dLh = nullptr, *dS16 = nullptr, *dState = nullptr;
+    // (three independent producers -> three streams; see enqueue())
+    uint8_t *dLh = nullptr, *dS16 = nullptr, *dSup = nullptr, *dState = nullptr, *dStateUp = nullptr;
     size_t state_stride = 0;
+    hipStream_t stream_h = nullptr, stream_up = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_h = nullptr, ev_up = nullptr;
     std::vector<int> cmax;               // per frame: upper bound of the cost values in dC
     bool vz_valid = false;
     int agg_mode = 0;                    // 0 auto, 1 per-direction line kernels, 2 fused sweeps (if eligible)
@@ -80,12 +83,15 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dLh, p->dS16, p->dState};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dLh, p->dS16, p->dSup, p->dState, p->dStateUp};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    for (hipEvent_t e : {p->ev_fork, p->ev_h, p->ev_up})
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {p->stream, p->stream_h, p->stream_up})
+        if (st) (void)hipStreamDestroy(st);
     delete p;
 }
 
@@ -125,14 +131,22 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
     alloc((void**)&p->dVz, (size_t)D * 8);
     alloc((void**)&p->dCraw, B * p->N);
     alloc((void**)&p->dC, B * p->N);
-    alloc((void**)&p->dL, B * p->N * pr.paths);
+    const bool sweep_ok = pr.paths == 8 && agg_packed_lpp(D) != 0;
+    if (!sweep_ok) alloc((void**)&p->dL, B * p->N * pr.paths);     // else allocated on first use of the line kernels
     alloc((void**)&p->dBestD, B * p->NP * 4);
     alloc((void**)&p->dMinC, B * p->NP * 4);
-    if (pr.paths == 8 && agg_packed_lpp(D)) {
+    if (sweep_ok) {
         p->state_stride = sweep_state_bytes(W, D);
         alloc((void**)&p->dLh, B * p->N * 2);
         alloc((void**)&p->dS16, B * p->N * 2);
+        alloc((void**)&p->dSup, B * p->N * 2);
         alloc((void**)&p->dState, 2 * B * p->state_stride);
+        alloc((void**)&p->dStateUp, 2 * B * p->state_stride);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream_h, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream_up, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_up, hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
@@ -225,20 +239,30 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         if (changed) select_kernel(p);
     }
     if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_SWEEP) {
+        // Three independent producers of partial sums, forked off the plan's stream and joined
+        // before the WTA: a single sweep launch (strips x frames workgroups) does not fill 256 CUs.
+        FSGM_HIP(hipEventRecord(p->ev_fork, p->stream));
+        FSGM_HIP(hipStreamWaitEvent(p->stream_h, p->ev_fork, 0));
+        FSGM_HIP(hipStreamWaitEvent(p->stream_up, p->ev_fork, 0));
         AggArgs a;                                   // the two horizontal paths: per-direction kernel, 2 slots
         a.C = p->dC; a.L = p->dLh;
         a.c_frame_stride = p->N; a.l_frame_stride = p->N * 2; a.l_dir_stride = p->N;
         a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
-        launch_aggregate(p->stream, a, 2, p->batch, AGG_PACKED_NOWRAP);
+        launch_aggregate(p->stream_h, a, 2, p->batch, AGG_PACKED_NOWRAP);
         SweepArgs w;
-        w.C = p->dC; w.c_frame_stride = p->N;
-        w.S = p->dS16; w.s_frame_stride = p->N * 2;
-        w.Lh = p->dLh; w.lh_frame_stride = p->N * 2; w.lh_dir_stride = p->N;
-        w.state_in = p->dState; w.state_out = p->dState; w.state_frame_stride = p->state_stride;
+        w.C = p->dC; w.c_frame_stride = p->N; w.s_frame_stride = p->N * 2;
+        w.state_frame_stride = p->state_stride;
         w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
+        w.S = p->dSup; w.state_in = p->dStateUp; w.state_out = p->dStateUp;
+        launch_sweep(p->stream_up, w, p->batch, true);   // pass-1 paths (point mirror)
+        w.S = p->dS16; w.state_in = p->dState; w.state_out = p->dState;
         launch_sweep(p->stream, w, p->batch, false);     // pass-0 paths from above
-        launch_sweep(p->stream, w, p->batch, true);      // their point mirrors + the horizontal pair
+        FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
+        FSGM_HIP(hipEventRecord(p->ev_up, p->stream_up));
+        FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_h, 0));
+        FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_up, 0));
     } else if (stages & FSGM_STAGE_AGGREGATE) {
+        if (!p->dL) FSGM_HIP(hipMalloc((void**)&p->dL, (size_t)p->batch * p->N * p->prm.paths));
         AggArgs a;
         a.C = p->dC; a.L = p->dL;
         a.c_frame_stride = p->N; a.l_frame_stride = p->N * p->prm.paths; a.l_dir_stride = p->N;
@@ -251,7 +275,10 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
         a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
-        launch_wta_s16(p->stream, a, (const uint16_t*)p->dS16, p->N * 2, nullptr, p->batch);
+        SweepSumArgs q;
+        q.Sdn = p->dS16; q.Sup = p->dSup; q.s_frame_stride = p->N * 2;
+        q.Lh = p->dLh; q.lh_frame_stride = p->N * 2; q.lh_dir_stride = p->N; q.Sdbg = nullptr;
+        launch_wta_sweep(p->stream, a, q, p->batch);
     } else if (stages & FSGM_STAGE_WTA) {
         WtaArgs a;
         a.L = p->dL; a.l_frame_stride = p->N * p->prm.paths; a.l_dir_stride = p->N;
@@ -316,7 +343,10 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         a.off = p->dOff + f * p->NP; a.bestD = p->dBestD + f * p->NP; a.minC = p->dMinC + f * p->NP; a.vMax = p->vMax;
         a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
-        launch_wta_s16(p->stream, a, (const uint16_t*)(p->dS16 + (size_t)f * p->N * 2), p->N * 2, p->dS, 1);
+        SweepSumArgs q;
+        q.Sdn = p->dS16 + (size_t)f * p->N * 2; q.Sup = p->dSup + (size_t)f * p->N * 2; q.s_frame_stride = p->N * 2;
+        q.Lh = p->dLh + (size_t)f * p->N * 2; q.lh_frame_stride = p->N * 2; q.lh_dir_stride = p->N; q.Sdbg = p->dS;
+        launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));
         FSGM_HIP(hipMemcpy(S, p->dS, p->N * 4, hipMemcpyDeviceToHost));

@@ -48,16 +48,23 @@ struct WtaArgs {
 struct SweepArgs {
     const uint8_t* C;         // [frames] cost volumes
     size_t c_frame_stride;
-    uint8_t* S;               // [frames] summed path costs, u16, lane-private layout (see epi_sweep.hip)
+    uint8_t* S;               // [frames] this sweep's sum of three paths, u16, lane-private layout (see epi_sweep.hip)
     size_t s_frame_stride;    // bytes
-    const uint8_t* Lh;        // [frames][2] horizontal path costs (from the left, from the right), up sweep only
-    size_t lh_frame_stride, lh_dir_stride;
     const uint8_t* state_in;  // [frames][3][W][D] normalised path states of the row above this block
     uint8_t* state_out;       // same, written for the next block
     size_t state_frame_stride;
     int W, H, D;
     int P1, P2;
     int y0, rows;             // rows [y0, y0+rows) of the sweep frame
+};
+
+struct SweepSumArgs {          // what wta_sweep_kernel adds up
+    const uint8_t* Sdn;       // [frames] u16 sums of the down sweep
+    const uint8_t* Sup;       // [frames] u16 sums of the up sweep
+    size_t s_frame_stride;
+    const uint8_t* Lh;        // [frames][2] u8 horizontal path costs (from the left, from the right)
+    size_t lh_frame_stride, lh_dir_stride;
+    uint32_t* Sdbg;           // optional natural-order u32 dump of S [frames][NP][D]
 };
 
 enum { AGG_PACKED_NOWRAP = 0, AGG_PACKED_WRAP = 1, AGG_GENERIC = 2, AGG_SWEEP = 3 };
@@ -70,7 +77,7 @@ void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
 int    sweep_rows_per_launch(int D);
 size_t sweep_state_bytes(int W, int D);   // one state buffer of one frame
 void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, bool up);
-void launch_wta_s16(hipStream_t st, const WtaArgs& a, const uint16_t* S, size_t s_frame_stride, uint32_t* Sdbg, int frames);
+void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);
 void launch_sum_paths(hipStream_t st, const uint8_t* L, uint32_t* S, size_t n, size_t dir_stride, int ndirs);
 
 }  // namespace fsgm

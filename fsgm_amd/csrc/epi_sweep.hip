@@ -6,12 +6,13 @@
 // (+1,+1) and from above-right (-1,+1), calc_cost_sgm.cpp:193-226 -- are computed TOGETHER for the
 // same pixel, so C is read once per sweep and only their sum leaves the chip:
 //
-//   horizontal kernel  (existing agg_packed_kernel, 2 slots)   C -> L_left, L_right      (u8)
-//   down sweep         C             -> S_dn = L_v + L_dl + L_dr                           (u16)
-//   up sweep (mirror)  C, S_dn, L_left, L_right -> S = all 8 paths                         (u16, in place)
-//   wta_s16_kernel     S -> bestD, minC
+//   horizontal kernel  (existing agg_packed_kernel, 2 slots)   C -> L_left, L_right   (u8)
+//   down sweep         C -> S_dn = sum of the three pass-0 paths from above             (u16)
+//   up sweep           C -> S_up = the same on the point-mirrored frame (pass 1)        (u16)
+//   wta_sweep_kernel   S_dn + S_up + L_left + L_right -> bestD, minC
 //
-// = 16 B per voxel instead of 24.
+// = 16 B per voxel instead of 24, and the three producers are independent of each other, so
+// they run concurrently on three streams (each sweep launch alone is too small to fill 256 CUs).
 //
 // The diagonal paths couple neighbouring columns, so a workgroup that owns a strip of columns needs
 // its neighbours' boundary values every row.  Instead of in-kernel neighbour synchronisation the
@@ -194,25 +195,9 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
             step_norm<LPP>(LE, LO, HE, HO, NE, NO, st, P1pk, P2pk, j);
             sDiag[par ^ 1][hdir][(hx - lbase) * LPP + j] = pack16(LE, LO);
         }
-        // sum of this sweep's three paths (+ the other five in the up sweep)        :227-232
+        // sum of this sweep's three paths                                           :227-232
         if (own_ok) {
             const size_t so = (size_t)vox_off(gx, y) >> 3;                 // uint4 index: 32 B per lane
-            if (UP) {
-                const uint4 s0 = Sf[so], s1 = Sf[so + 1];
-                SE[0] += s0.x; SO[0] += s0.y; SE[1] += s0.z; SO[1] += s0.w;
-                SE[2] += s1.x; SO[2] += s1.y; SE[3] += s1.z; SO[3] += s1.w;
-                const uint8_t* Lh = a.Lh + f * a.lh_frame_stride;
-                uint32_t E2[4], O2[4];
-                // slot 0 = from the left, slot 1 = from the right: both stored at ACTUAL pixel addresses
-                const int p = y * W + gx;
-                const uint32_t act = (uint32_t)(NP - 1 - p) * D + (uint32_t)j * 16;
-                unpack16(*(const uint4*)(Lh + act), E2, O2);
-#pragma unroll
-                for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
-                unpack16(*(const uint4*)(Lh + a.lh_dir_stride + act), E2, O2);
-#pragma unroll
-                for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
-            }
             Sf[so] = make_uint4(SE[0], SO[0], SE[1], SO[1]);
             Sf[so + 1] = make_uint4(SE[2], SO[2], SE[3], SO[3]);
         }
@@ -245,13 +230,12 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
 }
 
 // =============================================================================================
-// WTA on the summed volume S (u16, lane-private layout written by the sweeps:
-// per pixel and lane j: {E0,O0,E1,O1},{E2,O2,E3,O3}, E[k] = (d[4k], d[4k+2]), O[k] = (d[4k+1], d[4k+3]))
-// calc_cost_sgm.cpp:259-308 + :414-426, same tail as wta_packed_kernel.
+// WTA over S = S_dn + S_up + L_left + L_right  (calc_cost_sgm.cpp:227-232, :259-308, :414-426).
+// S_dn / S_up: u16 in the sweeps' lane-private layout -- per pixel and lane j two uint4
+// {E0,O0,E1,O1},{E2,O2,E3,O3} with E[k] = (d[4k], d[4k+2]), O[k] = (d[4k+1], d[4k+3]).
 // =============================================================================================
 template <int LPP>
-__global__ __launch_bounds__(256) void wta_s16_kernel(WtaArgs a, const uint16_t* __restrict__ S, size_t s_frame_stride,
-                                                       uint32_t* __restrict__ Sdbg) {
+__global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs q) {
     constexpr int D = LPP * 16;
     constexpr int PPB = 256 / LPP;
     __shared__ uint32_t sS[256 * 8];
@@ -261,10 +245,21 @@ __global__ __launch_bounds__(256) void wta_s16_kernel(WtaArgs a, const uint16_t*
     const bool valid = gp < NP;
     const int p = valid ? gp : NP - 1;
     const size_t f = blockIdx.y;
-    const uint4* Sf = (const uint4*)((const uint8_t*)S + f * s_frame_stride);
-    const size_t so = ((size_t)p * D + (size_t)j * 16) >> 3;
-    const uint4 s0 = Sf[so], s1 = Sf[so + 1];
-    const uint32_t E[4] = {s0.x, s0.z, s1.x, s1.z}, O[4] = {s0.y, s0.w, s1.y, s1.w};
+    const size_t bo = (size_t)p * D + (size_t)j * 16;                    // byte offset in a u8 volume
+    const uint4* Sd = (const uint4*)(q.Sdn + f * q.s_frame_stride);
+    const uint4* Su = (const uint4*)(q.Sup + f * q.s_frame_stride);
+    const uint8_t* Lh = q.Lh + f * q.lh_frame_stride;
+    const uint4 d0 = Sd[bo >> 3], d1 = Sd[(bo >> 3) + 1], u0 = Su[bo >> 3], u1 = Su[(bo >> 3) + 1];
+    uint32_t E[4] = {d0.x + u0.x, d0.z + u0.z, d1.x + u1.x, d1.z + u1.z};
+    uint32_t O[4] = {d0.y + u0.y, d0.w + u0.w, d1.y + u1.y, d1.w + u1.w};
+    uint32_t E2[4], O2[4];
+    unpack16(*(const uint4*)(Lh + bo), E2, O2);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
+    unpack16(*(const uint4*)(Lh + q.lh_dir_stride + bo), E2, O2);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
+
     uint32_t key = 0xFFFFFFFFu;
     uint32_t* row = sS + (size_t)(tid / LPP) * (D / 2) + j * 8;
 #pragma unroll
@@ -272,10 +267,10 @@ __global__ __launch_bounds__(256) void wta_s16_kernel(WtaArgs a, const uint16_t*
         const uint32_t v0 = E[k] & 0xFFFF, v1 = O[k] & 0xFFFF, v2 = E[k] >> 16, v3 = O[k] >> 16;
         row[2 * k] = v0 | (v1 << 16);
         row[2 * k + 1] = v2 | (v3 << 16);
-        const uint32_t d0 = (uint32_t)j * 16 + 4 * k;
-        key = min(key, min(min((v0 << 8) | d0, (v1 << 8) | (d0 + 1)), min((v2 << 8) | (d0 + 2), (v3 << 8) | (d0 + 3))));
-        if (Sdbg && valid) {
-            uint32_t* o = Sdbg + f * (size_t)NP * D + (size_t)p * D + d0;
+        const uint32_t dd = (uint32_t)j * 16 + 4 * k;
+        key = min(key, min(min((v0 << 8) | dd, (v1 << 8) | (dd + 1)), min((v2 << 8) | (dd + 2), (v3 << 8) | (dd + 3))));
+        if (q.Sdbg && valid) {
+            uint32_t* o = q.Sdbg + f * (size_t)NP * D + (size_t)p * D + dd;
             o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
         }
     }
@@ -288,8 +283,10 @@ __global__ __launch_bounds__(256) void wta_s16_kernel(WtaArgs a, const uint16_t*
         if (a.subpixel && best > 1) {
             c_1 = srow[best - 1];
             if (best + 1 < (uint32_t)D) c1 = srow[best + 1];
-            else if (p + 1 < NP) c1 = ((const uint16_t*)Sf)[(size_t)(p + 1) * D];       // next pixel's d=0 (:296)
-            else c1 = 0;
+            else if (p + 1 < NP) {                                           // next pixel's d=0 (:296)
+                const size_t nb = (size_t)(p + 1) * D;
+                c1 = (uint32_t)((const uint16_t*)Sd)[nb] + ((const uint16_t*)Su)[nb] + Lh[nb] + Lh[q.lh_dir_stride + nb];
+            }
         }
         wta_finish(a, f, p, best, minc, c_1, c1);
     }
@@ -329,16 +326,16 @@ void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, bool up) {
     }
 }
 
-void launch_wta_s16(hipStream_t st, const WtaArgs& a, const uint16_t* S, size_t s_frame_stride, uint32_t* Sdbg, int frames) {
+void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames) {
     const int NP = a.W * a.H;
     const int lpp = agg_packed_lpp(a.D);
     dim3 grid((NP + 256 / lpp - 1) / (256 / lpp), frames);
     switch (lpp) {
-        case 1: hipLaunchKernelGGL(wta_s16_kernel<1>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
-        case 2: hipLaunchKernelGGL(wta_s16_kernel<2>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
-        case 4: hipLaunchKernelGGL(wta_s16_kernel<4>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
-        case 8: hipLaunchKernelGGL(wta_s16_kernel<8>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
-        case 16: hipLaunchKernelGGL(wta_s16_kernel<16>, grid, dim3(256), 0, st, a, S, s_frame_stride, Sdbg); break;
+        case 1: hipLaunchKernelGGL(wta_sweep_kernel<1>, grid, dim3(256), 0, st, a, q); break;
+        case 2: hipLaunchKernelGGL(wta_sweep_kernel<2>, grid, dim3(256), 0, st, a, q); break;
+        case 4: hipLaunchKernelGGL(wta_sweep_kernel<4>, grid, dim3(256), 0, st, a, q); break;
+        case 8: hipLaunchKernelGGL(wta_sweep_kernel<8>, grid, dim3(256), 0, st, a, q); break;
+        case 16: hipLaunchKernelGGL(wta_sweep_kernel<16>, grid, dim3(256), 0, st, a, q); break;
     }
 }
 
