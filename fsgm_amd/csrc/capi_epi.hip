@@ -30,11 +30,14 @@ struct fsgm_epi_plan {
     uint8_t *dCraw = nullptr, *dC = nullptr, *dL = nullptr;
     uint32_t *dBestD = nullptr, *dMinC = nullptr, *dS = nullptr;
     // fused-sweep aggregation (epi_sweep.hip): horizontal path costs, u16 sums, block-boundary states
-    // (three independent producers -> three streams; see enqueue())
-    uint8_t *dLh = nullptr, *dS16 = nullptr, *dSup = nullptr, *dState = nullptr, *dStateUp = nullptr;
+    // (see enqueue(): horizontal kernel on stream_h; the frames split into two lanes that sweep
+    // down then up on stream / stream_b)
+    uint8_t *dLh = nullptr, *dX = nullptr, *dXup = nullptr, *dState = nullptr;
+    uint4* dRec = nullptr;
+    uint16_t* dS0 = nullptr;
     size_t state_stride = 0;
-    hipStream_t stream_h = nullptr, stream_up = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_h = nullptr, ev_up = nullptr;
+    hipStream_t stream_h = nullptr, stream_b = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_h = nullptr, ev_b = nullptr;
     std::vector<int> cmax;               // per frame: upper bound of the cost values in dC
     bool vz_valid = false;
     int agg_mode = 0;                    // 0 auto, 1 per-direction line kernels, 2 fused sweeps (if eligible)
@@ -49,7 +52,8 @@ static void select_kernel(fsgm_epi_plan* p) {
     const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + std::max(p->P1, p->P2) <= 255;
     p->kernel_kind = nowrap ? AGG_PACKED_NOWRAP : AGG_PACKED_WRAP;
     // the fused sweeps cover the 8-path no-wrap case; everything else stays on the line kernels
-    if (nowrap && p->prm.paths == 8 && p->agg_mode != 1 && p->dS16) p->kernel_kind = AGG_SWEEP;
+    // (3*P2 <= 255: the excess sum of three paths fits a byte)
+    if (nowrap && 3 * p->P2 <= 255 && p->prm.paths == 8 && p->agg_mode != 1 && p->dX) p->kernel_kind = AGG_SWEEP;
 }
 
 extern "C" {
@@ -83,14 +87,14 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dLh, p->dS16, p->dSup, p->dState, p->dStateUp};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dLh, p->dX, p->dXup, p->dState, p->dRec, p->dS0};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    for (hipEvent_t e : {p->ev_fork, p->ev_h, p->ev_up})
+    for (hipEvent_t e : {p->ev_fork, p->ev_h, p->ev_b})
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {p->stream, p->stream_h, p->stream_up})
+    for (hipStream_t st : {p->stream, p->stream_h, p->stream_b})
         if (st) (void)hipStreamDestroy(st);
     delete p;
 }
@@ -138,15 +142,15 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
     if (sweep_ok) {
         p->state_stride = sweep_state_bytes(W, D);
         alloc((void**)&p->dLh, B * p->N * 2);
-        alloc((void**)&p->dS16, B * p->N * 2);
-        alloc((void**)&p->dSup, B * p->N * 2);
+        alloc((void**)&p->dX, B * p->N);
         alloc((void**)&p->dState, 2 * B * p->state_stride);
-        alloc((void**)&p->dStateUp, 2 * B * p->state_stride);
+        alloc((void**)&p->dRec, B * p->NP * sizeof(uint4));
+        alloc((void**)&p->dS0, B * p->NP * sizeof(uint16_t));
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream_h, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream_up, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream_b, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_up, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_b, hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
@@ -239,28 +243,39 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         if (changed) select_kernel(p);
     }
     if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_SWEEP) {
-        // Three independent producers of partial sums, forked off the plan's stream and joined
-        // before the WTA: a single sweep launch (strips x frames workgroups) does not fill 256 CUs.
+        // One sweep launch (strips x frames workgroups) cannot fill 256 CUs, so the work is forked:
+        // the horizontal pair runs on stream_h, and the frames split into two lanes, each sweeping
+        // down and then up (the final up sweep needs its lane's X_dn and the horizontal pair).
+        const int nA = (p->batch + 1) / 2, nB = p->batch - nA;
         FSGM_HIP(hipEventRecord(p->ev_fork, p->stream));
         FSGM_HIP(hipStreamWaitEvent(p->stream_h, p->ev_fork, 0));
-        FSGM_HIP(hipStreamWaitEvent(p->stream_up, p->ev_fork, 0));
+        if (nB) FSGM_HIP(hipStreamWaitEvent(p->stream_b, p->ev_fork, 0));
         AggArgs a;                                   // the two horizontal paths: per-direction kernel, 2 slots
         a.C = p->dC; a.L = p->dLh;
         a.c_frame_stride = p->N; a.l_frame_stride = p->N * 2; a.l_dir_stride = p->N;
         a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
         launch_aggregate(p->stream_h, a, 2, p->batch, AGG_PACKED_NOWRAP);
-        SweepArgs w;
-        w.C = p->dC; w.c_frame_stride = p->N; w.s_frame_stride = p->N * 2;
-        w.state_frame_stride = p->state_stride;
-        w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
-        w.S = p->dSup; w.state_in = p->dStateUp; w.state_out = p->dStateUp;
-        launch_sweep(p->stream_up, w, p->batch, true);   // pass-1 paths (point mirror)
-        w.S = p->dS16; w.state_in = p->dState; w.state_out = p->dState;
-        launch_sweep(p->stream, w, p->batch, false);     // pass-0 paths from above
         FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
-        FSGM_HIP(hipEventRecord(p->ev_up, p->stream_up));
-        FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_h, 0));
-        FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_up, 0));
+        for (int lane = 0; lane < 2; lane++) {
+            const int f0 = lane ? nA : 0, nf = lane ? nB : nA;
+            if (!nf) continue;
+            hipStream_t st = lane ? p->stream_b : p->stream;
+            SweepArgs w;
+            w.C = p->dC + (size_t)f0 * p->N; w.c_frame_stride = p->N;
+            w.X = p->dX + (size_t)f0 * p->N; w.x_frame_stride = p->N;
+            w.Lh = p->dLh + (size_t)f0 * p->N * 2; w.lh_frame_stride = p->N * 2; w.lh_dir_stride = p->N;
+            w.rec = p->dRec + (size_t)f0 * p->NP; w.s0 = p->dS0 + (size_t)f0 * p->NP;
+            w.state_in = w.state_out = p->dState + (size_t)2 * f0 * p->state_stride;
+            w.state_frame_stride = p->state_stride;
+            w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
+            launch_sweep(st, w, nf, 0);                              // pass-0 paths from above -> X_dn
+            FSGM_HIP(hipStreamWaitEvent(st, p->ev_h, 0));
+            launch_sweep(st, w, nf, 2);                              // pass-1 paths + everything else + WTA
+        }
+        if (nB) {
+            FSGM_HIP(hipEventRecord(p->ev_b, p->stream_b));
+            FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_b, 0));
+        }
     } else if (stages & FSGM_STAGE_AGGREGATE) {
         if (!p->dL) FSGM_HIP(hipMalloc((void**)&p->dL, (size_t)p->batch * p->N * p->prm.paths));
         AggArgs a;
@@ -270,15 +285,12 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         launch_aggregate(p->stream, a, p->prm.paths, p->batch, p->kernel_kind);
     }
     if ((stages & FSGM_STAGE_WTA) && p->kernel_kind == AGG_SWEEP) {
-        WtaArgs a;
+        WtaArgs a;                                   // the argmin happened inside the final sweep; finish the records
         a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
         a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
         a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
-        SweepSumArgs q;
-        q.Sdn = p->dS16; q.Sup = p->dSup; q.s_frame_stride = p->N * 2;
-        q.Lh = p->dLh; q.lh_frame_stride = p->N * 2; q.lh_dir_stride = p->N; q.Sdbg = nullptr;
-        launch_wta_sweep(p->stream, a, q, p->batch);
+        launch_sweep_finish(p->stream, a, p->dRec, p->dS0, p->batch);
     } else if (stages & FSGM_STAGE_WTA) {
         WtaArgs a;
         a.L = p->dL; a.l_frame_stride = p->N * p->prm.paths; a.l_dir_stride = p->N;
@@ -336,15 +348,27 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
     FSGM_REQUIRE(p && S, "fsgm_epi_plan_download_sum: null argument");
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_HIP(hipSetDevice(p->prm.device));
-    if (p->kernel_kind == AGG_SWEEP) {               // re-run the S16 WTA of that frame with its debug tap on
+    if (p->kernel_kind == AGG_SWEEP) {
+        // S never exists in HBM in sweep mode.  Debug tap: materialise X_up of that frame with a
+        // non-final up sweep, then let wta_sweep_kernel rebuild S = X_dn + X_up + 6C + L_left + L_right.
+        FSGM_HIP(hipStreamSynchronize(p->stream));
         if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
+        if (!p->dXup) FSGM_HIP(hipMalloc((void**)&p->dXup, p->N));
+        SweepArgs w;
+        w.C = p->dC + (size_t)f * p->N; w.c_frame_stride = p->N;
+        w.X = p->dXup; w.x_frame_stride = p->N;
+        w.Lh = nullptr; w.lh_frame_stride = 0; w.lh_dir_stride = 0; w.rec = nullptr; w.s0 = nullptr;
+        w.state_in = w.state_out = p->dState + (size_t)2 * f * p->state_stride;   // idle now: scratch for one frame
+        w.state_frame_stride = p->state_stride;
+        w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
+        launch_sweep(p->stream, w, 1, 1);
         WtaArgs a;
         a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
         a.off = p->dOff + f * p->NP; a.bestD = p->dBestD + f * p->NP; a.minC = p->dMinC + f * p->NP; a.vMax = p->vMax;
         a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
         SweepSumArgs q;
-        q.Sdn = p->dS16 + (size_t)f * p->N * 2; q.Sup = p->dSup + (size_t)f * p->N * 2; q.s_frame_stride = p->N * 2;
+        q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX + (size_t)f * p->N; q.Xup = p->dXup; q.v_frame_stride = p->N;
         q.Lh = p->dLh + (size_t)f * p->N * 2; q.lh_frame_stride = p->N * 2; q.lh_dir_stride = p->N; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());

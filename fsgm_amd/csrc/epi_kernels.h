@@ -48,8 +48,12 @@ struct WtaArgs {
 struct SweepArgs {
     const uint8_t* C;         // [frames] cost volumes
     size_t c_frame_stride;
-    uint8_t* S;               // [frames] this sweep's sum of three paths, u16, lane-private layout (see epi_sweep.hip)
-    size_t s_frame_stride;    // bytes
+    uint8_t* X;               // [frames] u8 excess sums: written by modes 0/1, read (the down sweep's) by mode 2
+    size_t x_frame_stride;
+    const uint8_t* Lh;        // mode 2: [frames][2] horizontal path costs (from the left, from the right)
+    size_t lh_frame_stride, lh_dir_stride;
+    uint4* rec;               // mode 2: [frames][NP] {best, minC, S[best-1], S[best+1]}
+    uint16_t* s0;             // mode 2: [frames][NP] S[0] of every pixel
     const uint8_t* state_in;  // [frames][3][W][D] normalised path states of the row above this block
     uint8_t* state_out;       // same, written for the next block
     size_t state_frame_stride;
@@ -58,11 +62,12 @@ struct SweepArgs {
     int y0, rows;             // rows [y0, y0+rows) of the sweep frame
 };
 
-struct SweepSumArgs {          // what wta_sweep_kernel adds up
-    const uint8_t* Sdn;       // [frames] u16 sums of the down sweep
-    const uint8_t* Sup;       // [frames] u16 sums of the up sweep
-    size_t s_frame_stride;
-    const uint8_t* Lh;        // [frames][2] u8 horizontal path costs (from the left, from the right)
+struct SweepSumArgs {          // what wta_sweep_kernel adds up (all u8 volumes, one frame stride)
+    const uint8_t* C;
+    const uint8_t* Xdn;       // excess sums of the down sweep
+    const uint8_t* Xup;       // excess sums of the up sweep
+    size_t v_frame_stride;
+    const uint8_t* Lh;        // [frames][2] horizontal path costs (from the left, from the right)
     size_t lh_frame_stride, lh_dir_stride;
     uint32_t* Sdbg;           // optional natural-order u32 dump of S [frames][NP][D]
 };
@@ -76,7 +81,8 @@ void launch_aggregate(hipStream_t st, AggArgs a, int paths, int frames, int kern
 void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
 int    sweep_rows_per_launch(int D);
 size_t sweep_state_bytes(int W, int D);   // one state buffer of one frame
-void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, bool up);
+void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode);   // 0 down, 1 up, 2 up + fused WTA
+void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames);
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);
 void launch_sum_paths(hipStream_t st, const uint8_t* L, uint32_t* S, size_t n, size_t dir_stride, int ndirs);
 

@@ -7,12 +7,17 @@
 // same pixel, so C is read once per sweep and only their sum leaves the chip:
 //
 //   horizontal kernel  (existing agg_packed_kernel, 2 slots)   C -> L_left, L_right   (u8)
-//   down sweep         C -> S_dn = sum of the three pass-0 paths from above             (u16)
-//   up sweep           C -> S_up = the same on the point-mirrored frame (pass 1)        (u16)
-//   wta_sweep_kernel   S_dn + S_up + L_left + L_right -> bestD, minC
+//   down sweep         C -> X_dn = sum over the three pass-0 paths from above of (L_r - C)   (u8)
+//   up sweep           C -> X_up = the same on the point-mirrored frame (pass 1)             (u8)
+//   wta_sweep_kernel   S = X_dn + X_up + 6*C + L_left + L_right -> bestD, minC
 //
-// = 16 B per voxel instead of 24, and the three producers are independent of each other, so
-// they run concurrently on three streams (each sweep launch alone is too small to fill 256 CUs).
+// Every path cost satisfies C <= L_r <= C + P2 when nothing wraps, so the EXCESS L_r - C of three
+// paths fits a byte whenever 3*P2 <= 255 (the reference uses P2 = 64 and 32): the partial sums
+// cost 1 B per voxel instead of 2.  Total 13 B per voxel instead of 24, and the three producers
+// are independent of each other, so they run concurrently on three streams (one sweep launch
+// alone -- strips x frames workgroups -- is too small to fill 256 CUs).
+// MODE 2 (final up sweep) goes further: it reads X_dn and the horizontal pair itself, forms S in
+// registers and does the WTA on the spot, so neither X_up nor S ever reaches HBM (10 B/voxel).
 //
 // The diagonal paths couple neighbouring columns, so a workgroup that owns a strip of columns needs
 // its neighbours' boundary values every row.  Instead of in-kernel neighbour synchronisation the
@@ -62,11 +67,13 @@ __device__ __forceinline__ uint4 pack16(const uint32_t (&E)[4], const uint32_t (
 }
 
 // One DP step on normalised state (calc_cost_sgm.cpp:33-66).  LE/LO: previous pixel's L - m;
-// on return they hold the new pixel's normalised state and NE/NO its true path costs.
+// on return they hold the new pixel's normalised state, and XE/XO its excess L_new - C
+// (= min(L'[d], min(L'[d-1], L'[d+1]) + P1, P2), in [0, P2]).
 template <int LPP>
 __device__ __forceinline__ void step_norm(uint32_t (&LE)[4], uint32_t (&LO)[4], const uint32_t (&CE)[4],
-                                          const uint32_t (&CO)[4], uint32_t (&NE)[4], uint32_t (&NO)[4],
+                                          const uint32_t (&CO)[4], uint32_t (&XE)[4], uint32_t (&XO)[4],
                                           const bool start, const uint32_t P1pk, const uint32_t P2pk, const int j) {
+    uint32_t NE[4], NO[4];
     constexpr uint32_t SENT = 0xFFFFFFFFu;
     uint32_t prevO3 = dpp_mov<DPP_ROW_SHR1>(SENT, LO[3]);
     uint32_t nextE0 = dpp_mov<DPP_ROW_SHL1>(SENT, LE[0]);
@@ -77,8 +84,10 @@ __device__ __forceinline__ void step_norm(uint32_t (&LE)[4], uint32_t (&LO)[4], 
     for (int k = 0; k < 4; k++) {
         const uint32_t nbE = pk_min(align16(LO[k], k ? LO[k - 1] : prevO3), LO[k]);
         const uint32_t nbO = pk_min(LE[k], align16(k < 3 ? LE[k + 1] : nextE0, LE[k]));
-        NE[k] = pk_add(CE[k], pk_min(pk_min(LE[k], pk_add(nbE, P1pk)), p2lane));
-        NO[k] = pk_add(CO[k], pk_min(pk_min(LO[k], pk_add(nbO, P1pk)), p2lane));
+        XE[k] = pk_min(pk_min(LE[k], pk_add(nbE, P1pk)), p2lane);
+        XO[k] = pk_min(pk_min(LO[k], pk_add(nbO, P1pk)), p2lane);
+        NE[k] = pk_add(CE[k], XE[k]);
+        NO[k] = pk_add(CO[k], XO[k]);
     }
     const uint32_t mm = pk_min(pk_min(pk_min(NE[0], NO[0]), pk_min(NE[1], NO[1])),
                                pk_min(pk_min(NE[2], NO[2]), pk_min(NE[3], NO[3])));
@@ -93,10 +102,14 @@ __device__ __forceinline__ void step_norm(uint32_t (&LE)[4], uint32_t (&LO)[4], 
 }  // namespace
 
 // =============================================================================================
-// sweep kernel: rows [y0, y0+rows) of the pass-0 frame (UP: of the point-mirrored frame).
+// sweep kernel: rows [y0, y0+rows) of the sweep frame.
+//   MODE 0: pass-0 frame, writes X_dn.   MODE 1: point-mirrored frame, writes X_up.
+//   MODE 2: point-mirrored frame, final: S = X_dn + X_up + 6C + L_left + L_right in registers,
+//           WTA per pixel, writes one record {best, minC, S[best-1], S[best+1]} + S[0] per pixel.
 // =============================================================================================
-template <int LPP, bool UP>
+template <int LPP, int MODE>
 __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
+    constexpr bool UP = MODE != 0;
     constexpr int PXW = 64 / LPP;            // columns per wave
     constexpr int D = LPP * 16;
     constexpr int STRIP = 4 * PXW;           // own columns per workgroup
@@ -104,6 +117,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
     constexpr int NCOL = STRIP + 2 * T + 2;  // LDS columns: forward column x  <->  index x - (a0 - T - 1)
     constexpr int PF = 2;                    // rows of C in flight per lane
     __shared__ uint4 sDiag[2][2][NCOL * LPP];    // [row parity][0: from above-left, 1: from above-right][column][lane-of-pixel]
+    __shared__ uint32_t sRow[MODE == 2 ? 256 * 8 : 1];   // MODE 2: S of the wave's pixels in natural d order (u16)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPP, j = lane % LPP;
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
     const int a0 = (int)blockIdx.x * STRIP;                      // first own column of the strip
     const size_t f = blockIdx.y;
     const uint8_t* __restrict__ Cf = a.C + f * a.c_frame_stride;
-    uint4* __restrict__ Sf = (uint4*)(a.S + f * a.s_frame_stride);
+    uint8_t* __restrict__ Xf = a.X + f * a.x_frame_stride;
     const uint8_t* __restrict__ StIn = a.state_in + f * a.state_frame_stride;    // [3][W][D] u8, written by the previous launch
     uint8_t* __restrict__ StOut = a.state_out + f * a.state_frame_stride;        // other buffer: no launch reads what it writes
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
@@ -129,9 +143,12 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
     const int hxc = min(max(hx, 0), W - 1);
     const int lbase = a0 - T - 1;                                // forward column of LDS index 0
 
-    auto vox_off = [&](int x, int y) -> uint32_t {               // byte offset of (x,y)'s 16 costs of this lane
+    auto pix_of = [&](int x, int y) -> int {                     // actual pixel index of sweep-frame (x,y)
         const int p = y * W + x;
-        return (uint32_t)(UP ? NP - 1 - p : p) * D + (uint32_t)j * 16;
+        return UP ? NP - 1 - p : p;
+    };
+    auto vox_off = [&](int x, int y) -> uint32_t {               // byte offset of (x,y)'s 16 costs of this lane
+        return (uint32_t)pix_of(x, y) * D + (uint32_t)j * 16;
     };
 
     // ---- block prologue: path states of the row above (from the previous launch) ----
@@ -159,31 +176,31 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
     auto do_row = [&](const int k, const uint4 cOwn, const uint4 cHalo) {
         const int y = y0 + k, par = k & 1;
         const bool top = y == 0;
-        uint32_t CE[4], CO[4], NE[4], NO[4], SE[4], SO[4];
+        uint32_t CE[4], CO[4], XE[4], XO[4], SE[4], SO[4];
         unpack16(cOwn, CE, CO);
 
         // from above (0,+1)                                            calc_cost_sgm.cpp:193-202
-        step_norm<LPP>(VE, VO, CE, CO, NE, NO, top, P1pk, P2pk, j);
+        step_norm<LPP>(VE, VO, CE, CO, XE, XO, top, P1pk, P2pk, j);
 #pragma unroll
-        for (int q = 0; q < 4; q++) { SE[q] = NE[q]; SO[q] = NO[q]; }
+        for (int q = 0; q < 4; q++) { SE[q] = XE[q]; SO[q] = XO[q]; }
 
         // from above-left (+1,+1): predecessor column gx-1                        :205-213
         {
             uint32_t LE[4], LO[4];
             unpack16(sDiag[par][0][(gx - 1 - lbase) * LPP + j], LE, LO);
-            step_norm<LPP>(LE, LO, CE, CO, NE, NO, top || gx == 0, P1pk, P2pk, j);
+            step_norm<LPP>(LE, LO, CE, CO, XE, XO, top || gx == 0, P1pk, P2pk, j);
             sDiag[par ^ 1][0][(gx - lbase) * LPP + j] = pack16(LE, LO);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { SE[q] += NE[q]; SO[q] += NO[q]; }
+            for (int q = 0; q < 4; q++) { SE[q] += XE[q]; SO[q] += XO[q]; }
         }
         // from above-right (-1,+1): predecessor column gx+1                       :215-225
         {
             uint32_t LE[4], LO[4];
             unpack16(sDiag[par][1][(gx + 1 - lbase) * LPP + j], LE, LO);
-            step_norm<LPP>(LE, LO, CE, CO, NE, NO, top || gx == W - 1, P1pk, P2pk, j);
+            step_norm<LPP>(LE, LO, CE, CO, XE, XO, top || gx == W - 1, P1pk, P2pk, j);
             sDiag[par ^ 1][1][(gx - lbase) * LPP + j] = pack16(LE, LO);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { SE[q] += NE[q]; SO[q] += NO[q]; }
+            for (int q = 0; q < 4; q++) { SE[q] += XE[q]; SO[q] += XO[q]; }
         }
         // halo unit: keeps the inward-flowing diagonal correct for the next rows
         {
@@ -192,14 +209,48 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
             const int px = hdir == 0 ? hx - 1 : hx + 1;
             unpack16(sDiag[par][hdir][(px - lbase) * LPP + j], LE, LO);
             const bool st = top || (hdir == 0 ? hx == 0 : hx == W - 1);
-            step_norm<LPP>(LE, LO, HE, HO, NE, NO, st, P1pk, P2pk, j);
+            step_norm<LPP>(LE, LO, HE, HO, XE, XO, st, P1pk, P2pk, j);
             sDiag[par ^ 1][hdir][(hx - lbase) * LPP + j] = pack16(LE, LO);
         }
-        // sum of this sweep's three paths                                           :227-232
-        if (own_ok) {
-            const size_t so = (size_t)vox_off(gx, y) >> 3;                 // uint4 index: 32 B per lane
-            Sf[so] = make_uint4(SE[0], SO[0], SE[1], SO[1]);
-            Sf[so + 1] = make_uint4(SE[2], SO[2], SE[3], SO[3]);
+        if (MODE != 2) {
+            // excess sum of this sweep's three paths, one byte per voxel (3*P2 <= 255)      :227-232
+            if (own_ok) *(uint4*)(Xf + vox_off(gx, y)) = pack16(SE, SO);
+        } else {
+            // S = X_up (registers) + X_dn + 6*C + from-the-left + from-the-right, all at this pixel
+            const uint32_t off = vox_off(gxc, y);
+            const uint8_t* Lh = a.Lh + f * a.lh_frame_stride;
+            uint32_t E2[4], O2[4];
+            unpack16(*(const uint4*)(Xf + off), E2, O2);                          // X_dn
+#pragma unroll
+            for (int q = 0; q < 4; q++) { SE[q] += E2[q] + 6u * CE[q]; SO[q] += O2[q] + 6u * CO[q]; }
+            unpack16(*(const uint4*)(Lh + off), E2, O2);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
+            unpack16(*(const uint4*)(Lh + a.lh_dir_stride + off), E2, O2);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
+            // WTA: first minimum over d (:263-271) via (S << 8 | d) keys
+            uint32_t key = 0xFFFFFFFFu;
+            uint32_t* row = sRow + (size_t)(tid / LPP) * (D / 2) + j * 8;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t v0 = SE[q] & 0xFFFF, v1 = SO[q] & 0xFFFF, v2 = SE[q] >> 16, v3 = SO[q] >> 16;
+                row[2 * q] = v0 | (v1 << 16);
+                row[2 * q + 1] = v2 | (v3 << 16);
+                const uint32_t dd = (uint32_t)j * 16 + 4 * q;
+                key = min(key, min(min((v0 << 8) | dd, (v1 << 8) | (dd + 1)), min((v2 << 8) | (dd + 2), (v3 << 8) | (dd + 3))));
+            }
+            key = group_min_u32<LPP>(key);
+            __builtin_amdgcn_wave_barrier();                 // sRow rows are private to the wave that wrote them
+            if (j == 0 && own_ok) {
+                const uint32_t best = key & 0xFF, minc = key >> 8;
+                const uint16_t* srow = (const uint16_t*)(sRow + (size_t)(tid / LPP) * (D / 2));
+                const uint32_t c_1 = best > 0 ? srow[best - 1] : 0u;
+                const uint32_t c1 = best + 1 < (uint32_t)D ? srow[best + 1] : 0u;   // best == D-1: fsgm finish kernel takes the next pixel's S[0]
+                const int ap = pix_of(gx, y);
+                a.rec[f * (size_t)NP + ap] = make_uint4(best, minc, c_1, c1);
+                a.s0[f * (size_t)NP + ap] = (uint16_t)srow[0];
+            }
         }
         __syncthreads();                                         // diagonal states of row y visible to row y+1
     };
@@ -230,9 +281,24 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
 }
 
 // =============================================================================================
-// WTA over S = S_dn + S_up + L_left + L_right  (calc_cost_sgm.cpp:227-232, :259-308, :414-426).
-// S_dn / S_up: u16 in the sweeps' lane-private layout -- per pixel and lane j two uint4
-// {E0,O0,E1,O1},{E2,O2,E3,O3} with E[k] = (d[4k], d[4k+2]), O[k] = (d[4k+1], d[4k+3]).
+// finish kernel for MODE 2: parabola + vz->disparity from the per-pixel records
+// (calc_cost_sgm.cpp:278-308, :414-426).  best == D-1 reads the next pixel's S[0] (:296).
+// =============================================================================================
+__global__ __launch_bounds__(256) void sweep_finish_kernel(WtaArgs a, const uint4* __restrict__ rec,
+                                                           const uint16_t* __restrict__ s0) {
+    const int NP = a.W * a.H;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    const size_t f = blockIdx.y;
+    const uint4 r = rec[f * (size_t)NP + p];
+    uint32_t c1 = r.w;
+    if (r.x + 1 == (uint32_t)a.D) c1 = p + 1 < NP ? (uint32_t)s0[f * (size_t)NP + p + 1] : 0u;
+    wta_finish(a, f, p, r.x, r.y, r.z, c1);
+}
+
+// =============================================================================================
+// WTA over S = X_dn + X_up + 6*C + L_left + L_right  (calc_cost_sgm.cpp:227-232, :259-308, :414-426)
+// for the non-final mode (X_up materialised by a MODE 1 sweep).
 // =============================================================================================
 template <int LPP>
 __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs q) {
@@ -246,13 +312,17 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
     const int p = valid ? gp : NP - 1;
     const size_t f = blockIdx.y;
     const size_t bo = (size_t)p * D + (size_t)j * 16;                    // byte offset in a u8 volume
-    const uint4* Sd = (const uint4*)(q.Sdn + f * q.s_frame_stride);
-    const uint4* Su = (const uint4*)(q.Sup + f * q.s_frame_stride);
     const uint8_t* Lh = q.Lh + f * q.lh_frame_stride;
-    const uint4 d0 = Sd[bo >> 3], d1 = Sd[(bo >> 3) + 1], u0 = Su[bo >> 3], u1 = Su[(bo >> 3) + 1];
-    uint32_t E[4] = {d0.x + u0.x, d0.z + u0.z, d1.x + u1.x, d1.z + u1.z};
-    uint32_t O[4] = {d0.y + u0.y, d0.w + u0.w, d1.y + u1.y, d1.w + u1.w};
-    uint32_t E2[4], O2[4];
+    uint32_t E[4], O[4], E2[4], O2[4];
+    unpack16(*(const uint4*)(q.C + f * q.v_frame_stride + bo), E, O);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { E[k] *= 6u; O[k] *= 6u; }
+    unpack16(*(const uint4*)(q.Xdn + f * q.v_frame_stride + bo), E2, O2);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
+    unpack16(*(const uint4*)(q.Xup + f * q.v_frame_stride + bo), E2, O2);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
     unpack16(*(const uint4*)(Lh + bo), E2, O2);
 #pragma unroll
     for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
@@ -284,8 +354,8 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
             c_1 = srow[best - 1];
             if (best + 1 < (uint32_t)D) c1 = srow[best + 1];
             else if (p + 1 < NP) {                                           // next pixel's d=0 (:296)
-                const size_t nb = (size_t)(p + 1) * D;
-                c1 = (uint32_t)((const uint16_t*)Sd)[nb] + ((const uint16_t*)Su)[nb] + Lh[nb] + Lh[q.lh_dir_stride + nb];
+                const size_t nb = f * q.v_frame_stride + (size_t)(p + 1) * D;
+                c1 = 6u * q.C[nb] + q.Xdn[nb] + q.Xup[nb] + Lh[(size_t)(p + 1) * D] + Lh[q.lh_dir_stride + (size_t)(p + 1) * D];
             }
         }
         wta_finish(a, f, p, best, minc, c_1, c1);
@@ -299,7 +369,7 @@ int sweep_rows_per_launch(int D) { const int lpp = agg_packed_lpp(D); return lpp
 size_t sweep_state_bytes(int W, int D) { return (size_t)3 * W * D; }
 
 template <int LPP>
-static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, bool up) {
+static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode) {
     constexpr int STRIP = 4 * (64 / LPP), T = 2 * (64 / LPP);
     dim3 grid((a.W + STRIP - 1) / STRIP, frames);
     uint8_t* const buf0 = a.state_out;                     // caller passes the base of 2 x frames x state buffers
@@ -310,20 +380,25 @@ static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, bool up) {
         a.rows = T;
         a.state_in = b ? buf0 : buf1;
         a.state_out = b ? buf1 : buf0;
-        if (up) hipLaunchKernelGGL((sweep_kernel<LPP, true>), grid, dim3(256), 0, st, a);
-        else    hipLaunchKernelGGL((sweep_kernel<LPP, false>), grid, dim3(256), 0, st, a);
+        if (mode == 0)      hipLaunchKernelGGL((sweep_kernel<LPP, 0>), grid, dim3(256), 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((sweep_kernel<LPP, 1>), grid, dim3(256), 0, st, a);
+        else                hipLaunchKernelGGL((sweep_kernel<LPP, 2>), grid, dim3(256), 0, st, a);
     }
 }
 
-void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, bool up) {
+void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode) {
     switch (agg_packed_lpp(a.D)) {
-        case 1: launch_sweep_t<1>(st, a, frames, up); break;
-        case 2: launch_sweep_t<2>(st, a, frames, up); break;
-        case 4: launch_sweep_t<4>(st, a, frames, up); break;
-        case 8: launch_sweep_t<8>(st, a, frames, up); break;
-        case 16: launch_sweep_t<16>(st, a, frames, up); break;
+        case 1: launch_sweep_t<1>(st, a, frames, mode); break;
+        case 2: launch_sweep_t<2>(st, a, frames, mode); break;
+        case 4: launch_sweep_t<4>(st, a, frames, mode); break;
+        case 8: launch_sweep_t<8>(st, a, frames, mode); break;
+        case 16: launch_sweep_t<16>(st, a, frames, mode); break;
         default: break;
     }
+}
+
+void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames) {
+    hipLaunchKernelGGL(sweep_finish_kernel, dim3((a.W * a.H + 255) / 256, frames), dim3(256), 0, st, a, rec, s0);
 }
 
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames) {
