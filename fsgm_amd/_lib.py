@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfsgm_hip.so")
+# FSGM_LIB_PATH: developer override to A/B two builds of the library in one session
+LIB_PATH = os.environ.get("FSGM_LIB_PATH") or os.path.join(_HERE, "libfsgm_hip.so")
 
 FSGM_OK = 0
 STAGE_COST, STAGE_AGGREGATE, STAGE_WTA, STAGE_ALL = 1, 2, 4, 7

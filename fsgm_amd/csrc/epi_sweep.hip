@@ -108,14 +108,14 @@ __device__ __forceinline__ void step_norm(uint32_t (&LE)[4], uint32_t (&LO)[4], 
 //           WTA per pixel, writes one record {best, minC, S[best-1], S[best+1]} + S[0] per pixel.
 // =============================================================================================
 template <int LPP, int MODE>
-__global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(256, 4) void sweep_kernel(SweepArgs a) {   // <= 128 VGPRs: 4 workgroups per CU
     constexpr bool UP = MODE != 0;
     constexpr int PXW = 64 / LPP;            // columns per wave
     constexpr int D = LPP * 16;
     constexpr int STRIP = 4 * PXW;           // own columns per workgroup
     constexpr int T = 2 * PXW;               // halo width = max rows per launch
     constexpr int NCOL = STRIP + 2 * T + 2;  // LDS columns: forward column x  <->  index x - (a0 - T - 1)
-    constexpr int PF = 2;                    // rows of C in flight per lane
+    constexpr int PF = MODE == 2 ? 2 : 3;    // rows of C in flight per lane
     __shared__ uint4 sDiag[2][2][NCOL * LPP];    // [row parity][0: from above-left, 1: from above-right][column][lane-of-pixel]
     __shared__ uint32_t sRow[MODE == 2 ? 256 * 8 : 1];   // MODE 2: S of the wave's pixels in natural d order (u16)
 
@@ -172,10 +172,21 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
         ringHalo[i] = *(const uint4*)(Cf + vox_off(hxc, y));
     }
 
+    const uint8_t* __restrict__ Lhf = MODE == 2 ? a.Lh + f * a.lh_frame_stride : nullptr;
+
     // one row of the block: 4 DP steps per wave, one barrier
     auto do_row = [&](const int k, const uint4 cOwn, const uint4 cHalo) {
         const int y = y0 + k, par = k & 1;
         const bool top = y == 0;
+        // MODE 2: the other partial sums of the own pixel; issued now, consumed after the four DP
+        // steps of this row, which hide most of their latency
+        uint4 curX, curL0, curL1;
+        if (MODE == 2) {
+            const uint32_t off = vox_off(gxc, y);
+            curX = *(const uint4*)(Xf + off);
+            curL0 = *(const uint4*)(Lhf + off);
+            curL1 = *(const uint4*)(Lhf + a.lh_dir_stride + off);
+        }
         uint32_t CE[4], CO[4], XE[4], XO[4], SE[4], SO[4];
         unpack16(cOwn, CE, CO);
 
@@ -217,16 +228,14 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs a) {
             if (own_ok) *(uint4*)(Xf + vox_off(gx, y)) = pack16(SE, SO);
         } else {
             // S = X_up (registers) + X_dn + 6*C + from-the-left + from-the-right, all at this pixel
-            const uint32_t off = vox_off(gxc, y);
-            const uint8_t* Lh = a.Lh + f * a.lh_frame_stride;
             uint32_t E2[4], O2[4];
-            unpack16(*(const uint4*)(Xf + off), E2, O2);                          // X_dn
+            unpack16(curX, E2, O2);                                               // X_dn
 #pragma unroll
             for (int q = 0; q < 4; q++) { SE[q] += E2[q] + 6u * CE[q]; SO[q] += O2[q] + 6u * CO[q]; }
-            unpack16(*(const uint4*)(Lh + off), E2, O2);
+            unpack16(curL0, E2, O2);
 #pragma unroll
             for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
-            unpack16(*(const uint4*)(Lh + a.lh_dir_stride + off), E2, O2);
+            unpack16(curL1, E2, O2);
 #pragma unroll
             for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
             // WTA: first minimum over d (:263-271) via (S << 8 | d) keys
