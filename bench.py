@@ -22,6 +22,9 @@ sys.path.insert(0, ROOT)
 W, H, D, PATHS = 1242, 375, 128, 8
 P1, P2, VMAX = 6, 64, 0.3
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM/fabric bytes per voxel of the sweep pipeline from rocprofv3 PMC passes (FETCH_SIZE doubled as
+# MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, + WRITE_SIZE), profiles/r01_pmc_traffic.md
+TRAFFIC_BYTES_PER_VOXEL = 11.4
 
 
 def cpu_baseline(sample_rows=48):
@@ -50,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-gpu", type=int, default=8)
+    ap.add_argument("--frames-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -74,9 +77,13 @@ def main():
     plan = EpiPlan(W, H, D, B, paths=PATHS, device=local_rank)
     plan.set_penalties(P1, P2, VMAX)
     _, _, off = synth.epi_maps(W, H, "axis")
-    for f in range(B):                                       # distinct seed per (rank, frame)
-        plan.upload_cost(f, synth.cost_volume(W, H, D, seed=1000 * rank + f, cmax=24))
+    # distinct volume per (rank, frame): 4 seeded base volumes per rank, the others are column
+    # rotations of them (cheap to make, still all different)
+    bases = [synth.cost_volume(W, H, D, seed=1000 * rank + s, cmax=24) for s in range(min(4, B))]
+    for f in range(B):
+        plan.upload_cost(f, bases[f] if f < 4 else np.ascontiguousarray(np.roll(bases[f % 4], 37 * (f // 4), axis=1)))
         plan.upload_offset(f, off)
+    del bases
     stages = STAGE_AGGREGATE | STAGE_WTA
 
     def barrier():
@@ -97,7 +104,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-kernel timing with HIP events on the plan's own stream (rank 0 reports)
+    # stage timing with HIP events on the plan's own stream (the forked streams join it before the
+    # second event), rank 0 reports
     agg_ms = plan.time(STAGE_AGGREGATE, warmup=1, iters=max(3, args.steps // 2))
     wta_ms = plan.time(STAGE_WTA, warmup=1, iters=max(3, args.steps // 2))
 
@@ -114,9 +122,13 @@ def main():
             "config": {"workload": "KITTI 1242x375 D=128, 8 paths, aggregation stage (C resident in HBM -> bestD/minC)",
                        "frames_per_gpu": B, "P1": P1, "P2": P2, "kernel": plan.kernel_name,
                        "step": "aggregate(8 paths) + sum/WTA/subpixel", "sharding": "frames, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "agg_packed_kernel<8,false>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": agg_ms, "wta_ms": wta_ms},
+            # the aggregation is one stage of three kernel types that run concurrently on three
+            # streams (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane, agg_packed_kernel<8>
+            # for the horizontal pair): the roofline is taken over the stage, HIP events fork->join
+            "roofline": {"bound": "hbm", "kernel": "aggregation stage: sweep_kernel<8,0> + sweep_kernel<8,2> + agg_packed_kernel<8,false>(2 paths)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": TRAFFIC_BYTES_PER_VOXEL * B * W * H * D if plan.kernel_name.startswith("sweep") else None,
+                         "algorithmic_bytes": alg_bytes_launch, "stage_ms": agg_ms, "finish_ms": wta_ms},
         }
         try:
             import ctypes as C
