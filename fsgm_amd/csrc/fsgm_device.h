@@ -63,13 +63,17 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
 }
 
-// min over a group of G adjacent lanes (G = 1,2,4,8,16, group aligned), result in every lane
+// min over a group of G adjacent lanes (G = 1,2,4,8,16, group aligned), result in every lane.
+// v_min_u32 with the DPP modifier on its first source: one instruction per butterfly level
+// (the compiler emits mov + mov_dpp + min for the builtin form).  The s_nop covers the
+// VALU-write -> DPP-read hazard (2 wait states), which hipcc does not pad inside asm.
+#define FSGM_MIN_DPP(x, ctrl) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(x))
 template <int G>
 __device__ __forceinline__ uint32_t group_min_u32(uint32_t x) {
-    if (G >= 2)  x = min(x, dpp_mov<DPP_QUAD_1032>(x, x));
-    if (G >= 4)  x = min(x, dpp_mov<DPP_QUAD_2301>(x, x));
-    if (G >= 8)  x = min(x, dpp_mov<DPP_ROW_HALF_MIRROR>(x, x));
-    if (G >= 16) x = min(x, dpp_mov<DPP_ROW_MIRROR>(x, x));
+    if (G >= 2)  FSGM_MIN_DPP(x, "quad_perm:[1,0,3,2]");
+    if (G >= 4)  FSGM_MIN_DPP(x, "quad_perm:[2,3,0,1]");
+    if (G >= 8)  FSGM_MIN_DPP(x, "row_half_mirror");
+    if (G >= 16) FSGM_MIN_DPP(x, "row_mirror");
     return x;
 }
 
