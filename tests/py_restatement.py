@@ -146,3 +146,341 @@ def vz_to_disp(bestD, off, vMax, n):                    # :414-426
             r = d / n * vMax
             out[y, x] = int((off[y, x] * (r / (1 - r))) * 256)
     return out
+
+
+# =====================================================================================
+# calc_pyd_cost_sgm.cpp -- second restatement, raster order like the reference
+# =====================================================================================
+def _trunc(v):                                          # C (int) conversion of a double
+    return int(v)
+
+
+def pyd_cost(cen1, cen2, mv, rAgg, rX, rY):             # :374-437
+    H, W = cen1.shape
+    Sy = 2 * rY + 1
+    D = (2 * rX + 1) * Sy
+    C = np.zeros((H, W, D), np.uint8)
+    win = (2 * rAgg + 1) ** 2
+    for y in range(H):
+        for x in range(W):
+            mvx, mvy = mv[0, y, x], mv[1, y, x]
+            d = 0
+            for offx in range(-rX, rX + 1):
+                for offy in range(-rY, rY + 1):
+                    s = 0
+                    for ay in range(-rAgg, rAgg + 1):
+                        for ax in range(-rAgg, rAgg + 1):
+                            y1, x1 = y + ay, x + ax
+                            if y1 < 0 or y1 > H - 1 or x1 < 0 or x1 > W - 1:
+                                s += 5
+                                continue
+                            y2 = _trunc(1.0 * (offy + y1) + mvy + 0.5)
+                            x2 = _trunc(1.0 * (offx + x1) + mvx + 0.5)
+                            if y2 < 0 or y2 > H - 1 or x2 < 0 or x2 > W - 1:
+                                s += 5
+                                continue
+                            s += bin(int(cen1[y1, x1]) ^ int(cen2[y2, x2])).count("1")
+                    C[y, x, d] = _trunc((1.0 * s / win) + 0.5) & 0xFF
+                    d += 1
+    return C
+
+
+def pyd_step(Lpre, C, dx, dy, Sx, Sy, P1, P2):          # :34-89
+    D = Sx * Sy
+    out = [0] * (D + 1)
+    lpm = Lpre[D]
+    mn = 255
+    for sx in range(Sx):
+        for sy in range(Sy):
+            ypre = _trunc(sy + dy + 0.5)
+            xpre = _trunc(sx + dx + 0.5)
+            min1 = min2 = _u8(lpm + P2)
+            if 0 <= xpre < Sx and 0 <= ypre < Sy:
+                min1 = Lpre[xpre * Sy + ypre]
+            for k in range(-2, 3):
+                for m in range(-2, 3):
+                    if m == 0 and k == 0:
+                        continue
+                    ty, tx = ypre + k, xpre + m
+                    if 0 <= tx < Sx and 0 <= ty < Sy:
+                        min2 = min(min2, _u8(Lpre[tx * Sy + ty] + P1))
+            best = min(_u8(lpm + P2), min1, min2)
+            d = sx * Sy + sy
+            out[d] = _u8(int(C[d]) + best - lpm)
+            mn = min(mn, out[d])
+    out[D] = mn
+    return out
+
+
+def pyd_sgm2d(I1, C, mv, Sx, Sy, P1, P2, diag, totalPass, adaptive):      # :114-296
+    H, W, D = C.shape
+    Sp = np.zeros((H, W, D), np.int64)
+
+    def p2(cur, pre):
+        if not adaptive:
+            return P2
+        return P2 // 8 if abs(int(I1[cur]) - int(I1[pre])) > 50 else P2
+
+    ystart, yend, ystep, xstart, xend, xstep = 0, H, 1, 0, W, 1
+    for ps in range(totalPass):
+        if ps == 1:
+            ystart, yend, ystep, xstart, xend, xstep = H - 1, -1, -1, W - 1, -1, -1
+        L1pre = None
+        L3pre, L2pre, L4pre = {}, {}, {}
+        y = ystart
+        while y != yend:
+            L3cur, L2cur, L4cur = {}, {}, {}
+            x = xstart
+            while x != xend:
+                c = C[y, x]
+                st = [int(v) for v in c] + [0]
+
+                def step(Lp, py, px):
+                    return pyd_step(Lp, c, mv[0, y, x] - mv[0, py, px], mv[1, y, x] - mv[1, py, px], Sx, Sy, P1,
+                                    p2((y, x), (py, px)))
+                L1 = st if x == xstart else step(L1pre, y, x - xstep)
+                L3 = st if y == ystart else step(L3pre[x], y - ystep, x)
+                tot = np.array(L1[:D]) + np.array(L3[:D])
+                if diag:
+                    L2 = st if (x == xstart or y == ystart) else step(L2pre[x - xstep], y - ystep, x - xstep)
+                    L4 = st if (y == ystart or x == xend - xstep) else step(L4pre[x + xstep], y - ystep, x + xstep)
+                    tot = tot + np.array(L2[:D]) + np.array(L4[:D])
+                    L2cur[x], L4cur[x] = L2, L4
+                Sp[y, x] += tot
+                L1pre = L1
+                L3cur[x] = L3
+                x += xstep
+            L3pre, L2pre, L4pre = L3cur, L2cur, L4cur
+            y += ystep
+    return Sp.astype(np.uint32)
+
+
+def pyd_wta(Sp, Sx, Sy, subpixel):                      # :298-364
+    H, W, D = Sp.shape
+    bestD = np.zeros((H, W), np.uint32)
+    minC = np.zeros((H, W), np.uint32)
+    mvSub = np.zeros((2, H, W))
+
+    def par(cl, c0, cr):
+        return (cr - cl) / (c0 - cl) / 2.0 if cr < cl else (cr - cl) / (c0 - cr) / 2.0
+    for y in range(H):
+        for x in range(W):
+            s = [float(v) for v in Sp[y, x]]
+            idx = 0
+            for d in range(1, D):
+                if s[d] < s[idx]:
+                    idx = d
+            bestD[y, x], minC[y, x] = idx, int(s[idx])
+            if not subpixel:
+                continue
+            dx, dy = idx // Sy, idx % Sy
+            if 0 < dy < Sy - 1:
+                mvSub[1, y, x] = par(s[idx - 1], s[idx], s[idx + 1])
+            if 0 < dx < Sx - 1:
+                mvSub[0, y, x] = par(s[idx - Sy], s[idx], s[idx + Sy])
+    return bestD, minC, mvSub
+
+
+# =====================================================================================
+# calc_pyd_cost_sgm_ng.cpp -- second restatement
+# =====================================================================================
+def ng_cost(cen1, cen2, mv, rAgg, r):                   # :370-446
+    H, W = cen1.shape
+    mvH, mvW = mv.shape[1:]
+    cph = (2 * r + 1) ** 2
+    D = 9 * cph
+    out = np.zeros((H, W, D, 3), np.int64)              # mvx, mvy, cost
+    win = (2 * rAgg + 1) ** 2
+    for y in range(H):
+        for x in range(W):
+            d = 0
+            for dy in (-8, 0, 8):
+                for dx in (-8, 0, 8):
+                    yn, xn = min(max(y + dy, 0), mvH - 1), min(max(x + dx, 0), mvW - 1)
+                    mvx, mvy = mv[0, yn, xn], mv[1, yn, xn]
+                    for offx in range(-r, r + 1):
+                        for offy in range(-r, r + 1):
+                            s = 0
+                            for ay in range(-rAgg, rAgg + 1):
+                                for ax in range(-rAgg, rAgg + 1):
+                                    y1, x1 = y + ay, x + ax
+                                    if y1 < 0 or y1 > H - 1 or x1 < 0 or x1 > W - 1:
+                                        s += 5
+                                        continue
+                                    y2, x2 = _trunc((offy + y1) + mvy), _trunc((offx + x1) + mvx)
+                                    if y2 < 0 or y2 > H - 1 or x2 < 0 or x2 > W - 1:
+                                        s += 5
+                                        continue
+                                    s += bin(int(cen1[y1, x1]) ^ int(cen2[y2, x2])).count("1")
+                            out[y, x, d] = (_trunc(mvx + offx), _trunc(mvy + offy), _trunc((1.0 * s / win) + 0.5))
+                            d += 1
+    return out
+
+
+def ng_step(Lpre, lpm_entry, C, P1, P2):                # :39-78; entries are (mvx, mvy, cost)
+    D = len(C)
+    lpm = _u8(lpm_entry)
+    out = []
+    mn = 255
+    for d in range(D):
+        mvx, mvy, cc = C[d]
+        min1 = min2 = _u8(lpm + P2)
+        for d2 in range(D):
+            px, py, pc = Lpre[d2]
+            if mvx == px and mvy == py:
+                min1 = _u8(pc)
+            elif abs(mvx - px) <= 2 and abs(mvy - py) <= 2:
+                min2 = min(min2, _u8(pc + P1))
+        best = min(_u8(lpm + P2), min1, min2)
+        cost = (cc + best) - lpm
+        out.append((mvx, mvy, cost))
+        mn = min(mn, _u8(cost))
+    return out, mn
+
+
+def ng_sgm2d(Cc, P1, P2):                               # :101-299 (2 passes x 2 paths)
+    H, W, D, _ = Cc.shape
+    Sp = np.zeros((H, W, D), np.int64)
+    for ps in range(2):
+        if ps == 0:
+            ys, ye, yst, xs, xe, xst = 0, H, 1, 0, W, 1
+        else:
+            ys, ye, yst, xs, xe, xst = H - 1, -1, -1, W - 1, -1, -1
+        L1pre = None
+        L3pre = {}
+        y = ys
+        while y != ye:
+            L3cur = {}
+            x = xs
+            while x != xe:
+                c = [tuple(int(v) for v in e) for e in Cc[y, x]]
+                L1 = (c, 0) if x == xs else ng_step(L1pre[0], L1pre[1], c, P1, P2)
+                L3 = (c, 0) if y == ys else ng_step(L3pre[x][0], L3pre[x][1], c, P1, P2)
+                Sp[y, x] += np.array([e[2] for e in L1[0]]) + np.array([e[2] for e in L3[0]])
+                L1pre = L1
+                L3cur[x] = L3
+                x += xst
+            L3pre = L3cur
+            y += yst
+    S = (Sp & 0xFFFFFFFF).astype(np.uint32)
+    minC = np.zeros((H, W), np.uint32)
+    flow = np.zeros((2, H, W))
+    for y in range(H):
+        for x in range(W):
+            idx = 0
+            for d in range(1, D):
+                if S[y, x, d] < S[y, x, idx]:
+                    idx = d
+            minC[y, x] = S[y, x, idx]
+            flow[0, y, x], flow[1, y, x] = Cc[y, x, idx, 0], Cc[y, x, idx, 1]
+    return S, minC, flow
+
+
+# =====================================================================================
+# calc_cost_sgm_ng.cpp -- second restatement (literal double buffers, raster order)
+# =====================================================================================
+def otf(I1, I2, P1, P2, rnd):
+    H, W = I1.shape
+    c1, c2 = census(I1), census(I2)
+    N, M, D = 2, 1, 108
+    E = D + N
+    zero = lambda n: [[0, 0, 0] for _ in range(n)]       # [mvx, mvy, cost]
+    L1 = [zero(E), zero(E)]
+    L2 = [[zero(E) for _ in range(W)] for _ in range(2)]
+    L3 = [[zero(E) for _ in range(W)] for _ in range(2)]
+    L4 = [[zero(E) for _ in range(W)] for _ in range(2)]
+    Sp = np.zeros((H, W, D), np.int64)
+    Cvol = np.zeros((H, W, D, 3), np.int64)
+    ri = [0]
+
+    def step(L, Lpre, C, p2):                            # :46-98, writes into list L in place
+        lpm = _u8(Lpre[D][2])
+        for i in range(N):
+            L[D + i][2] = 255
+        for d in range(D):
+            mvx, mvy, cc = C[d]
+            min1 = min2 = _u8(lpm + p2)
+            for d2 in range(D):
+                px, py, pc = Lpre[d2]
+                if mvx == px and mvy == py:
+                    min1 = _u8(pc)
+                elif abs(mvx - px) <= 2 and abs(mvy - py) <= 2:
+                    min2 = min(min2, _u8(pc + P1))
+            best = min(_u8(lpm + p2), min1, min2)
+            L[d] = [mvx, mvy, (cc + best) - lpm]
+            j = 0
+            while j < N and not (L[d][2] < L[D + j][2]):
+                j += 1
+            if j < N:
+                for i in range(N - 1, j, -1):
+                    L[D + i] = list(L[D + i - 1])
+                L[D + j] = list(L[d])
+
+    def start(L, C):
+        for d in range(D):
+            L[d] = list(C[d])
+        L[D][2] = 0
+
+    l1pre, l1cur, rpre, rcur = 0, 1, 0, 1
+    for y in range(H):
+        for x in range(W):
+            pL1c, pL2c, pL3c, pL4c = L1[l1cur], L2[rcur][x], L3[rcur][x], L4[rcur][x]
+            C = []
+            for hint in (pL1c, pL2c, pL3c, pL4c):        # :122-186
+                for i in range(N + M):
+                    if i < N:
+                        mvx, mvy = hint[D + i][0], hint[D + i][1]
+                    else:
+                        mvx = int(rnd[ri[0]]) % 256 - 128
+                        mvy = int(rnd[ri[0] + 1]) % 128 - 64
+                        ri[0] += 2
+                    for offy in (-1, 0, 1):
+                        for offx in (-1, 0, 1):
+                            s = 0
+                            for ay in range(-2, 3):
+                                for ax in range(-2, 3):
+                                    y1 = min(max(y + ay, 0), H - 1)
+                                    x1 = min(max(x + ax, 0), W - 1)
+                                    y2 = min(max((offy + y1) + mvy, 0), H - 1)
+                                    x2 = min(max((offx + x1) + mvx, 0), W - 1)
+                                    s += bin(int(c1[y1, x1]) ^ int(c2[y2, x2])).count("1")
+                            C.append([mvx + offx, mvy + offy, int(1.0 * s / 25 + 0.5)])
+            Cvol[y, x] = C
+            if x == 0:
+                start(pL1c, C)
+                start(pL2c, C)
+            if y == 0:
+                start(pL3c, C)
+                start(pL2c, C)
+                start(pL4c, C)
+            if x == W - 1:
+                start(pL4c, C)
+            pc = int(I1[y, x])
+
+            def ap2(pp):
+                return P2 // 8 if abs(pc - int(pp)) > 50 else P2
+            if x != 0:
+                step(pL1c, L1[l1pre], C, ap2(I1[y, x - 1]))
+            if y != 0:
+                step(pL3c, L3[rpre][x], C, ap2(I1[y - 1, x]))
+            if x != 0 and y != 0:
+                step(pL2c, L2[rpre][x - 1], C, ap2(I1[y - 1, x - 1]))
+            if x != W - 1 and y != 0:
+                step(pL4c, L4[rpre][x + 1], C, ap2(I1[y - 1, x + 1]))
+            for d in range(D):
+                Sp[y, x, d] += pL1c[d][2] + pL3c[d][2]
+                Sp[y, x, d] += pL2c[d][2] + pL4c[d][2]
+            l1pre, l1cur = l1cur, l1pre
+        rpre, rcur = rcur, rpre
+    S = (Sp & 0xFFFFFFFF).astype(np.uint32)
+    minC = np.zeros((H, W), np.uint32)
+    flow = np.zeros((2, H, W))
+    for y in range(H):
+        for x in range(W):
+            idx = 0
+            for d in range(1, D):
+                if S[y, x, d] < S[y, x, idx]:
+                    idx = d
+            minC[y, x] = S[y, x, idx]
+            flow[0, y, x], flow[1, y, x] = Cvol[y, x, idx, 0], Cvol[y, x, idx, 1]
+    return minC, flow
