@@ -44,39 +44,39 @@ __global__ __launch_bounds__(256) void census5x5_kernel(const uint8_t* __restric
 // One thread = one pixel x 4 consecutive d.  fp64 geometry in the reference's association
 // order with explicit round-to-nearest mul/add (no FMA contraction).
 // =============================================================================================
+template <bool VEC4>                                       // VEC4: D % 4 == 0, no per-element guards, one u32 store
 __global__ __launch_bounds__(256) void epi_rawcost_kernel(EpiCostArgs a) {
     const int W = a.W, H = a.H, D = a.D;
     const int NP = W * H;
     const int Dq = (D + 3) >> 2;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (long long)NP * Dq) return;
-    const int p = (int)(gid / Dq), q = (int)(gid - (long long)p * Dq);
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;        // NP * Dq < 2^31 (checked on the host)
+    if (gid >= (uint32_t)NP * (uint32_t)Dq) return;
+    const int p = (int)(gid / (uint32_t)Dq), q = (int)(gid - (uint32_t)p * (uint32_t)Dq);
     const size_t f = blockIdx.y;
-    const double* p0 = a.pd0 + f * 2 * (size_t)NP;
-    const double* nd = a.nd + f * 2 * (size_t)NP;
+    const double* __restrict__ p0 = a.pd0 + f * 2 * (size_t)NP;
+    const double* __restrict__ nd = a.nd + f * 2 * (size_t)NP;
     const double bx = __dsub_rn(p0[p], 1.0), by = __dsub_rn(p0[NP + p], 1.0);          // :348-349
     const double ux = nd[p], uy = nd[NP + p];
     const double off = a.off[f * (size_t)NP + p];
-    const uint32_t* cen1 = a.cen1 + f * (size_t)NP;
-    const uint32_t* cen2 = a.cen2 + f * (size_t)NP;
-    const uint32_t c1 = cen1[p];
-    uint8_t* out = a.Craw + f * (size_t)NP * D + (size_t)p * D + 4 * q;
+    const uint32_t* __restrict__ cen2 = a.cen2 + f * (size_t)NP;
+    const uint32_t c1 = a.cen1[f * (size_t)NP + p];
+    uint8_t* out = a.Craw + f * (size_t)NP * D + (uint32_t)p * (uint32_t)D + 4u * q;
+    const double* __restrict__ vz = a.vz + 4 * q;
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int d = 4 * q + k;
-        if (d < D) {
-            const double s = __dmul_rn(off, a.vz[d]);                                      // offset * vzInd
+        if (VEC4 || 4 * q + k < D) {
+            const double s = __dmul_rn(off, vz[k]);                                        // offset * vzInd
             const double ox = __dmul_rn(s, ux), oy = __dmul_rn(s, uy);                    // :365-366
-            int x2 = f64_to_i32_x86(round(__dadd_rn(bx, ox)));                            // :371
-            int y2 = f64_to_i32_x86(round(__dadd_rn(by, oy)));                            // :372
+            int x2 = round_to_i32_x86(__dadd_rn(bx, ox));                                 // :371
+            int y2 = round_to_i32_x86(__dadd_rn(by, oy));                                 // :372
             x2 = clampi(x2, 0, W - 1);
             y2 = clampi(y2, 0, H - 1);
             const uint32_t cost = __popc(c1 ^ cen2[y2 * W + x2]);                         // :377-378
             packed |= cost << (8 * k);
         }
     }
-    if ((D & 3) == 0) {
+    if (VEC4) {
         *(uint32_t*)out = packed;
     } else {
         for (int k = 0; k < 4; k++)
@@ -130,6 +130,56 @@ __global__ __launch_bounds__(256) void box5x5_kernel(const uint8_t* __restrict__
                 }
             }
             out[k] = (uint8_t)((2 * s + 25) / 50);
+        }
+    }
+}
+
+// =============================================================================================
+// 5x5 box mean, sliding-window form for D % 4 == 0 (same result as box5x5_kernel).
+// One thread = one pixel column x 4 consecutive d, walking down BOX_ROWS rows: per row one
+// horizontal 5-sum (5 u32 loads, even/odd bytes in 16-bit fields) and a 5-deep ring of those sums
+// for the vertical part: 5 loads per output instead of 25.
+// =============================================================================================
+constexpr int BOX_ROWS = 32;
+__global__ __launch_bounds__(256) void box5x5_sliding_kernel(const uint8_t* __restrict__ Craw,
+                                                             uint8_t* __restrict__ C, int W, int H, int D) {
+    const int Dq = D >> 2;
+    const int cols = 256 / Dq;                               // pixel columns per block (Dq <= 256 here)
+    const int q = threadIdx.x % Dq, xi = threadIdx.x / Dq;
+    const int x = blockIdx.x * cols + xi;
+    if (xi >= cols || x >= W) return;
+    const int y0 = blockIdx.y * BOX_ROWS, y1 = min(y0 + BOX_ROWS, H);
+    const size_t NP = (size_t)W * H;
+    const uint8_t* raw = Craw + (size_t)blockIdx.z * NP * D + 4 * q;
+    uint8_t* out = C + (size_t)blockIdx.z * NP * D + 4 * q;
+    int xs[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) xs[k] = clampi(x + k - 2, 0, W - 1);
+    auto hsum = [&](int y, uint32_t& he, uint32_t& ho) {     // horizontal 5-sum of row clamp(y)
+        const uint8_t* r = raw + (size_t)clampi(y, 0, H - 1) * W * D;
+        he = 0; ho = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const uint32_t w = *(const uint32_t*)(r + (size_t)xs[k] * D);
+            he += w & 0x00FF00FFu;
+            ho += (w >> 8) & 0x00FF00FFu;
+        }
+    };
+    uint32_t re[5], ro[5];                                   // ring: rows y-2 .. y+2 around the output row
+#pragma unroll
+    for (int k = 0; k < 4; k++) hsum(y0 - 2 + k, re[k], ro[k]);
+    for (int yb = y0; yb < y1; yb += 5) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {                        // static ring slot = (k + 4) % 5
+            const int y = yb + k;
+            if (y < y1) {
+                hsum(y + 2, re[(k + 4) % 5], ro[(k + 4) % 5]);
+                const uint32_t se = re[0] + re[1] + re[2] + re[3] + re[4];
+                const uint32_t so = ro[0] + ro[1] + ro[2] + ro[3] + ro[4];
+                const uint32_t b0 = (2 * (se & 0xFFFF) + 25) / 50, b2 = (2 * (se >> 16) + 25) / 50;
+                const uint32_t b1 = (2 * (so & 0xFFFF) + 25) / 50, b3 = (2 * (so >> 16) + 25) / 50;
+                *(uint32_t*)(out + ((size_t)y * W + x) * D) = (b0 & 0xFF) | ((b1 & 0xFF) << 8) | ((b2 & 0xFF) << 16) | ((b3 & 0xFF) << 24);
+            }
         }
     }
 }
@@ -496,8 +546,15 @@ void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int
 void launch_epi_cost(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frames) {
     const long long n = (long long)a.W * a.H * ((a.D + 3) / 4);
     dim3 grid((unsigned)((n + 255) / 256), frames);
-    hipLaunchKernelGGL(epi_rawcost_kernel, grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(box5x5_kernel, grid, dim3(256), 0, st, (const uint8_t*)a.Craw, C, a.W, a.H, a.D);
+    if ((a.D & 3) == 0) hipLaunchKernelGGL(epi_rawcost_kernel<true>, grid, dim3(256), 0, st, a);
+    else                hipLaunchKernelGGL(epi_rawcost_kernel<false>, grid, dim3(256), 0, st, a);
+    if ((a.D & 3) == 0 && a.D <= 1024) {
+        const int cols = 256 / (a.D >> 2);
+        dim3 g2((a.W + cols - 1) / cols, (a.H + BOX_ROWS - 1) / BOX_ROWS, frames);
+        hipLaunchKernelGGL(box5x5_sliding_kernel, g2, dim3(256), 0, st, (const uint8_t*)a.Craw, C, a.W, a.H, a.D);
+    } else {
+        hipLaunchKernelGGL(box5x5_kernel, grid, dim3(256), 0, st, (const uint8_t*)a.Craw, C, a.W, a.H, a.D);
+    }
 }
 
 int agg_packed_lpp(int D) {

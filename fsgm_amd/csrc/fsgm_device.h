@@ -19,6 +19,20 @@ __device__ __forceinline__ uint32_t f64_to_u32_x86(double v) { return (uint32_t)
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, max(lo, v)); }
 
+// (int)round(v) exactly as x86-64 computes it -- C round() is half away from zero, the cast is
+// cvttsd2si -- with 4 fp64-rate instructions instead of ocml round + two fp64 range compares:
+//   t = trunc(v), f = v - t (exact), result = (int)t +- 1 when |f| >= 0.5.
+// |v| >= 2^31, inf and NaN are recognised from the exponent field and give INT_MIN; a rounded
+// value of exactly 2^31 comes out of the wrapping integer add as INT_MIN as well.
+__device__ __forceinline__ int32_t round_to_i32_x86(double v) {
+    const uint32_t hi = (uint32_t)__double2hiint(v);
+    const double t = trunc(v);
+    const double f = __dsub_rn(v, t);
+    const uint32_t n = (uint32_t)(int32_t)t;
+    const uint32_t inc = fabs(f) >= 0.5 ? ((hi >> 31) ? 0xFFFFFFFFu : 1u) : 0u;
+    return ((hi >> 20) & 0x7FFu) >= 1023u + 31u ? INT32_MIN : (int32_t)(n + inc);
+}
+
 // ---- packed 2 x u16 arithmetic (VOP3P v_pk_*_u16) ----
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {

@@ -223,3 +223,25 @@ def test_run_sharded_with_the_hip_compute(gpu_lib, oracle):
         bd, mc = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, 8)
         np.testing.assert_array_equal(gbd, bd)
         np.testing.assert_array_equal(gmc, mc)
+
+
+def test_cost_volume_rounding_edge_cases(gpu_lib, oracle):
+    """Sample positions engineered onto the hard cases of (int)round(v): exact halves of both signs,
+    0.5 - 1ulp (where floor(v+0.5) would be wrong), values just inside / at / beyond +-2^31."""
+    W, H, D = 40, 24, 16
+    I1, I2 = synth.image_pair(W, H, D, seed=8)
+    pd0, nd, off = synth.epi_maps(W, H, "axis")
+    nd[0][:] = 1.0; nd[1][:] = 0.0
+    off[:] = 0.0                                             # sample position = Pd0 - 1 exactly
+    specials = [0.5, 1.5, 2.5, -0.5, -1.5, 0.49999999999999994, -0.49999999999999994, 1.4999999999999998,
+                2147483647.5, 2147483647.4, 2147483648.0, -2147483648.0, -2147483648.5, -2147483649.0,
+                4294967296.0, 1e300, -1e300, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 38.5, 39.5, 39.49999999999999]
+    for i, v in enumerate(specials):
+        pd0[0, i % H, (3 * i) % W] = v + 1.0 if np.isfinite(v) and abs(v) < 1e15 else v
+        pd0[1, (i + 5) % H, (3 * i + 1) % W] = v + 1.0 if np.isfinite(v) and abs(v) < 1e15 else v
+    want = oracle.epi_cost(I1, I2, D, 0.3, pd0, nd, off)
+    with EpiPlan(W, H, D, 1) as plan:
+        plan.upload(0, I1, I2, pd0, nd, off)
+        plan.run(STAGE_COST)
+        got = plan.download_cost(0)
+    np.testing.assert_array_equal(got, want)
