@@ -103,8 +103,9 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** plan, int32_t width, int32_t he
                                  int32_t dMax, int32_t batch, const fsgm_epi_params* prm);
 void        fsgm_epi_plan_destroy(fsgm_epi_plan* plan);
 fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t P2, double vMax);
-/* Aggregation strategy: 0 = auto (fused sweeps when eligible: 8 paths, D = 16<<k, no-wrap
- * penalties), 1 = per-direction line kernels, 2 = same as 0.  Results are identical. */
+/* Aggregation strategy: 0 = auto (fused sweeps when eligible -- 8 paths, D = 16<<k, no-wrap
+ * penalties with 3*P2 <= 255 -- and the plan holds >= 4 frames; else the per-direction line
+ * kernels), 1 = line kernels, 2 = fused sweeps whenever eligible.  Results are identical. */
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* plan, int32_t mode);
 /* host -> HBM (async on the plan's stream) */
 fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* plan, int32_t frame, const uint8_t* I1,

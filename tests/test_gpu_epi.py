@@ -80,7 +80,9 @@ def test_aggregate_sum_bit_exact(gpu_lib, oracle, W, H, D, P1, P2, cmax, kernel,
     with EpiPlan(W, H, D, 1, paths=paths) as plan:
         plan.set_penalties(P1, P2, 0.3)
         plan.upload_cost(0, Cv)
-        # auto mode: the fused sweeps take the 8-path no-wrap case, the line kernels everything else
+        # mode 2: the fused sweeps take the 8-path no-wrap case, the line kernels everything else
+        assert plan.kernel_name == kernel                   # auto mode, 1 frame: line kernels
+        plan.set_agg_mode(2)
         assert plan.kernel_name == ("sweep16/nowrap" if (paths == 8 and kernel == "packed16/nowrap") else kernel)
         plan.run(STAGE_AGGREGATE)
         got = plan.download_sum(0)
@@ -102,6 +104,7 @@ def test_sweep_blocks_and_strips(gpu_lib, oracle, W, H, D):
         plan.set_penalties(6, 64, 0.3)
         plan.upload_cost(0, Cv)
         plan.upload_cost(1, np.ascontiguousarray(Cv[::-1]))
+        plan.set_agg_mode(2)
         assert plan.kernel_name == "sweep16/nowrap"
         plan.run(STAGE_AGGREGATE)
         got = plan.download_sum(0)
@@ -143,10 +146,12 @@ def test_wta_subpixel_bit_exact(gpu_lib, oracle, W, H, D, subpixel, vz):
         plan.set_penalties(6, 64, 0.3)
         plan.upload_cost(0, Cv)
         plan.upload_offset(0, off)
-        plan.run(STAGE_AGGREGATE | STAGE_WTA)
-        gbd, gmc = plan.download(0)
-    np.testing.assert_array_equal(gmc, mc)
-    np.testing.assert_array_equal(gbd, bd)
+        for mode in (1, 2):                                  # line kernels + WTA kernel / sweeps with fused WTA
+            plan.set_agg_mode(mode)
+            plan.run(STAGE_AGGREGATE | STAGE_WTA)
+            gbd, gmc = plan.download(0)
+            np.testing.assert_array_equal(gmc, mc, err_msg=plan.kernel_name)
+            np.testing.assert_array_equal(gbd, bd, err_msg=plan.kernel_name)
 
 
 # ---------------------------------------------------------------- whole MEX
@@ -165,7 +170,8 @@ def test_calc_cost_sgm_whole_mex(gpu_lib, oracle, W, H, D, kind, paths):
 
 
 def test_calc_cost_sgm_kitti_shape_8_paths(gpu_lib, oracle):
-    """BASELINE config 3: 1242x375, D=128, 8 paths -- full-size bit-exact comparison."""
+    """BASELINE config 3: 1242x375, D=128, 8 paths -- full-size bit-exact comparison, through the
+    host entry point (one frame: line kernels) and through a plan forced onto the fused sweeps."""
     W, H, D = 1242, 375, 128
     I1, I2 = synth.image_pair(W, H, D, seed=1)
     pd0, nd, off = synth.epi_maps(W, H, "axis")
@@ -175,12 +181,22 @@ def test_calc_cost_sgm_kitti_shape_8_paths(gpu_lib, oracle):
     np.testing.assert_array_equal(gS, S)
     np.testing.assert_array_equal(gmc, mc)
     np.testing.assert_array_equal(gbd, bd)
+    with EpiPlan(W, H, D, 1, paths=8) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        plan.set_agg_mode(2)
+        plan.upload(0, I1, I2, pd0, nd, off)
+        plan.run()
+        assert plan.kernel_name == "sweep16/nowrap"
+        sbd, smc = plan.download(0)
+        np.testing.assert_array_equal(smc, mc)
+        np.testing.assert_array_equal(sbd, bd)
+        np.testing.assert_array_equal(plan.download_sum(0), S)
 
 
 def test_batch_matches_single_frames(gpu_lib, oracle):
     W, H, D = 96, 64, 64
     frames = []
-    for s in range(3):
+    for s in range(5):                                       # >= 4 frames: auto mode picks the fused sweeps
         I1, I2 = synth.image_pair(W, H, D, seed=20 + s)
         pd0, nd, off = synth.epi_maps(W, H, "general", seed=30 + s)
         frames.append((I1, I2, pd0, nd, off))
@@ -199,6 +215,7 @@ def test_full_size_property_mirror_symmetry(gpu_lib):
     Cv = synth.cost_volume(W, H, D, seed=99, cmax=24)
     with EpiPlan(W, H, D, 2, paths=8) as plan:
         plan.set_penalties(6, 64, 0.3)
+        plan.set_agg_mode(2)
         plan.upload_cost(0, Cv)
         plan.upload_cost(1, np.ascontiguousarray(Cv[::-1, ::-1, :]))
         plan.run(STAGE_AGGREGATE)
