@@ -11,6 +11,7 @@ struct fsgm_pyd_plan {
     int W = 0, H = 0, mvW = 0, mvH = 0, rX = 0, rY = 0, rAgg = 0, batch = 0, device = 0;
     int Sx = 0, Sy = 0, D = 0;
     int P1 = 6, P2 = 32, diagonal = 1, totalPass = 2, adaptive = 0, subpixel = 0;   // pyramidal_sgm.m:15-22
+    int cmax = 24;                       // upper bound of the values in dC
     size_t NP = 0, N = 0, MV = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -41,6 +42,8 @@ fsgm_status fsgm_pyd_plan_create(fsgm_pyd_plan** out, int32_t W, int32_t H, int3
     FSGM_REQUIRE(mvW >= W && mvH >= H, "preMv (%d x %d) must be at least as large as the image (%d x %d): the reference "
                  "indexes it with image coordinates (calc_pyd_cost_sgm.cpp:388-389)", mvW, mvH, W, H);
     FSGM_REQUIRE(rX >= 0 && rY >= 0 && rAgg >= 0, "window half sizes must be >= 0");
+    if (2 * rX + 1 > FSGM_PYD_MAX_SIDE || 2 * rY + 1 > FSGM_PYD_MAX_SIDE)
+        return fail(FSGM_ERR_UNSUPPORTED, "search window side exceeds %d", FSGM_PYD_MAX_SIDE);
     FSGM_REQUIRE(batch >= 1, "batch must be >= 1");
     const long long D = (long long)(2 * rX + 1) * (2 * rY + 1);
     if (D > FSGM_PYD_MAX_D) return fail(FSGM_ERR_UNSUPPORTED, "search window %lld candidates exceeds %d", D, FSGM_PYD_MAX_D);
@@ -102,6 +105,9 @@ fsgm_status fsgm_pyd_plan_upload_cost(fsgm_pyd_plan* p, int32_t f, const uint8_t
     FSGM_REQUIRE(p && C, "fsgm_pyd_plan_upload_cost: null argument");
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_HIP(hipSetDevice(p->device));
+    int cm = p->cmax;
+    for (size_t i = 0; i < p->N; i++) cm = C[i] > cm ? C[i] : cm;
+    p->cmax = cm;
     FSGM_HIP(hipMemcpyAsync(p->dC + f * p->N, C, p->N, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
     return FSGM_OK;
@@ -122,7 +128,12 @@ static fsgm_status pyd_enqueue(fsgm_pyd_plan* p, int stages, uint32_t* dS) {
     g.W = p->W; g.H = p->H; g.mvW = p->mvW; g.mvH = p->mvH; g.Sx = p->Sx; g.Sy = p->Sy;
     g.P1 = p->P1; g.P2 = p->P2; g.adaptive = p->adaptive;
     plan_pyd_dirs(g, p->diagonal, p->totalPass, w.weight);
-    if (stages & FSGM_STAGE_AGGREGATE) launch_pyd_aggregate(p->stream, g, p->batch);
+    if (stages & FSGM_STAGE_AGGREGATE) {
+        // cmax: 24 for volumes built here (census 5x5 Hamming mean; out-of-image taps add 5), else as uploaded
+        const int cm = p->cmax;
+        const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + (p->P1 > p->P2 ? p->P1 : p->P2) <= 255;
+        launch_pyd_aggregate(p->stream, g, p->batch, !nowrap);
+    }
     if (stages & FSGM_STAGE_WTA) {
         w.L = p->dL; w.bestD = p->dBestD; w.minC = p->dMinC; w.mvSub = p->dMvSub; w.S = dS;
         w.W = p->W; w.H = p->H; w.Sx = p->Sx; w.Sy = p->Sy; w.ndirs = g.ndirs; w.subpixel = p->subpixel;

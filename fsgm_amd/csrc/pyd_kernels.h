@@ -5,6 +5,7 @@
 #include <stddef.h>
 
 #define FSGM_PYD_MAX_D 1024      // candidates per pixel the 2-D kernels accept (Sx*Sy)
+#define FSGM_PYD_MAX_SIDE 64     // and each side of the search window (2*half+1)
 
 namespace fsgm {
 
@@ -45,7 +46,8 @@ struct PydWtaArgs {
 void launch_pyd_cost(hipStream_t st, const PydCostArgs& a, int frames);
 // returns the number of path slots it planned (nd or 2*nd)
 int  plan_pyd_dirs(PydAggArgs& a, int diagonal, int totalPass, uint32_t weight[8]);
-void launch_pyd_aggregate(hipStream_t st, const PydAggArgs& a, int frames);
+// wrap = false: penalties in the no-wrap range (0 <= P1,P2, max C + P2 + max(P1,P2) <= 255)
+void launch_pyd_aggregate(hipStream_t st, const PydAggArgs& a, int frames, bool wrap);
 void launch_pyd_wta(hipStream_t st, const PydWtaArgs& a, int frames);
 
 }  // namespace fsgm
