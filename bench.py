@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo to rehearse on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,9 +70,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    local_rank %= torch.cuda.device_count()                  # one process per GPU; wraps only when rehearsing on fewer GPUs
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     B = args.frames_per_gpu
     plan = EpiPlan(W, H, D, B, paths=PATHS, device=local_rank)
@@ -100,7 +105,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

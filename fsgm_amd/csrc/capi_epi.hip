@@ -57,7 +57,7 @@ static void select_kernel(fsgm_epi_plan* p) {
     // for 1-3 frames (one MEX call) the line kernels finish sooner (0.43 vs 1.27 ms at one
     // 1242x375x128 frame; crossover at 4, measured).
     const bool want = p->agg_mode == 2 || (p->agg_mode == 0 && p->batch >= 4);
-    if (nowrap && 3 * p->P2 <= 255 && p->prm.paths == 8 && want && p->dX) p->kernel_kind = AGG_SWEEP;
+    if (nowrap && 3 * p->P2 <= 255 && p->prm.paths == 8 && want) p->kernel_kind = AGG_SWEEP;
 }
 
 extern "C" {
@@ -139,23 +139,10 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
     alloc((void**)&p->dVz, (size_t)D * 8);
     alloc((void**)&p->dCraw, B * p->N);
     alloc((void**)&p->dC, B * p->N);
-    const bool sweep_ok = pr.paths == 8 && agg_packed_lpp(D) != 0;
-    if (!sweep_ok) alloc((void**)&p->dL, B * p->N * pr.paths);     // else allocated on first use of the line kernels
+    // the per-voxel intermediates of the two aggregation strategies (L_r for the line kernels;
+    // L_left/right, X_dn, states, records for the fused sweeps) are allocated on first use
     alloc((void**)&p->dBestD, B * p->NP * 4);
     alloc((void**)&p->dMinC, B * p->NP * 4);
-    if (sweep_ok) {
-        p->state_stride = sweep_state_bytes(W, D);
-        alloc((void**)&p->dLh, B * p->N * 2);
-        alloc((void**)&p->dX, B * p->N);
-        alloc((void**)&p->dState, 2 * B * p->state_stride);
-        alloc((void**)&p->dRec, B * p->NP * sizeof(uint4));
-        alloc((void**)&p->dS0, B * p->NP * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream_h, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream_b, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_b, hipEventDisableTiming);
-    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -232,7 +219,28 @@ fsgm_status fsgm_epi_plan_upload_offset(fsgm_epi_plan* p, int32_t f, const doubl
     return FSGM_OK;
 }
 
+static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
+    if (p->dX) return FSGM_OK;
+    const size_t B = p->batch;
+    p->state_stride = sweep_state_bytes(p->W, p->D);
+    FSGM_HIP(hipMalloc((void**)&p->dLh, B * p->N * 2));
+    FSGM_HIP(hipMalloc((void**)&p->dState, 2 * B * p->state_stride));
+    FSGM_HIP(hipMalloc((void**)&p->dRec, B * p->NP * sizeof(uint4)));
+    FSGM_HIP(hipMalloc((void**)&p->dS0, B * p->NP * sizeof(uint16_t)));
+    FSGM_HIP(hipStreamCreateWithFlags(&p->stream_h, hipStreamNonBlocking));
+    FSGM_HIP(hipStreamCreateWithFlags(&p->stream_b, hipStreamNonBlocking));
+    FSGM_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    FSGM_HIP(hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming));
+    FSGM_HIP(hipEventCreateWithFlags(&p->ev_b, hipEventDisableTiming));
+    FSGM_HIP(hipMalloc((void**)&p->dX, B * p->N));           // last: marks the set complete
+    return FSGM_OK;
+}
+
 static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
+    if (p->kernel_kind == AGG_SWEEP && (stages & (FSGM_STAGE_AGGREGATE | FSGM_STAGE_WTA))) {
+        fsgm_status st = ensure_sweep_buffers(p);
+        if (st != FSGM_OK) return st;
+    }
     if (stages & FSGM_STAGE_COST) {
         fsgm_status st = ensure_vz(p);
         if (st != FSGM_OK) return st;
@@ -356,6 +364,8 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         // S never exists in HBM in sweep mode.  Debug tap: materialise X_up of that frame with a
         // non-final up sweep, then let wta_sweep_kernel rebuild S = X_dn + X_up + 6C + L_left + L_right.
         FSGM_HIP(hipStreamSynchronize(p->stream));
+        fsgm_status es = ensure_sweep_buffers(p);
+        if (es != FSGM_OK) return es;
         if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
         if (!p->dXup) FSGM_HIP(hipMalloc((void**)&p->dXup, p->N));
         SweepArgs w;
