@@ -107,17 +107,17 @@ __device__ __forceinline__ void step_norm(uint32_t (&LE)[4], uint32_t (&LO)[4], 
 //   MODE 2: point-mirrored frame, final: S = X_dn + X_up + 6C + L_left + L_right in registers,
 //           WTA per pixel, writes one record {best, minC, S[best-1], S[best+1]} + S[0] per pixel.
 // =============================================================================================
-template <int LPP, int MODE>
-__global__ __launch_bounds__(256, 4) void sweep_kernel(SweepArgs a) {   // <= 128 VGPRs: 4 workgroups per CU
+template <int LPP, int MODE, int NWV>
+__global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     constexpr bool UP = MODE != 0;
     constexpr int PXW = 64 / LPP;            // columns per wave
     constexpr int D = LPP * 16;
-    constexpr int STRIP = 4 * PXW;           // own columns per workgroup
-    constexpr int T = 2 * PXW;               // halo width = max rows per launch
+    constexpr int STRIP = NWV * PXW;         // own columns per workgroup
+    constexpr int T = (NWV / 2) * PXW;       // halo width = max rows per launch (one halo step per wave per row)
     constexpr int NCOL = STRIP + 2 * T + 2;  // LDS columns: forward column x  <->  index x - (a0 - T - 1)
     constexpr int PF = MODE == 2 ? 2 : 3;    // rows of C in flight per lane
     __shared__ uint4 sDiag[2][2][NCOL * LPP];    // [row parity][0: from above-left, 1: from above-right][column][lane-of-pixel]
-    __shared__ uint32_t sRow[MODE == 2 ? 256 * 8 : 1];   // MODE 2: S of the wave's pixels in natural d order (u16)
+    __shared__ uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 1];   // MODE 2: S of the wave's pixels in natural d order (u16)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPP, j = lane % LPP;
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256, 4) void sweep_kernel(SweepArgs a) {   // <= 12
     const int gxc = min(gx, W - 1);
     // halo unit of this wave: waves 0,1 -> from-above-left on the T columns left of the strip,
     //                         waves 2,3 -> from-above-right on the T columns right of it
-    const int hdir = wave >> 1;
-    const int hx = hdir == 0 ? a0 - T + wave * PXW + g : a0 + STRIP + (wave - 2) * PXW + g;
+    const int hdir = wave >= NWV / 2 ? 1 : 0;
+    const int hx = hdir == 0 ? a0 - T + wave * PXW + g : a0 + STRIP + (wave - NWV / 2) * PXW + g;
     const int hxc = min(max(hx, 0), W - 1);
     const int lbase = a0 - T - 1;                                // forward column of LDS index 0
 
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 4) void sweep_kernel(SweepArgs a) {   // <= 12
     uint32_t VE[4] = {0, 0, 0, 0}, VO[4] = {0, 0, 0, 0};          // vertical path state of the own column
     if (!first_block) {
         unpack16(*(const uint4*)(StIn + (size_t)gxc * D + j * 16), VE, VO);
-        for (int i = tid; i < 2 * NCOL * LPP; i += 256) {
+        for (int i = tid; i < 2 * NCOL * LPP; i += NWV * 64) {
             const int dir = i / (NCOL * LPP), r = i - dir * (NCOL * LPP);
             const int c = r / LPP, jj = r - c * LPP;
             const int x = min(max(lbase + c, 0), W - 1);
@@ -383,12 +383,16 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
 // =============================================================================================
 // launchers
 // =============================================================================================
-int sweep_rows_per_launch(int D) { const int lpp = agg_packed_lpp(D); return lpp ? 2 * (64 / lpp) : 0; }
+#ifndef FSGM_SWEEP_WAVES
+#define FSGM_SWEEP_WAVES 4      // waves per sweep workgroup (4: 32-column strips, 16 rows per launch at D = 128)
+#endif
+int sweep_rows_per_launch(int D) { const int lpp = agg_packed_lpp(D); return lpp ? (FSGM_SWEEP_WAVES / 2) * (64 / lpp) : 0; }
 size_t sweep_state_bytes(int W, int D) { return (size_t)3 * W * D; }
 
 template <int LPP>
 static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode) {
-    constexpr int STRIP = 4 * (64 / LPP), T = 2 * (64 / LPP);
+    constexpr int NWV = FSGM_SWEEP_WAVES;
+    constexpr int STRIP = NWV * (64 / LPP), T = (NWV / 2) * (64 / LPP);
     dim3 grid((a.W + STRIP - 1) / STRIP, frames);
     uint8_t* const buf0 = a.state_out;                     // caller passes the base of 2 x frames x state buffers
     uint8_t* const buf1 = a.state_out + (size_t)frames * a.state_frame_stride;
@@ -398,9 +402,9 @@ static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode) {
         a.rows = T;
         a.state_in = b ? buf0 : buf1;
         a.state_out = b ? buf1 : buf0;
-        if (mode == 0)      hipLaunchKernelGGL((sweep_kernel<LPP, 0>), grid, dim3(256), 0, st, a);
-        else if (mode == 1) hipLaunchKernelGGL((sweep_kernel<LPP, 1>), grid, dim3(256), 0, st, a);
-        else                hipLaunchKernelGGL((sweep_kernel<LPP, 2>), grid, dim3(256), 0, st, a);
+        if (mode == 0)      hipLaunchKernelGGL((sweep_kernel<LPP, 0, NWV>), grid, dim3(NWV * 64), 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((sweep_kernel<LPP, 1, NWV>), grid, dim3(NWV * 64), 0, st, a);
+        else                hipLaunchKernelGGL((sweep_kernel<LPP, 2, NWV>), grid, dim3(NWV * 64), 0, st, a);
     }
 }
 

@@ -1,6 +1,7 @@
 #!/bin/bash
+# developer aid: per-kernel VGPR/SGPR/LDS/scratch/occupancy of one .hip file (hipcc -Rpass-analysis=kernel-resource-usage)
 # usage: tools_resusage.sh file.hip  -> one line per kernel: name VGPRs SGPRs scratch LDS occupancy
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 -I/root/repo/include -c "$1" -o /tmp/scratch/_ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 -I'$(dirname "$0")/../include' -c "$1" -o /tmp/scratch/_ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re
 cur={}
 for line in sys.stdin:
