@@ -48,6 +48,29 @@ def cpu_baseline(sample_rows=48):
             "sample": f"oracle fsgm_oracle_epi_aggregate, {reps} x (1242x{sample_rows}x128, 8 paths), {dt:.1f} s"}
 
 
+def pyramid3(args):
+    """BASELINE config 4: pyramidal 2-D path, 1242x375, 3-level pyramid, 11x11 window, 8 paths, 2 passes,
+    P1=6, P2=32 (pyramidal_sgm.m:15-22).  Reports kernel milliseconds per level (HIP events)."""
+    import fsgm_amd
+    from fsgm_amd import synth, PydPlan
+    from fsgm_amd._lib import STAGE_COST, STAGE_AGGREGATE, STAGE_WTA
+    levels, total = [], 0.0
+    for (w, h) in [(311, 94), (621, 188), (1242, 375)]:          # coarse to fine, ceil(size/2) like impyramid
+        plan = PydPlan(w, h, w, h, 5, 5, 2, 1)
+        plan.set_params(6, 32, 1, 2, 0, int((w, h) == (1242, 375)))
+        I1, I2 = synth.image_pair(w, h, 16, seed=2)
+        plan.upload(0, I1, I2, synth.hint_map(w, h, "even", seed=3))
+        ms = [plan.time(st, 1, max(3, args.steps // 4)) for st in (STAGE_COST, STAGE_AGGREGATE, STAGE_WTA)]
+        levels.append({"size": [w, h], "cost_ms": ms[0], "aggregate_ms": ms[1], "wta_ms": ms[2]})
+        total += sum(ms)
+        plan.close()
+    vp = sum(l["size"][0] * l["size"][1] for l in levels) * 121 * 8
+    print(json.dumps({"metric": "calc_pyd_cost_sgm 3-level pyramid, kernel time per image pair", "value": total, "unit": "ms",
+                      "higher_is_better": False, "n_gpus": 1, "dtype": "u8", "data": "synthetic",
+                      "config": {"workload": "pyramid 1242x375 / 621x188 / 311x94, 11x11 window (D=121), 8 paths, 2 passes"},
+                      "voxel_paths_per_s": vp / (total * 1e-3), "levels": levels}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,7 +79,12 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo to rehearse on one GPU)")
+    ap.add_argument("--workload", default="epi8", choices=["epi8", "pyramid3"],
+                    help="epi8 = the headline metric (default); pyramid3 = BASELINE config 4, kernel times of a 3-level "
+                         "calc_pyd_cost_sgm pyramid at 1242x375 (secondary, 1 GPU, not the judged line)")
     args = ap.parse_args()
+    if args.workload == "pyramid3":
+        return pyramid3(args)
 
     import numpy as np
     import torch
