@@ -21,7 +21,8 @@ class FsgmError(RuntimeError):
 
 
 class EpiParams(C.Structure):
-    _fields_ = [("paths", C.c_int32), ("subpixel", C.c_int32), ("vz_to_disp", C.c_int32), ("device", C.c_int32)]
+    _fields_ = [("paths", C.c_int32), ("subpixel", C.c_int32), ("vz_to_disp", C.c_int32), ("device", C.c_int32),
+                ("fb_check", C.c_int32)]
 
 
 class EpiIn(C.Structure):
@@ -31,7 +32,8 @@ class EpiIn(C.Structure):
 
 
 class EpiOut(C.Structure):
-    _fields_ = [("bestD", C.c_void_p), ("minC", C.c_void_p), ("C", C.c_void_p), ("S", C.c_void_p)]
+    _fields_ = [("bestD", C.c_void_p), ("minC", C.c_void_p), ("C", C.c_void_p), ("S", C.c_void_p),
+                ("conf", C.c_void_p), ("bestD2", C.c_void_p)]
 
 
 _lib = None
@@ -67,6 +69,7 @@ def load():
     lib.fsgm_epi_plan_sync.argtypes = [vp]
     lib.fsgm_epi_plan_download.argtypes = [vp, i32, vp, vp]
     lib.fsgm_epi_plan_download_cost.argtypes = [vp, i32, vp]
+    lib.fsgm_epi_plan_download_fb.argtypes = [vp, i32, vp, vp]
     lib.fsgm_epi_plan_download_sum.argtypes = [vp, i32, vp]
     lib.fsgm_epi_plan_time.argtypes = [vp, i32, i32, i32, f32p]
     lib.fsgm_epi_plan_stream.argtypes = [vp]

@@ -29,6 +29,8 @@ struct fsgm_epi_plan {
     double *dPd0 = nullptr, *dNd = nullptr, *dOff = nullptr, *dVz = nullptr;
     uint8_t *dCraw = nullptr, *dC = nullptr, *dL = nullptr;
     uint32_t *dBestD = nullptr, *dMinC = nullptr, *dS = nullptr;
+    uint32_t *dD2enc = nullptr, *dD2 = nullptr;          // forward-backward check (prm.fb_check)
+    uint8_t* dConf = nullptr;
     // fused-sweep aggregation (epi_sweep.hip): horizontal path costs, u16 sums, block-boundary states
     // (see enqueue(): horizontal kernel on stream_h; the frames split into two lanes that sweep
     // down then up on stream / stream_b)
@@ -84,6 +86,7 @@ fsgm_epi_params fsgm_epi_params_default(void) {
     p.subpixel = 1;      // calc_cost_sgm.cpp:560
     p.vz_to_disp = 1;    // calc_cost_sgm.cpp:4
     p.device = 0;
+    p.fb_check = 0;      // calc_cost_sgm.cpp:589-590 (commented out)
     return p;
 }
 
@@ -91,7 +94,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dLh, p->dX, p->dXup, p->dState, p->dRec, p->dS0};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dState, p->dRec, p->dS0};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -112,6 +115,8 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
     FSGM_REQUIRE(batch >= 1, "fsgm_epi_plan_create: batch must be >= 1");
     const fsgm_epi_params pr = prm ? *prm : fsgm_epi_params_default();
     FSGM_REQUIRE(pr.paths == 4 || pr.paths == 8, "fsgm_epi_plan_create: paths must be 4 or 8 (got %d)", pr.paths);
+    if (pr.fb_check && D > 511)
+        return fail(FSGM_ERR_UNSUPPORTED, "fb_check needs dMax <= 511 (bestD must stay below INVALID_DISPARITY)");
     if (D > FSGM_GENERIC_MAX_D)
         return fail(FSGM_ERR_UNSUPPORTED, "dMax %d exceeds the supported maximum %d", D, FSGM_GENERIC_MAX_D);
     if ((double)W * H * D >= 2147483648.0)
@@ -143,6 +148,11 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
     // L_left/right, X_dn, states, records for the fused sweeps) are allocated on first use
     alloc((void**)&p->dBestD, B * p->NP * 4);
     alloc((void**)&p->dMinC, B * p->NP * 4);
+    if (pr.fb_check) {
+        alloc((void**)&p->dD2enc, B * p->NP * 4);
+        alloc((void**)&p->dD2, B * p->NP * 4);
+        alloc((void**)&p->dConf, B * p->NP);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -301,15 +311,24 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
         a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
         a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
-        a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
+        a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp && !p->prm.fb_check;
         launch_sweep_finish(p->stream, a, p->dRec, p->dS0, p->batch);
     } else if (stages & FSGM_STAGE_WTA) {
         WtaArgs a;
         a.L = p->dL; a.l_frame_stride = p->N * p->prm.paths; a.l_dir_stride = p->N;
         a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
         a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
-        a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
+        a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp && !p->prm.fb_check;
         launch_wta(p->stream, a, p->batch, p->packed);
+    }
+    if ((stages & FSGM_STAGE_WTA) && p->prm.fb_check) {
+        // the check sees bestD before the vz conversion (order of calc_cost_sgm.cpp:584-594)
+        FbArgs b;
+        b.D1 = p->dBestD; b.pd0 = p->dPd0; b.nd = p->dNd; b.off = p->dOff;
+        b.D2enc = p->dD2enc; b.D2 = p->dD2; b.conf = p->dConf;
+        b.vMax = p->vMax; b.W = p->W; b.H = p->H; b.n = p->D + 1; b.thr = 2;      // :483 thr = 2
+        launch_fb_check(p->stream, b, p->batch);
+        if (p->prm.vz_to_disp) launch_vz_convert(p->stream, p->dBestD, p->dOff, p->W, p->H, p->D, p->vMax, p->batch);
     }
     FSGM_HIP(hipGetLastError());
     return FSGM_OK;
@@ -344,6 +363,17 @@ fsgm_status fsgm_epi_plan_download(fsgm_epi_plan* p, int32_t f, uint32_t* bestD,
     FSGM_HIP(hipStreamSynchronize(p->stream));
     if (bestD) FSGM_HIP(hipMemcpy(bestD, p->dBestD + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
     if (minC) FSGM_HIP(hipMemcpy(minC, p->dMinC + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_download_fb(fsgm_epi_plan* p, int32_t f, uint8_t* conf, uint32_t* bestD2) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
+    FSGM_REQUIRE(p->prm.fb_check, "the plan was created without fb_check");
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    if (conf) FSGM_HIP(hipMemcpy(conf, p->dConf + f * p->NP, p->NP, hipMemcpyDeviceToHost));
+    if (bestD2) FSGM_HIP(hipMemcpy(bestD2, p->dD2 + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
     return FSGM_OK;
 }
 
@@ -465,7 +495,7 @@ static std::vector<fsgm_epi_plan*> g_cache;
 static fsgm_status cached_plan(fsgm_epi_plan** out, int W, int H, int D, int batch, const fsgm_epi_params& pr) {
     for (fsgm_epi_plan* p : g_cache)
         if (p->W == W && p->H == H && p->D == D && p->batch == batch && p->prm.paths == pr.paths &&
-            p->prm.device == pr.device) {
+            p->prm.device == pr.device && p->prm.fb_check == pr.fb_check) {
             p->prm = pr;
             *out = p;
             return FSGM_OK;
@@ -514,6 +544,8 @@ fsgm_status fsgm_calc_cost_sgm_batch_host(int32_t n, const fsgm_epi_in* in, cons
     if ((st = fsgm_epi_plan_run(p, FSGM_STAGE_ALL)) != FSGM_OK) return st;
     for (int i = 0; i < n; i++) {
         if ((st = fsgm_epi_plan_download(p, i, out[i].bestD, out[i].minC)) != FSGM_OK) return st;
+        if (pr.fb_check && (out[i].conf || out[i].bestD2) &&
+            (st = fsgm_epi_plan_download_fb(p, i, out[i].conf, out[i].bestD2)) != FSGM_OK) return st;
         if (out[i].C && (st = fsgm_epi_plan_download_cost(p, i, out[i].C)) != FSGM_OK) return st;
         if (out[i].S && (st = fsgm_epi_plan_download_sum(p, i, out[i].S)) != FSGM_OK) return st;
     }

@@ -72,6 +72,18 @@ struct SweepSumArgs {          // what wta_sweep_kernel adds up (all u8 volumes,
     uint32_t* Sdbg;           // optional natural-order u32 dump of S [frames][NP][D]
 };
 
+struct FbArgs {                // forward-backward check (calc_cost_sgm.cpp:429-536)
+    const uint32_t* D1;       // [frames][NP] bestD before vz->disparity
+    const double* pd0;        // [frames][2][NP]
+    const double* nd;         // [frames][2][NP]
+    const double* off;        // [frames][NP]
+    uint32_t* D2enc;          // [frames][NP] scratch: max(D1 + 1) scattered, 0 = invalid
+    uint32_t* D2;             // [frames][NP] out: bestD2 (512<<8 where invalid)
+    uint8_t* conf;            // [frames][NP] out: 1 = consistent
+    double vMax;
+    int W, H, n, thr;
+};
+
 enum { AGG_PACKED_NOWRAP = 0, AGG_PACKED_WRAP = 1, AGG_GENERIC = 2, AGG_SWEEP = 3 };
 
 int  agg_packed_lpp(int D);   // lanes per pixel of the packed kernels, 0 if D is not 16<<k, k<=4
@@ -84,6 +96,8 @@ size_t sweep_state_bytes(int W, int D);   // one state buffer of one frame
 void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode);   // 0 down, 1 up, 2 up + fused WTA
 void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames);
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);
+void launch_fb_check(hipStream_t st, const FbArgs& a, int frames);
+void launch_vz_convert(hipStream_t st, uint32_t* bestD, const double* off, int W, int H, int D, double vMax, int frames);
 void launch_sum_paths(hipStream_t st, const uint8_t* L, uint32_t* S, size_t n, size_t dir_stride, int ndirs);
 
 }  // namespace fsgm

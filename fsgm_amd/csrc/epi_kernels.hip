@@ -536,6 +536,96 @@ __global__ __launch_bounds__(256) void wta_generic_kernel(WtaArgs a) {
 }
 
 // =============================================================================================
+// forward-backward consistency check  (calc_cost_sgm.cpp:429-480 calc_disp_from_first, :482-536
+// forward_backward_check; dead code in the shipped reference -- its call at :589-590 is commented
+// out -- offered here as an option).  Runs on bestD (vz index * 256) before vz->disparity.
+// The reference's scatter "D2[t] = D1 if D2[t] is invalid or smaller" in raster order is a
+// maximum over the contributing pixels, so it is done with atomicMax on D1+1 (0 = invalid).
+// =============================================================================================
+__device__ __forceinline__ double fb_displacement(const FbArgs& a, size_t f, int p, uint32_t d1) {
+    const double d = __ddiv_rn((double)d1, 256.0);                                 // :447 / :502
+    const double r = __dmul_rn(__ddiv_rn(d, (double)a.n), a.vMax);
+    const double vz = __ddiv_rn(r, __dsub_rn(1.0, r));
+    return __dmul_rn(a.off[f * (size_t)a.W * a.H + p], vz);                        // :451 / :506
+}
+
+__global__ __launch_bounds__(256) void fb_scatter_kernel(FbArgs a) {
+    const int NP = a.W * a.H;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    const size_t f = blockIdx.y;
+    const uint32_t d1 = a.D1[f * (size_t)NP + p];
+    const double d = fb_displacement(a, f, p, d1);
+    const double* p0 = a.pd0 + f * 2 * (size_t)NP;
+    const double* nd = a.nd + f * 2 * (size_t)NP;
+    const int p2x = f64_to_i32_x86(__dadd_rn(__dsub_rn(p0[p], 1.0), __dmul_rn(d, nd[p])));            // :462
+    const int p2y = f64_to_i32_x86(__dadd_rn(__dsub_rn(p0[NP + p], 1.0), __dmul_rn(d, nd[NP + p])));  // :463
+    uint32_t* enc = a.D2enc + f * (size_t)NP;
+#pragma unroll
+    for (int dy = 0; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = 0; dx <= 1; dx++) {
+            const long long tx = (long long)dx + p2x, ty = (long long)dy + p2y;
+            if (tx >= 0 && tx < a.W && ty >= 0 && ty < a.H) atomicMax(&enc[ty * a.W + tx], d1 + 1u);    // :471-474
+        }
+}
+
+__global__ __launch_bounds__(256) void fb_check_kernel(FbArgs a) {
+    const int NP = a.W * a.H;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    const size_t f = blockIdx.y;
+    const uint32_t INVALID = 512u << 8;                                            // :5
+    const uint32_t* enc = a.D2enc + f * (size_t)NP;
+    const uint32_t mine = enc[p];
+    a.D2[f * (size_t)NP + p] = mine ? mine - 1u : INVALID;                         // plhs[3] in natural form
+    const uint32_t d1 = a.D1[f * (size_t)NP + p];
+    const double d = fb_displacement(a, f, p, d1);
+    const double* p0 = a.pd0 + f * 2 * (size_t)NP;
+    const double* nd = a.nd + f * 2 * (size_t)NP;
+    const int p2x = round_to_i32_x86(__dadd_rn(__dsub_rn(p0[p], 1.0), __dmul_rn(d, nd[p])));            // :516
+    const int p2y = round_to_i32_x86(__dadd_rn(__dsub_rn(p0[NP + p], 1.0), __dmul_rn(d, nd[NP + p])));  // :517
+    uint8_t ok = 1;                                                                // :485
+    if (p2x < 0 || p2x > a.W - 1 || p2y < 0 || p2y > a.H - 1) ok = 0;              // :519-522
+    else {
+        const uint32_t t = enc[p2y * a.W + p2x];
+        if (t == 0) ok = 0;                                                        // :524-527
+        else {
+            long long diff = (long long)(int32_t)d1 - (long long)(int32_t)(t - 1u);   // :529
+            if (diff < 0) diff = -diff;
+            if (diff > a.thr) ok = 0;
+        }
+    }
+    a.conf[f * (size_t)NP + p] = ok;
+}
+
+// convert_vzInd_to_disp as its own pass (calc_cost_sgm.cpp:414-426), used when the check above
+// has to see bestD before the conversion
+__global__ __launch_bounds__(256) void vz_convert_kernel(uint32_t* __restrict__ bestD, const double* __restrict__ off,
+                                                         int NP, int n, double vMax) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    const size_t i = (size_t)blockIdx.y * NP + p;
+    const double d = __ddiv_rn((double)bestD[i], 256.0);
+    const double r = __dmul_rn(__ddiv_rn(d, (double)n), vMax);
+    const double vz = __ddiv_rn(r, __dsub_rn(1.0, r));
+    bestD[i] = f64_to_u32_x86(__dmul_rn(__dmul_rn(off[i], vz), 256.0));
+}
+
+void launch_fb_check(hipStream_t st, const FbArgs& a, int frames) {
+    const int NP = a.W * a.H;
+    (void)hipMemsetAsync(a.D2enc, 0, (size_t)frames * NP * 4, st);                 // :440-442 all invalid
+    dim3 grid((NP + 255) / 256, frames);
+    hipLaunchKernelGGL(fb_scatter_kernel, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(fb_check_kernel, grid, dim3(256), 0, st, a);
+}
+
+void launch_vz_convert(hipStream_t st, uint32_t* bestD, const double* off, int W, int H, int D, double vMax, int frames) {
+    dim3 grid((W * H + 255) / 256, frames);
+    hipLaunchKernelGGL(vz_convert_kernel, grid, dim3(256), 0, st, bestD, off, W * H, D + 1, vMax);
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int H, int frames) {

@@ -25,14 +25,15 @@ def _f64(a, shape, name):
     return np.ascontiguousarray(a)
 
 
-def _params(paths, subpixel, vz_to_disp, device):
+def _params(paths, subpixel, vz_to_disp, device, fb_check=0):
     p = EpiParams()
     p.paths, p.subpixel, p.vz_to_disp, p.device = int(paths), int(subpixel), int(vz_to_disp), int(device)
+    p.fb_check = int(fb_check)
     return p
 
 
 def calc_cost_sgm_batch(frames, dMax, vMax, P1, P2, *, paths=4, subpixel=1, vz_to_disp=1, device=0,
-                        return_volumes=False):
+                        return_volumes=False, fb_check=0):
     """frames: list of (I1, I2, pixelPosD0, normDir, offset) of one shape, processed concurrently."""
     lib = _lib.load()
     n = len(frames)
@@ -57,33 +58,38 @@ def calc_cost_sgm_batch(frames, dMax, vMax, P1, P2, *, paths=4, subpixel=1, vz_t
         e.I1, e.I2, e.width, e.height, e.dMax, e.vMax = ptr(I1), ptr(I2), W, H, D, float(vMax)
         e.pixelPosD0, e.normDir, e.offset, e.P1, e.P2 = ptr(pd0), ptr(nd), ptr(off), int(P1), int(P2)
         o = outs[i]
-        o.bestD, o.minC, o.C, o.S = ptr(bestD), ptr(minC), ptr(Cv), ptr(Sv)
-        res.append((bestD, minC, Cv, Sv) if return_volumes else (bestD, minC))
-    prm = _params(paths, subpixel, vz_to_disp, device)
+        conf = np.zeros((H, W), np.uint8) if fb_check else None
+        bestD2 = np.zeros((H, W), np.uint32) if fb_check else None
+        o.bestD, o.minC, o.C, o.S, o.conf, o.bestD2 = ptr(bestD), ptr(minC), ptr(Cv), ptr(Sv), ptr(conf), ptr(bestD2)
+        r = (bestD, minC, Cv, Sv) if return_volumes else (bestD, minC)
+        res.append(r + (conf, bestD2) if fb_check else r)
+    prm = _params(paths, subpixel, vz_to_disp, device, fb_check)
     check(lib.fsgm_calc_cost_sgm_batch_host(n, ins, outs, C.byref(prm)))
     return res
 
 
 def calc_cost_sgm(I1, I2, dMax, vMax, pixelPosD0, normlizeDirection, offsetFromPosD0, P1, P2, *,
-                  paths=4, subpixel=1, vz_to_disp=1, device=0, return_volumes=False):
+                  paths=4, subpixel=1, vz_to_disp=1, device=0, return_volumes=False, fb_check=0):
     """[bestD, minC] = calc_cost_sgm(I1, I2, dMax, vMax, pixelPosD0, normlizeDirection,
     offsetFromPosD0, P1, P2)  -- same argument order and meaning as the MEX.
 
     Keyword arguments are the reference's compile-time switches (defaults = as shipped).
+    fb_check=1 additionally returns (conf, bestD2): the forward-backward check the reference has
+    commented out (calc_cost_sgm.cpp:482-536, :589-590).
     """
     return calc_cost_sgm_batch([(I1, I2, pixelPosD0, normlizeDirection, offsetFromPosD0)], dMax, vMax, P1, P2,
                                paths=paths, subpixel=subpixel, vz_to_disp=vz_to_disp, device=device,
-                               return_volumes=return_volumes)[0]
+                               return_volumes=return_volumes, fb_check=fb_check)[0]
 
 
 class EpiPlan:
     """Device-resident plan: `batch` frames of width x height x dMax stay in HBM across calls."""
 
-    def __init__(self, width, height, dMax, batch=1, *, paths=4, subpixel=1, vz_to_disp=1, device=0):
+    def __init__(self, width, height, dMax, batch=1, *, paths=4, subpixel=1, vz_to_disp=1, device=0, fb_check=0):
         self.lib = _lib.load()
         self.W, self.H, self.D, self.batch, self.paths = int(width), int(height), int(dMax), int(batch), int(paths)
         self._h = C.c_void_p()
-        prm = _params(paths, subpixel, vz_to_disp, device)
+        prm = _params(paths, subpixel, vz_to_disp, device, fb_check)
         check(self.lib.fsgm_epi_plan_create(C.byref(self._h), self.W, self.H, self.D, self.batch, C.byref(prm)))
 
     def close(self):
@@ -138,6 +144,13 @@ class EpiPlan:
         minC = np.empty((self.H, self.W), np.uint32)
         check(self.lib.fsgm_epi_plan_download(self._h, frame, ptr(bestD), ptr(minC)))
         return bestD, minC
+
+    def download_fb(self, frame):
+        """(conf, bestD2) of the forward-backward check (plans created with fb_check=1)."""
+        conf = np.empty((self.H, self.W), np.uint8)
+        bestD2 = np.empty((self.H, self.W), np.uint32)
+        check(self.lib.fsgm_epi_plan_download_fb(self._h, frame, ptr(conf), ptr(bestD2)))
+        return conf, bestD2
 
     def download_cost(self, frame):
         Cv = np.empty((self.H, self.W, self.D), np.uint8)

@@ -4,7 +4,8 @@
 // called as [bestD, minC] = ... from epipolar_sgm_of.m:45.  Everything computes on the GPU through
 // libfsgm_hip.so; this file only unpacks mxArrays.
 // Environment: FSGM_DEVICE (HIP ordinal, default 0); FSGM_EPI_PATHS=8 enables the diagonal paths
-// the reference compiles out (calc_cost_sgm.cpp:104) -- default 4 = as shipped.
+// the reference compiles out (calc_cost_sgm.cpp:104) -- default 4 = as shipped; FSGM_EPI_FB_CHECK=1
+// runs the forward-backward check the reference has commented out (:589-590) and fills conf/bestD2.
 #include "gateway_common.h"
 
 extern "C" void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
@@ -37,9 +38,12 @@ extern "C" void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* 
     out.bestD = (uint32_t*)mxGetData(bestD);
     out.minC = (uint32_t*)mxGetData(minC);
     out.C = NULL; out.S = NULL;
+    out.conf = nlhs > 2 ? (uint8_t*)mxGetData(plhs[2]) : NULL;
+    out.bestD2 = nlhs > 3 ? (uint32_t*)mxGetData(plhs[3]) : NULL;
     fsgm_epi_params prm = fsgm_epi_params_default();
     prm.device = fsgm_env_int("FSGM_DEVICE", 0);
     prm.paths = fsgm_env_int("FSGM_EPI_PATHS", 4);
+    prm.fb_check = fsgm_env_int("FSGM_EPI_FB_CHECK", 0) != 0;
     fsgm_register_atexit();
     const fsgm_status st = fsgm_calc_cost_sgm_host(&in, &out, &prm);
     if (nlhs <= 1) mxDestroyArray(minC);

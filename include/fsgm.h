@@ -56,6 +56,9 @@ typedef struct {
     int32_t subpixel;     /* 1 = as shipped (subPixelRefine=true, calc_cost_sgm.cpp:560) */
     int32_t vz_to_disp;   /* 1 = as shipped (USE_VZIND, calc_cost_sgm.cpp:4,592-594) */
     int32_t device;       /* HIP device ordinal */
+    int32_t fb_check;     /* 0 = as shipped (call commented out, calc_cost_sgm.cpp:589-590: conf and bestD2 stay 0);
+                             1 = run forward_backward_check (:482-536, threshold 2) on bestD before vz->disparity.
+                             Needs dMax <= 511 (bestD must stay below INVALID_DISPARITY = 512<<8) */
 } fsgm_epi_params;
 
 fsgm_epi_params fsgm_epi_params_default(void);
@@ -79,6 +82,10 @@ typedef struct {
      * path costs S (u32 [H][W][D]) -- internal arrays of the reference (calc_cost_sgm.cpp:579,95) */
     uint8_t*  C;
     uint32_t* S;
+    /* plhs[2], plhs[3]: filled only when fb_check = 1 and the pointer is not NULL (the caller's
+     * zero-initialised arrays stay untouched otherwise, like in the shipped reference) */
+    uint8_t*  conf;               /* u8  [H][W], 1 = forward-backward consistent */
+    uint32_t* bestD2;             /* u32 [H][W], disparity of the second view, 512<<8 where invalid */
 } fsgm_epi_out;
 
 /* One frame, host pointers in / host pointers out.  This is what the calc_cost_sgm gateway
@@ -119,6 +126,7 @@ fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* plan, int32_t stages);
 fsgm_status fsgm_epi_plan_sync(fsgm_epi_plan* plan);
 /* HBM -> host (synchronous) */
 fsgm_status fsgm_epi_plan_download(fsgm_epi_plan* plan, int32_t frame, uint32_t* bestD, uint32_t* minC);
+fsgm_status fsgm_epi_plan_download_fb(fsgm_epi_plan* plan, int32_t frame, uint8_t* conf, uint32_t* bestD2);
 fsgm_status fsgm_epi_plan_download_cost(fsgm_epi_plan* plan, int32_t frame, uint8_t* C);
 fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* plan, int32_t frame, uint32_t* S);
 /* Average milliseconds of one fsgm_epi_plan_run(stages) over `iters` back-to-back runs after

@@ -50,6 +50,13 @@ void fsgm_oracle_epi_wta(uint32_t* bestD, uint32_t* minC, const uint32_t* S,
 void fsgm_oracle_epi_vz_to_disp(uint32_t* bestD, int W, int H, const double* offset,
                                 double vMax, int n);
 
+/* calc_cost_sgm.cpp:429-536: forward-backward consistency check (dead code in the shipped
+ * reference: its call at :589-590 is commented out).  Runs on bestD before vz->disparity.
+ * conf u8 [H*W] (1 = consistent), D2 u32 [H*W]. */
+void fsgm_oracle_epi_fb_check(uint8_t* conf, uint32_t* D2, const uint32_t* D1, int W, int H,
+                              const double* pixelPosD0, const double* normDir, const double* offset,
+                              double vMax, int n, int thr);
+
 /* calc_cost_sgm.cpp:539-598: the whole MEX.  paths: 4 = as shipped.  Optional debug outputs C
  * (u8 [H*W*D]) and S (u32 [H*W*D+1]) may be NULL. */
 void fsgm_oracle_calc_cost_sgm(uint32_t* bestD, uint32_t* minC,

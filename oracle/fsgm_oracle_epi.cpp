@@ -198,6 +198,54 @@ void fsgm_oracle_epi_vz_to_disp(uint32_t* bestD, int W, int H, const double* off
     }
 }
 
+/* calc_cost_sgm.cpp:429-480 calc_disp_from_first + :482-536 forward_backward_check (USE_VZIND
+ * branch).  Dead code in the reference as shipped (the call at :589-590 is commented out): it
+ * would run on bestD BEFORE convert_vzInd_to_disp.  D1 = bestD (vz index * 256). */
+void fsgm_oracle_epi_fb_check(uint8_t* conf, uint32_t* D2, const uint32_t* D1, int W, int H,
+                              const double* pixelPosD0, const double* normDir, const double* offset,
+                              double vMax, int n, int thr) {
+    const size_t NP = (size_t)W * H;
+    const uint32_t INVALID = 512u << 8;                              /* :5 INVALID_DISPARITY */
+    const double* dirX = normDir;   const double* dirY = normDir + NP;
+    const double* p0X = pixelPosD0; const double* p0Y = pixelPosD0 + NP;
+    for (size_t p = 0; p < NP; p++) D2[p] = INVALID;                 /* :440-442 */
+    auto displacement = [&](size_t p) {                              /* :447-451 / :502-506 */
+        double d = (double)D1[p] / 256;
+        const double vzRatio = d / n * vMax;
+        const double vzInd = vzRatio / (1 - vzRatio);
+        return offset[p] * vzInd;
+    };
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            const double d = displacement(p);
+            const int p2x = f64_to_i32((p0X[p] - 1) + d * dirX[p]);  /* :462 truncation */
+            const int p2y = f64_to_i32((p0Y[p] - 1) + d * dirY[p]);  /* :463 */
+            for (int dy = 0; dy <= 1; dy++)
+                for (int dx = 0; dx <= 1; dx++) {
+                    const long long tx = (long long)dx + p2x, ty = (long long)dy + p2y;
+                    if (tx >= 0 && tx < W && ty >= 0 && ty < H) {
+                        uint32_t& t = D2[(size_t)ty * W + tx];
+                        if (t == INVALID || t < D1[p]) t = D1[p];    /* :472-473 */
+                    }
+                }
+        }
+    memset(conf, 1, NP);                                             /* :485 */
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            const double d = displacement(p);
+            const int p2x = f64_to_i32(round((p0X[p] - 1) + d * dirX[p]));   /* :516 */
+            const int p2y = f64_to_i32(round((p0Y[p] - 1) + d * dirY[p]));   /* :517 */
+            if (p2x < 0 || p2x > W - 1 || p2y < 0 || p2y > H - 1) { conf[p] = 0; continue; }   /* :519-522 */
+            const uint32_t t = D2[(size_t)p2y * W + p2x];
+            if (t == INVALID) { conf[p] = 0; continue; }                                       /* :524-527 */
+            long long diff = (long long)(int32_t)D1[p] - (long long)(int32_t)t;                /* :529 int(D1) - int(D2) */
+            if (diff < 0) diff = -diff;
+            if (diff > thr) conf[p] = 0;
+        }
+}
+
 /* calc_cost_sgm.cpp:539-598 */
 void fsgm_oracle_calc_cost_sgm(uint32_t* bestD, uint32_t* minC,
                                const uint8_t* I1, const uint8_t* I2, int W, int H, int D,

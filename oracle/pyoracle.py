@@ -204,3 +204,14 @@ def calc_cost_sgm_ng(I1, I2, P1, P2, rand_stream):
     lib().fsgm_oracle_calc_cost_sgm_ng(_p(minC), _p(flow), _p(I1), _p(I2), W, H, int(P1), int(P2), _p(rs),
                                        C.c_int64(len(rs)))
     return minC, flow
+
+
+def epi_fb_check(D1, pd0, nd, off, vMax, n, thr=2):
+    """forward_backward_check of calc_cost_sgm.cpp:482-536 on bestD (before vz->disparity)."""
+    D1 = np.ascontiguousarray(D1, np.uint32)
+    H, W = D1.shape
+    conf = np.zeros((H, W), np.uint8)
+    D2 = np.zeros((H, W), np.uint32)
+    lib().fsgm_oracle_epi_fb_check(_p(conf), _p(D2), _p(D1), W, H, _p(np.ascontiguousarray(pd0)),
+                                   _p(np.ascontiguousarray(nd)), _p(np.ascontiguousarray(off)), C.c_double(vMax), int(n), int(thr))
+    return conf, D2

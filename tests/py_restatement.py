@@ -484,3 +484,36 @@ def otf(I1, I2, P1, P2, rnd):
             minC[y, x] = S[y, x, idx]
             flow[0, y, x], flow[1, y, x] = Cvol[y, x, idx, 0], Cvol[y, x, idx, 1]
     return minC, flow
+
+
+def fb_check(D1, pd0, nd, off, vMax, n, thr=2):         # calc_cost_sgm.cpp:429-536 (USE_VZIND), raster order
+    H, W = D1.shape
+    INVALID = 512 << 8
+    D2 = np.full((H, W), INVALID, np.int64)
+
+    def disp(y, x):
+        d = float(D1[y, x]) / 256
+        r = d / n * vMax
+        return off[y, x] * (r / (1 - r))
+    for y in range(H):
+        for x in range(W):
+            d = disp(y, x)
+            p2x = int((pd0[0, y, x] - 1) + d * nd[0, y, x])
+            p2y = int((pd0[1, y, x] - 1) + d * nd[1, y, x])
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    tx, ty = dx + p2x, dy + p2y
+                    if 0 <= tx < W and 0 <= ty < H:
+                        if D2[ty, tx] == INVALID or D2[ty, tx] < D1[y, x]:
+                            D2[ty, tx] = D1[y, x]
+    conf = np.ones((H, W), np.uint8)
+    for y in range(H):
+        for x in range(W):
+            d = disp(y, x)
+            p2x = int(_c_round((pd0[0, y, x] - 1) + d * nd[0, y, x]))
+            p2y = int(_c_round((pd0[1, y, x] - 1) + d * nd[1, y, x]))
+            if p2x < 0 or p2x > W - 1 or p2y < 0 or p2y > H - 1 or D2[p2y, p2x] == INVALID:
+                conf[y, x] = 0
+            elif abs(int(D1[y, x]) - int(D2[p2y, p2x])) > thr:
+                conf[y, x] = 0
+    return conf, D2.astype(np.uint32)

@@ -263,3 +263,29 @@ def test_cost_volume_rounding_edge_cases(gpu_lib, oracle):
         plan.run(STAGE_COST)
         got = plan.download_cost(0)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("W,H,D,kind,paths", [(64, 48, 16, "axis", 8), (97, 61, 64, "general", 8), (50, 40, 24, "general", 4),
+                                               (160, 90, 128, "axis", 8)])
+def test_forward_backward_check(gpu_lib, oracle, W, H, D, kind, paths):
+    """fb_check=1: forward_backward_check / calc_disp_from_first (calc_cost_sgm.cpp:429-536, dead code
+    in the shipped reference) on bestD before vz->disparity; conf and bestD2 bit-exact, bestD/minC unchanged."""
+    I1, I2 = synth.image_pair(W, H, D, seed=5)
+    pd0, nd, off = synth.epi_maps(W, H, kind, seed=6)
+    Cv = oracle.epi_cost(I1, I2, D, 0.3, pd0, nd, off)
+    S = oracle.epi_aggregate(Cv, 6, 64, paths)
+    bd_idx, mc = oracle.epi_wta(S, W, H, D, 1)
+    conf, d2 = oracle.epi_fb_check(bd_idx, pd0, nd, off, 0.3, D + 1)
+    bd = oracle.epi_vz_to_disp(bd_idx, off, 0.3, D + 1)
+    gbd, gmc, gconf, gd2 = calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, paths=paths, fb_check=1)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gbd, bd)
+    np.testing.assert_array_equal(gd2, d2)
+    np.testing.assert_array_equal(gconf, conf)
+    assert 0 < int(gconf.sum()) < W * H                      # both outcomes occur
+    # a batch of 5 goes through the fused sweeps: same answer
+    res = calc_cost_sgm_batch([(I1, I2, pd0, nd, off)] * 5, D, 0.3, 6, 64, paths=paths, fb_check=1)
+    for r in res:
+        np.testing.assert_array_equal(r[0], bd)
+        np.testing.assert_array_equal(r[2], conf)
+        np.testing.assert_array_equal(r[3], d2)

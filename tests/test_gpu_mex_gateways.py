@@ -23,6 +23,19 @@ def test_calc_cost_sgm_gateway_as_epipolar_sgm_of_calls_it(gpu_lib, oracle):
     assert outs[2].dtype == np.uint8 and not outs[2].any() and outs[3].dtype == np.uint32 and not outs[3].any()
     (only,), _ = mh.call("calc_cost_sgm", 0, I1, I2, D, 0.3, pd0, nd, off, 6, 64)
     np.testing.assert_array_equal(only, rbd)
+    # FSGM_EPI_FB_CHECK=1: the commented-out forward-backward check fills outputs 3 and 4
+    import os
+    os.environ["FSGM_EPI_FB_CHECK"] = "1"
+    try:
+        outs, _ = mh.call("calc_cost_sgm", 4, I1, I2, D, 0.3, pd0, nd, off, 6, 64)
+    finally:
+        del os.environ["FSGM_EPI_FB_CHECK"]
+    Cv = oracle.epi_cost(I1, I2, D, 0.3, pd0, nd, off)
+    idx, _ = oracle.epi_wta(oracle.epi_aggregate(Cv, 6, 64, 4), W, H, D, 1)
+    conf, d2 = oracle.epi_fb_check(idx, pd0, nd, off, 0.3, D + 1)
+    np.testing.assert_array_equal(outs[0], rbd)
+    np.testing.assert_array_equal(outs[2], conf)
+    np.testing.assert_array_equal(outs[3], d2)
 
 
 def test_calc_pyd_cost_sgm_gateway_as_pyramidal_sgm_calls_it(gpu_lib, oracle):

@@ -131,3 +131,17 @@ def test_oracle_regression_fixture(oracle):
         bd, mc = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, paths)
         np.testing.assert_array_equal(bd, g[f"bestD{paths}"])
         np.testing.assert_array_equal(mc, g[f"minC{paths}"])
+
+
+@pytest.mark.parametrize("kind", ["axis", "general"])
+def test_fb_check_vs_second_restatement(oracle, kind):
+    """forward_backward_check / calc_disp_from_first (calc_cost_sgm.cpp:429-536, dead code in the shipped MEX)."""
+    W, H, D = 20, 14, 16
+    I1, I2 = synth.image_pair(W, H, D, seed=4)
+    pd0, nd, off = synth.epi_maps(W, H, kind, seed=9)
+    bd, _, _, S = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, 8, want_volumes=True)
+    idx, _ = oracle.epi_wta(np.concatenate([S.reshape(-1), [0]]).astype(np.uint32), W, H, D, 1)
+    conf, d2 = oracle.epi_fb_check(idx, pd0, nd, off, 0.3, D + 1)
+    rconf, rd2 = R.fb_check(idx, pd0, nd, off, 0.3, D + 1)
+    np.testing.assert_array_equal(d2, rd2)
+    np.testing.assert_array_equal(conf, rconf)
