@@ -6,18 +6,21 @@
 // (+1,+1) and from above-right (-1,+1), calc_cost_sgm.cpp:193-226 -- are computed TOGETHER for the
 // same pixel, so C is read once per sweep and only their sum leaves the chip:
 //
-//   horizontal kernel  (existing agg_packed_kernel, 2 slots)   C -> L_left, L_right   (u8)
-//   down sweep         C -> X_dn = sum over the three pass-0 paths from above of (L_r - C)   (u8)
-//   up sweep           C -> X_up = the same on the point-mirrored frame (pass 1)             (u8)
-//   wta_sweep_kernel   S = X_dn + X_up + 6*C + L_left + L_right -> bestD, minC
+//   horizontal kernel (agg_packed_kernel, 2 slots)   C -> L_left, L_right                      (u8)
+//   down sweep   (MODE 0)   C -> X_dn = sum over the three pass-0 paths from above of (L_r - C)  (u8)
+//   final sweep  (MODE 2)   on the point-mirrored frame (pass 1): its own three paths, then in
+//                           registers S = X_up + X_dn + 6*C + L_left + L_right and the WTA;
+//                           writes one 18-byte record per PIXEL
+//   sweep_finish_kernel     parabola / vz->disparity from the records -> bestD, minC
 //
 // Every path cost satisfies C <= L_r <= C + P2 when nothing wraps, so the EXCESS L_r - C of three
-// paths fits a byte whenever 3*P2 <= 255 (the reference uses P2 = 64 and 32): the partial sums
-// cost 1 B per voxel instead of 2.  Total 13 B per voxel instead of 24, and the three producers
-// are independent of each other, so they run concurrently on three streams (one sweep launch
-// alone -- strips x frames workgroups -- is too small to fill 256 CUs).
-// MODE 2 (final up sweep) goes further: it reads X_dn and the horizontal pair itself, forms S in
-// registers and does the WTA on the spot, so neither X_up nor S ever reaches HBM (10 B/voxel).
+// paths fits a byte whenever 3*P2 <= 255 (the reference uses P2 = 64 and 32): X_dn costs 1 B per
+// voxel, and neither X_up nor S (u32 in the reference) ever reaches HBM.  10 B per voxel by design
+// (11.4 measured) instead of 24.  One sweep launch alone -- strips x frames workgroups -- is too
+// small to fill 256 CUs, so the host forks the work over three streams: the horizontal kernel, and
+// two lanes of frames that each sweep down and then up (capi_epi.hip).
+// MODE 1 (plain up sweep writing X_up) and wta_sweep_kernel exist for the debug tap that
+// rebuilds S in natural order (fsgm_epi_plan_download_sum).
 //
 // The diagonal paths couple neighbouring columns, so a workgroup that owns a strip of columns needs
 // its neighbours' boundary values every row.  Instead of in-kernel neighbour synchronisation the
