@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) void sum_paths_kernel(const uint8_t* __restric
 // =============================================================================================
 __device__ __forceinline__ uint32_t sum_at(const uint8_t* Lf, size_t dir_stride, int ndirs, size_t idx) {
     uint32_t s = 0;
-    for (int r = 0; r < ndirs; r++) s += Lf[r * dir_stride + idx];
+#pragma unroll
+    for (int r = 0; r < 8; r++) s += r < ndirs ? (uint32_t)Lf[r * dir_stride + idx] : 0u;   // loads issued together
     return s;
 }
 

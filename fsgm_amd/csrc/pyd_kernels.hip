@@ -300,8 +300,12 @@ __global__ __launch_bounds__(256) void pyd_agg_kernel(PydAggArgs a) {
 // WTA + y/x parabola  (calc_pyd_cost_sgm.cpp:298-364).  One wave per pixel.
 // =============================================================================================
 __device__ __forceinline__ uint32_t pyd_sum_at(const PydWtaArgs& a, const uint8_t* Lf, size_t vol, size_t idx) {
+    uint32_t v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = r < a.ndirs ? (uint32_t)Lf[r * vol + idx] : 0u;   // all loads in flight together
     uint32_t s = 0;
-    for (int r = 0; r < a.ndirs; r++) s += a.weight[r] * (uint32_t)Lf[r * vol + idx];
+#pragma unroll
+    for (int r = 0; r < 8; r++) s += a.weight[r] * v[r];
     return s;
 }
 
