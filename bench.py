@@ -41,7 +41,7 @@ def cpu_baseline(sample_rows=48):
         pyoracle.epi_aggregate(Cv, P1, P2, PATHS)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > 8.0 or reps >= 50:
+        if dt > 10.0 or reps >= 120:
             break
     vp = reps * W * sample_rows * D * PATHS
     return {"value": vp / dt, "unit": "voxel-paths/s", "cores": 1, "kind": "port",
