@@ -3,6 +3,7 @@
 #include "epi_kernels.h"
 #include "pyd_kernels.h"
 #include <mutex>
+#include <string.h>
 #include <vector>
 
 using namespace fsgm;
@@ -10,13 +11,15 @@ using namespace fsgm;
 struct fsgm_pyd_plan {
     int W = 0, H = 0, mvW = 0, mvH = 0, rX = 0, rY = 0, rAgg = 0, batch = 0, device = 0;
     int Sx = 0, Sy = 0, D = 0;
+    int RS = 0, PS = 0;                  // volume layout in HBM (pyd_kernels.h): row stride, bytes per pixel
     int P1 = 6, P2 = 32, diagonal = 1, totalPass = 2, adaptive = 0, subpixel = 0;   // pyramidal_sgm.m:15-22
     int cmax = 24;                       // upper bound of the values in dC
-    size_t NP = 0, N = 0, MV = 0;
+    size_t NP = 0, N = 0, MV = 0;        // N = bytes of one volume (NP * PS)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *dI1 = nullptr, *dI2 = nullptr, *dC = nullptr, *dL = nullptr;
-    uint32_t *dCen1 = nullptr, *dCen2 = nullptr, *dBestD = nullptr, *dMinC = nullptr, *dS = nullptr;
+    uint32_t *dCen1 = nullptr, *dCen2 = nullptr, *dBestD = nullptr, *dMinC = nullptr, *dS = nullptr, *dDesc = nullptr;
+    std::vector<uint8_t> stage;          // host staging for layout conversion of debug volumes
     double *dMv = nullptr, *dMvSub = nullptr;
 };
 
@@ -25,7 +28,7 @@ extern "C" {
 void fsgm_pyd_plan_destroy(fsgm_pyd_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    void* bufs[] = {p->dI1, p->dI2, p->dC, p->dL, p->dCen1, p->dCen2, p->dBestD, p->dMinC, p->dS, p->dMv, p->dMvSub};
+    void* bufs[] = {p->dI1, p->dI2, p->dC, p->dL, p->dCen1, p->dCen2, p->dBestD, p->dMinC, p->dS, p->dDesc, p->dMv, p->dMvSub};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -57,7 +60,8 @@ fsgm_status fsgm_pyd_plan_create(fsgm_pyd_plan** out, int32_t W, int32_t H, int3
     p->W = W; p->H = H; p->mvW = mvW; p->mvH = mvH; p->rX = rX; p->rY = rY; p->rAgg = rAgg;
     p->batch = batch; p->device = device;
     p->Sx = 2 * rX + 1; p->Sy = 2 * rY + 1; p->D = (int)D;
-    p->NP = (size_t)W * H; p->N = p->NP * D; p->MV = (size_t)mvW * mvH;
+    p->RS = pyd_row_stride(p->Sx, p->Sy); p->PS = p->Sx * p->RS;
+    p->NP = (size_t)W * H; p->N = p->NP * p->PS; p->MV = (size_t)mvW * mvH;
     const size_t B = batch;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(ptr, bytes); };
@@ -68,9 +72,11 @@ fsgm_status fsgm_pyd_plan_create(fsgm_pyd_plan** out, int32_t W, int32_t H, int3
     alloc((void**)&p->dMv, B * p->MV * 16);
     alloc((void**)&p->dC, B * p->N);
     alloc((void**)&p->dL, B * p->N * 8);
+    if (pyd_rows_layout(p->Sx, p->Sy)) alloc((void**)&p->dDesc, (B * p->NP * 8 + 4) * 4);   // + the dump slot
     alloc((void**)&p->dBestD, B * p->NP * 4);
     alloc((void**)&p->dMinC, B * p->NP * 4);
     alloc((void**)&p->dMvSub, B * p->NP * 16);
+    if (e == hipSuccess) e = hipMemset(p->dC, 0, B * p->N);         // padding bytes of the rows layout stay defined
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -106,9 +112,18 @@ fsgm_status fsgm_pyd_plan_upload_cost(fsgm_pyd_plan* p, int32_t f, const uint8_t
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_HIP(hipSetDevice(p->device));
     int cm = p->cmax;
-    for (size_t i = 0; i < p->N; i++) cm = C[i] > cm ? C[i] : cm;
+    const size_t ND = p->NP * p->D;
+    for (size_t i = 0; i < ND; i++) cm = C[i] > cm ? C[i] : cm;
     p->cmax = cm;
-    FSGM_HIP(hipMemcpyAsync(p->dC + f * p->N, C, p->N, hipMemcpyHostToDevice, p->stream));
+    const uint8_t* src = C;
+    if (p->PS != p->D) {                 // reference order [pixel][sx*Sy+sy] -> padded rows
+        p->stage.assign(p->N, 0);
+        for (size_t px = 0; px < p->NP; px++)
+            for (int sx = 0; sx < p->Sx; sx++)
+                memcpy(&p->stage[px * p->PS + (size_t)sx * p->RS], C + px * p->D + (size_t)sx * p->Sy, p->Sy);
+        src = p->stage.data();
+    }
+    FSGM_HIP(hipMemcpyAsync(p->dC + f * p->N, src, p->N, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
     return FSGM_OK;
 }
@@ -120,23 +135,32 @@ static fsgm_status pyd_enqueue(fsgm_pyd_plan* p, int stages, uint32_t* dS) {
         PydCostArgs a;
         a.cen1 = p->dCen1; a.cen2 = p->dCen2; a.mv = p->dMv; a.C = p->dC;
         a.W = p->W; a.H = p->H; a.mvW = p->mvW; a.mvH = p->mvH; a.rAgg = p->rAgg; a.rX = p->rX; a.rY = p->rY;
+        a.RS = p->RS; a.PS = p->PS;
         launch_pyd_cost(p->stream, a, p->batch);
     }
     PydAggArgs g;
     PydWtaArgs w;
-    g.I1 = p->dI1; g.C = p->dC; g.mv = p->dMv; g.L = p->dL;
+    g.I1 = p->dI1; g.C = p->dC; g.mv = p->dMv; g.L = p->dL; g.desc = p->dDesc; g.dump = p->dDesc ? p->dDesc + (size_t)p->batch * p->NP * 8 : nullptr;
     g.W = p->W; g.H = p->H; g.mvW = p->mvW; g.mvH = p->mvH; g.Sx = p->Sx; g.Sy = p->Sy;
+    g.RS = p->RS; g.PS = p->PS;
     g.P1 = p->P1; g.P2 = p->P2; g.adaptive = p->adaptive;
-    plan_pyd_dirs(g, p->diagonal, p->totalPass, w.weight);
+    // cmax: 24 for volumes built here (census 5x5 Hamming mean; out-of-image taps add 5), else as uploaded
+    const int cm = p->cmax;
+    const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + (p->P1 > p->P2 ? p->P1 : p->P2) <= 255;
+    const bool rows = nowrap && p->dDesc != nullptr;        // row-packed aggregation (pyd_rows.hip)
+    plan_pyd_dirs(g, p->diagonal, p->totalPass, w.weight, rows ? 16 : 4);
     if (stages & FSGM_STAGE_AGGREGATE) {
-        // cmax: 24 for volumes built here (census 5x5 Hamming mean; out-of-image taps add 5), else as uploaded
-        const int cm = p->cmax;
-        const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + (p->P1 > p->P2 ? p->P1 : p->P2) <= 255;
-        launch_pyd_aggregate(p->stream, g, p->batch, !nowrap);
+        if (rows) {
+            launch_pyd_rows_desc(p->stream, g, p->batch);
+            launch_pyd_rows_aggregate(p->stream, g, p->batch);
+        } else {
+            launch_pyd_aggregate(p->stream, g, p->batch, !nowrap);
+        }
     }
     if (stages & FSGM_STAGE_WTA) {
         w.L = p->dL; w.bestD = p->dBestD; w.minC = p->dMinC; w.mvSub = p->dMvSub; w.S = dS;
-        w.W = p->W; w.H = p->H; w.Sx = p->Sx; w.Sy = p->Sy; w.ndirs = g.ndirs; w.subpixel = p->subpixel;
+        w.W = p->W; w.H = p->H; w.Sx = p->Sx; w.Sy = p->Sy; w.RS = p->RS; w.PS = p->PS;
+        w.ndirs = g.ndirs; w.subpixel = p->subpixel;
         launch_pyd_wta(p->stream, w, p->batch);
     }
     FSGM_HIP(hipGetLastError());
@@ -166,7 +190,15 @@ fsgm_status fsgm_pyd_plan_download_cost(fsgm_pyd_plan* p, int32_t f, uint8_t* C)
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_HIP(hipSetDevice(p->device));
     FSGM_HIP(hipStreamSynchronize(p->stream));
-    FSGM_HIP(hipMemcpy(C, p->dC + f * p->N, p->N, hipMemcpyDeviceToHost));
+    if (p->PS == p->D) {
+        FSGM_HIP(hipMemcpy(C, p->dC + f * p->N, p->N, hipMemcpyDeviceToHost));
+        return FSGM_OK;
+    }
+    p->stage.resize(p->N);               // padded rows -> reference order
+    FSGM_HIP(hipMemcpy(p->stage.data(), p->dC + f * p->N, p->N, hipMemcpyDeviceToHost));
+    for (size_t px = 0; px < p->NP; px++)
+        for (int sx = 0; sx < p->Sx; sx++)
+            memcpy(C + px * p->D + (size_t)sx * p->Sy, &p->stage[px * p->PS + (size_t)sx * p->RS], p->Sy);
     return FSGM_OK;
 }
 
@@ -174,11 +206,12 @@ fsgm_status fsgm_pyd_plan_download_sum(fsgm_pyd_plan* p, int32_t f, uint32_t* S)
     FSGM_REQUIRE(p && S, "fsgm_pyd_plan_download_sum: null argument");
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_HIP(hipSetDevice(p->device));
-    if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, (size_t)p->batch * p->N * 4));
+    const size_t ND = p->NP * p->D;
+    if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, (size_t)p->batch * ND * 4));
     fsgm_status st = pyd_enqueue(p, FSGM_STAGE_WTA, p->dS);      // the WTA kernel taps S on its way
     if (st != FSGM_OK) return st;
     FSGM_HIP(hipStreamSynchronize(p->stream));
-    FSGM_HIP(hipMemcpy(S, p->dS + f * p->N, p->N * 4, hipMemcpyDeviceToHost));
+    FSGM_HIP(hipMemcpy(S, p->dS + f * ND, ND * 4, hipMemcpyDeviceToHost));
     return FSGM_OK;
 }
 

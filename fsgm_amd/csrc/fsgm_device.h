@@ -33,6 +33,12 @@ __device__ __forceinline__ int32_t round_to_i32_x86(double v) {
     return ((hi >> 20) & 0x7FFu) >= 1023u + 31u ? INT32_MIN : (int32_t)(n + inc);
 }
 
+// parabola vertex offset as the pyramidal variant writes it (calc_pyd_cost_sgm.cpp:341-344)
+__device__ __forceinline__ double pyd_parabola(double cl, double c0, double cr) {
+    return cr < cl ? __ddiv_rn(__ddiv_rn(__dsub_rn(cr, cl), __dsub_rn(c0, cl)), 2.0)
+                   : __ddiv_rn(__ddiv_rn(__dsub_rn(cr, cl), __dsub_rn(c0, cr)), 2.0);
+}
+
 // ---- packed 2 x u16 arithmetic (VOP3P v_pk_*_u16) ----
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {

@@ -1,8 +1,10 @@
 // pyd_kernels.hip -- gfx950 kernels for the pyramidal 2-D variant
 // (reference: calc_pyd_cost_sgm.cpp; citations per kernel).
 //
-// Cost volume C and per-path costs L_r: u8 [H][W][D], D = Sx*Sy, candidate index
-// d = sx*Sy + sy (x offset is the slow index, calc_pyd_cost_sgm.cpp:392-393).
+// Cost volume C and per-path costs L_r: u8 [H][W][PS]; candidate d = sx*Sy + sy (x offset is the
+// slow index, calc_pyd_cost_sgm.cpp:392-393) sits at byte sx*RS + sy of its pixel.  RS = Sy,
+// PS = D is the reference's own order; the padded "rows" layout (pyd_kernels.h) is what the
+// row-packed kernels of pyd_rows.hip use.  The kernels in this file accept either.
 #include "pyd_kernels.h"
 #include "fsgm_device.h"
 
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void pyd_cost_kernel(PydCostArgs a) {
     }
     const int win = (2 * r + 1) * (2 * r + 1);
     const double v = __dadd_rn(__ddiv_rn(__dmul_rn(1.0, (double)sum), (double)win), 0.5);         // :431
-    a.C[f * (size_t)NP * D + (size_t)p * D + d] = (uint8_t)(uint32_t)f64_to_i32_x86(v);
+    a.C[(f * (size_t)NP + p) * a.PS + (d / Sy) * a.RS + d % Sy] = (uint8_t)(uint32_t)f64_to_i32_x86(v);
 }
 
 // =============================================================================================
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(128) void pyd_cost_patch_kernel(PydCostArgs a) {
                 sum += (u == PYD_OUTSIDE || v == PYD_OUTSIDE) ? 5u : (uint32_t)__popc(u ^ v);      // :406,:419,:427
             }
         const double vv = __dadd_rn(__ddiv_rn(__dmul_rn(1.0, (double)sum), (double)win), 0.5);     // :431
-        a.C[f * (size_t)NP * D + (size_t)p * D + d] = (uint8_t)(uint32_t)f64_to_i32_x86(vv);
+        a.C[(f * (size_t)NP + p) * a.PS + ox * a.RS + oy] = (uint8_t)(uint32_t)f64_to_i32_x86(vv);
     }
 }
 
@@ -186,9 +188,10 @@ __global__ __launch_bounds__(256) void pyd_agg_kernel(PydAggArgs a) {
     const uint32_t ABSENT = 0x7F00;
     for (int i = lane; i < 2 * GN; i += 64) wbase[i] = ABSENT;
     const size_t f = blockIdx.y;
-    const uint8_t* __restrict__ Cf = a.C + f * (size_t)NP * D;
+    const int RS = a.RS, PS = a.PS;
+    const uint8_t* __restrict__ Cf = a.C + f * (size_t)NP * PS;
     const uint8_t* __restrict__ If = a.I1 + f * (size_t)NP;
-    uint8_t* __restrict__ Lf = a.L + (f * a.ndirs + slot) * (size_t)NP * D;
+    uint8_t* __restrict__ Lf = a.L + (f * a.ndirs + slot) * (size_t)NP * PS;
     const double* __restrict__ mvxp = a.mv + f * 2 * (size_t)a.mvW * a.mvH;
     const double* __restrict__ mvyp = mvxp + (size_t)a.mvW * a.mvH;
     // path direction in pass-0 coordinates; the predecessor of p is p - r
@@ -214,11 +217,11 @@ __global__ __launch_bounds__(256) void pyd_agg_kernel(PydAggArgs a) {
     auto fetch = [&](int cx, int cy, Fetch& o) {
         int ax, ay;
         actual(cx, cy, ax, ay);
-        const size_t off = ((size_t)ay * W + ax) * D;
+        const size_t off = ((size_t)ay * W + ax) * PS;
 #pragma unroll
         for (int i = 0; i < NCMAX; i++) {
             const int d = min(lane + 64 * i, D - 1);
-            o.c[i] = Cf[off + d];
+            o.c[i] = Cf[off + (d / Sy) * RS + d % Sy];
         }
         const int px = clampi(mirror ? ax + rx : ax - rx, 0, W - 1), py = clampi(mirror ? ay + ry : ay - ry, 0, H - 1);
         o.dx = __dsub_rn(mvxp[(size_t)ay * a.mvW + ax], mvxp[(size_t)py * a.mvW + px]);   // :213 etc.
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void pyd_agg_kernel(PydAggArgs a) {
         const bool start = is_start(t, x);
         int ax, ay;
         actual(x, y, ax, ay);
-        const size_t off = ((size_t)ay * W + ax) * D;
+        const size_t off = ((size_t)ay * W + ax) * PS;
         uint32_t lo = 255;
         if (start) {
 #pragma unroll
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void pyd_agg_kernel(PydAggArgs a) {
                 if (d < D) {
                     const int sx = d / Sy, sy = d - sx * Sy;
                     cur[cell(sx, sy)] = now.c[i];
-                    Lf[off + d] = (uint8_t)now.c[i];
+                    Lf[off + sx * RS + sy] = (uint8_t)now.c[i];
                 }
             }
             m = 0;                                                               // :182 stored minimum 0
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) void pyd_agg_kernel(PydAggArgs a) {
                     best = min(best, WRAP ? nb : nb + P1);
                     const uint32_t v = (now.c[i] + best - m) & 0xFF;             // :83
                     cur[cell(sx, sy)] = v;
-                    Lf[off + d] = (uint8_t)v;
+                    Lf[off + sx * RS + sy] = (uint8_t)v;
                     lo = min(lo, v);
                 }
             }
@@ -309,10 +312,6 @@ __device__ __forceinline__ uint32_t pyd_sum_at(const PydWtaArgs& a, const uint8_
     return s;
 }
 
-__device__ __forceinline__ double parabola(double cl, double c0, double cr) {
-    return cr < cl ? __ddiv_rn(__ddiv_rn(__dsub_rn(cr, cl), __dsub_rn(c0, cl)), 2.0)
-                   : __ddiv_rn(__ddiv_rn(__dsub_rn(cr, cl), __dsub_rn(c0, cr)), 2.0);
-}
 
 __global__ __launch_bounds__(256) void pyd_wta_kernel(PydWtaArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -320,12 +319,13 @@ __global__ __launch_bounds__(256) void pyd_wta_kernel(PydWtaArgs a) {
     const int p = blockIdx.x * 4 + wave;
     if (p >= NP) return;
     const size_t f = blockIdx.y;
-    const size_t vol = (size_t)NP * D;
+    const size_t vol = (size_t)NP * a.PS;
     const uint8_t* __restrict__ Lf = a.L + f * a.ndirs * vol;
+    auto at = [&](uint32_t d) { return (size_t)p * a.PS + (d / Sy) * a.RS + d % Sy; };
     uint32_t lo = 0xFFFFFFFFu, idx = 0xFFFFFFFFu;
     for (int d = lane; d < D; d += 64) {
-        const uint32_t s = pyd_sum_at(a, Lf, vol, (size_t)p * D + d);
-        if (a.S) a.S[f * vol + (size_t)p * D + d] = s;
+        const uint32_t s = pyd_sum_at(a, Lf, vol, at(d));
+        if (a.S) a.S[(f * NP + p) * D + d] = s;
         if (s < lo) { lo = s; idx = d; }                     // ascending d per lane: first minimum
     }
     uint32_t glo = lo;
@@ -341,11 +341,10 @@ __global__ __launch_bounds__(256) void pyd_wta_kernel(PydWtaArgs a) {
         if (a.subpixel) {
             const double c0 = (double)glo;
             const int dx = gidx / Sy, dy = gidx % Sy;                            // :333-334
-            const size_t b = (size_t)p * D + gidx;
             if (dy > 0 && dy < Sy - 1)
-                suby = parabola((double)pyd_sum_at(a, Lf, vol, b - 1), c0, (double)pyd_sum_at(a, Lf, vol, b + 1));
+                suby = pyd_parabola((double)pyd_sum_at(a, Lf, vol, at(gidx - 1)), c0, (double)pyd_sum_at(a, Lf, vol, at(gidx + 1)));
             if (dx > 0 && dx < Sx - 1)
-                subx = parabola((double)pyd_sum_at(a, Lf, vol, b - Sy), c0, (double)pyd_sum_at(a, Lf, vol, b + Sy));
+                subx = pyd_parabola((double)pyd_sum_at(a, Lf, vol, at(gidx - Sy)), c0, (double)pyd_sum_at(a, Lf, vol, at(gidx + Sy)));
         }
         a.mvSub[f * 2 * (size_t)NP + p] = subx;              // zero when subpixel is off (:476 zero-init output)
         a.mvSub[f * 2 * (size_t)NP + NP + p] = suby;
@@ -356,6 +355,7 @@ __global__ __launch_bounds__(256) void pyd_wta_kernel(PydWtaArgs a) {
 // launchers
 // =============================================================================================
 void launch_pyd_cost(hipStream_t st, const PydCostArgs& a, int frames) {
+    if (pyd_rows_cost_ok(a)) { launch_pyd_rows_cost(st, a, frames); return; }
     const long long n = (long long)a.W * a.H * (2 * a.rX + 1) * (2 * a.rY + 1);
     const int PX = 2 * a.rX + 1 + 2 * a.rAgg, PY = 2 * a.rY + 1 + 2 * a.rAgg, AW = 2 * a.rAgg + 1;
     const size_t lds = (size_t)(PX * PY + AW * AW + PX + PY) * 4;
@@ -367,7 +367,7 @@ void launch_pyd_cost(hipStream_t st, const PydCostArgs& a, int frames) {
     hipLaunchKernelGGL(pyd_cost_kernel, grid, dim3(256), 0, st, a);
 }
 
-int plan_pyd_dirs(PydAggArgs& a, int diagonal, int totalPass, uint32_t weight[8]) {
+int plan_pyd_dirs(PydAggArgs& a, int diagonal, int totalPass, uint32_t weight[8], int lines_per_block) {
     // pass 0: along x, along y, (+1,+1), (-1,+1); later passes: their point mirrors, all identical
     // (calc_pyd_cost_sgm.cpp:142-151 sets the mirrored start/step once at pass==1)
     static const int fwd[4] = {0, 1, 2, 3};
@@ -378,7 +378,7 @@ int plan_pyd_dirs(PydAggArgs& a, int diagonal, int totalPass, uint32_t weight[8]
         a.blk_begin[n] = acc;
         weight[n] = w;
         const int nlines = (code & 3) == 0 ? a.H : a.W;
-        acc += (nlines + 3) / 4;
+        acc += (nlines + lines_per_block - 1) / lines_per_block;
         n++;
     };
     if (totalPass >= 1) for (int k = 0; k < nd; k++) add(fwd[k], 1u);
@@ -407,6 +407,7 @@ void launch_pyd_aggregate(hipStream_t st, const PydAggArgs& a, int frames, bool 
 }
 
 void launch_pyd_wta(hipStream_t st, const PydWtaArgs& a, int frames) {
+    if (pyd_rows_wta_ok(a)) { launch_pyd_rows_wta(st, a, frames); return; }
     dim3 grid((a.W * a.H + 3) / 4, frames);
     hipLaunchKernelGGL(pyd_wta_kernel, grid, dim3(256), 0, st, a);
 }

@@ -1,0 +1,584 @@
+// pyd_rows.hip -- row-packed gfx950 kernels for the pyramidal 2-D variant
+// (reference: calc_pyd_cost_sgm.cpp; citations per kernel).  Same results as the generic kernels
+// of pyd_kernels.hip; used for search windows up to 11 x 11 (the reference's, pyramidal_sgm.m:17-19)
+// and penalties in the no-wrap range.
+//
+// Layout ("rows", pyd_kernels.h): a pixel's candidates are Sx rows of RS = 4*NW bytes (Sy costs +
+// padding), PS = Sx*RS bytes per pixel.  16 adjacent lanes (one DPP row) own one pixel, lane j the
+// candidate row sx = j (cost, WTA) or sx = j-2 (aggregation); a wave works on 4 pixels / 4 path
+// lines at a time, every lane moves its row as NW dwords.
+#include "pyd_kernels.h"
+#include "fsgm_device.h"
+
+namespace fsgm {
+
+constexpr int ROWS_MAXS = 11;           // largest window side of the rows layout
+constexpr uint32_t ROWS_OUTSIDE = 0xFFFFFFFFu;   // a census code never has bit 0 set (common.cpp:21)
+
+constexpr int DPP_ROW_SHL2 = 0x102;     // lane i <- lane i+2 (within a row of 16)
+constexpr int DPP_ROW_SHR2 = 0x112;     // lane i <- lane i-2
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
+    u16x2 r = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c);
+    return __builtin_bit_cast(uint32_t, r);
+}
+// per half: 0xFFFF where idx < n, else 0   (idx2, n2 packed small non-negative values)
+__device__ __forceinline__ uint32_t pk_lt_mask(uint32_t idx2, uint32_t n2) {
+    i16x2 d = __builtin_bit_cast(i16x2, pk_sub(idx2, n2));
+    d = d >> 15;
+    return __builtin_bit_cast(uint32_t, d);
+}
+// (m & a) | (~m & b) as one v_bfi_b32; the empty asm keeps the mask a plain register (otherwise the
+// compiler turns the selects back into compares on the halves)
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
+__device__ __forceinline__ uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+// DPP row shift whose out-of-row lanes read 0: for results that are only used in lanes whose source
+// lies inside the row (no register initialisation needed, unlike dpp_mov)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_shift0(uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t dup16(uint32_t v) { return v | (v << 16); }
+
+// =============================================================================================
+// 2-D window cost  (calc_pyd_cost_sgm.cpp:374-437), aggregation radius <= 2.
+// The sample column depends on offx+ax only and the sample row on offy+ay only (:415-416), so the
+// (Sx+2r) x (Sy+2r) patch of image-2 census codes that all candidates and taps of a pixel touch is
+// staged in LDS once; lane ox then walks its Sy candidates with the patch column in registers:
+// (2r+1) x (Sy+2r) LDS reads per (2r+1)^2 x Sy taps, two VALU instructions per tap.  A wave whose
+// 4 pixels have a tap outside either image (constant cost 5, USE_CONST_COST :32,405-421) takes the
+// compare-and-select form of the same loop.
+// =============================================================================================
+constexpr int COST_PM = ROWS_MAXS + 4;                   // max patch side
+constexpr int COST_SLOT_DW = COST_PM * COST_PM + 25 + 2 * 16;   // patch, image-1 taps, column/row tables
+
+template <int NW>
+__global__ __launch_bounds__(256) void pyd_rows_cost_kernel(PydCostArgs a) {
+    __shared__ uint32_t sCost[4 * 4 * COST_SLOT_DW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, slot = lane >> 4;
+    const int W = a.W, H = a.H, r = a.rAgg;
+    const int NP = W * H;
+    const int Sx = 2 * a.rX + 1, Sy = 2 * a.rY + 1;
+    const int PX = Sx + 2 * r, PY = Sy + 2 * r, AW = 2 * r + 1;
+    uint32_t* const patch = sCost + (wave * 4 + slot) * COST_SLOT_DW;   // [PY][PX]
+    uint32_t* const c1s = patch + COST_PM * COST_PM;                    // [AW][AW]
+    int* const x2tab = (int*)(c1s + 25);                                // [PX]
+    int* const y2tab = x2tab + 16;                                      // [PY]
+    int p = (blockIdx.x * 4 + wave) * 4 + slot;
+    const bool active = p < NP;
+    p = min(p, NP - 1);
+    const int y = p / W, x = p - y * W;
+    const size_t f = blockIdx.y;
+    const double* mvxp = a.mv + f * 2 * (size_t)a.mvW * a.mvH;
+    const double* mvyp = mvxp + (size_t)a.mvW * a.mvH;
+    const double mvx = mvxp[(size_t)a.mvW * y + x], mvy = mvyp[(size_t)a.mvW * y + x];   // :388-389
+    const uint32_t* __restrict__ cen1 = a.cen1 + f * (size_t)NP;
+    const uint32_t* __restrict__ cen2 = a.cen2 + f * (size_t)NP;
+    bool outside = false;
+    if (j < PX) {                                        // k = (offx + rX) + (ax + r)  ->  offx + x1 = x + k - rX - r
+        const int x2 = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)(x + j - a.rX - r), mvx), 0.5));   // :416
+        x2tab[j] = (x2 >= 0 && x2 <= W - 1) ? x2 : -1;
+    }
+    if (j < PY) {
+        const int y2 = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)(y + j - a.rY - r), mvy), 0.5));   // :415
+        y2tab[j] = (y2 >= 0 && y2 <= H - 1) ? y2 : -1;
+    }
+    for (int k = j; k < AW * AW; k += 16) {
+        const int y1 = y + k / AW - r, x1 = x + k % AW - r;
+        const bool in = y1 >= 0 && y1 <= H - 1 && x1 >= 0 && x1 <= W - 1;                            // :405
+        c1s[k] = in ? cen1[(size_t)W * (in ? y1 : 0) + (in ? x1 : 0)] : ROWS_OUTSIDE;
+        outside |= !in;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = j; k < PX * PY; k += 16) {
+        const int ky = k / PX, kx = k - ky * PX;
+        const int y2 = y2tab[ky], x2 = x2tab[kx];
+        const bool in = y2 >= 0 && x2 >= 0;                                                          // :418
+        patch[k] = in ? cen2[(size_t)W * (in ? y2 : 0) + (in ? x2 : 0)] : ROWS_OUTSIDE;
+        outside |= !in;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool any_outside = __builtin_amdgcn_ballot_w64(outside) != 0;       // wave-uniform
+    const int ox = min(j, Sx - 1);
+    uint32_t sum[4 * NW];
+#pragma unroll
+    for (int i = 0; i < 4 * NW; i++) sum[i] = 0;
+#pragma unroll
+    for (int ax = 0; ax < 5; ax++) {
+        if (ax >= AW) continue;
+        uint32_t pc[4 * NW + 4];                           // patch column ox+ax, rows 0 .. Sy+2r-1
+#pragma unroll
+        for (int q = 0; q < 4 * NW + 4; q++) pc[q] = q < PY ? patch[q * PX + ox + ax] : 0u;
+#pragma unroll
+        for (int ay = 0; ay < 5; ay++) {
+            if (ay >= AW) continue;
+            const uint32_t u = c1s[ay * AW + ax];
+            if (!any_outside) {
+#pragma unroll
+                for (int oy = 0; oy < 4 * NW; oy++) sum[oy] += __popc(u ^ pc[oy + ay]);              // :427
+            } else {
+#pragma unroll
+                for (int oy = 0; oy < 4 * NW; oy++) {
+                    const uint32_t v = pc[oy + ay];
+                    sum[oy] += (u == ROWS_OUTSIDE || v == ROWS_OUTSIDE) ? 5u : (uint32_t)__popc(u ^ v);   // :406,:419
+                }
+            }
+        }
+    }
+    const double win = (double)(AW * AW);
+    uint32_t out[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int oy = 4 * k + b;
+            const double vv = __dadd_rn(__ddiv_rn(__dmul_rn(1.0, (double)sum[oy]), win), 0.5);       // :431
+            const uint32_t c = oy < Sy ? ((uint32_t)f64_to_i32_x86(vv) & 0xFFu) : 0u;
+            w |= c << (8 * b);
+        }
+        out[k] = w;
+    }
+    if (active && j < Sx) {
+        uint32_t* dst = (uint32_t*)(a.C + (f * (size_t)NP + p) * a.PS + (size_t)j * a.RS);
+#pragma unroll
+        for (int k = 0; k < NW; k++) dst[k] = out[k];
+    }
+}
+
+// =============================================================================================
+// Per-step descriptors of the aggregation kernel: everything sgm_step derives from the hint map
+// and the image rather than from the path state (calc_pyd_cost_sgm.cpp:46-47 hint shift, :91-95
+// adaptive P2, :182 etc. path start).
+//
+// The shifted centre of candidate row sx is xpre = (int)(sx + dx + 0.5), a C truncation (:47):
+// floor for non-negative arguments, ceil for negative ones.  Hence xpre(sx) = sx + kf + [sx < na]
+// for some kf and a prefix length na -- two shift regimes -- for every real hint delta.  The
+// descriptor stores (kf, na) per axis and a flag saying the table really has that form (checked
+// entry by entry against the reference expression; entries whose 5x5 neighbourhood lies wholly
+// outside the window may differ).  Steps without the flag take the aggregation kernel's gather path.
+//   bits 0-5 kfx+16 | 6-9 nax | 10-15 kfy+16 | 16-19 nay | 20-27 P2 | 28 path start | 29 model ok
+// =============================================================================================
+constexpr uint32_t DESC_START = 1u << 28, DESC_OK = 1u << 29;
+
+__device__ __forceinline__ bool absent_centre(int c, int S) { return c <= -3 || c >= S + 2; }
+
+__device__ bool fit_shift(double delta, int S, int& kf, int& na) {
+    int t[ROWS_MAXS];
+    int jstar = -1, tstar = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS_MAXS; j++) {
+        t[j] = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)j, delta), 0.5));
+        if (j < S && !absent_centre(t[j], S)) { jstar = j; tstar = t[j]; }
+    }
+    if (jstar < 0) { kf = S + 3; na = 0; return true; }      // every neighbourhood lies outside the window
+    kf = tstar - jstar;
+    na = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS_MAXS; j++)
+        if (j < jstar && t[j] != j + kf) na = j + 1;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < ROWS_MAXS; j++)
+        if (j < S) {
+            const int model = j + kf + (j < na ? 1 : 0);
+            ok = ok && (t[j] == model || (absent_centre(t[j], S) && absent_centre(model, S)));
+        }
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void pyd_rows_desc_kernel(PydAggArgs a) {
+    const int W = a.W, H = a.H, NP = W * H;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= NP) return;
+    const int slot = blockIdx.y;
+    const size_t f = blockIdx.z;
+    const int code = a.dir_code[slot], base = code & 3;
+    const bool mirror = (code & 4) != 0;
+    const int rx = base == 1 ? 0 : (base == 3 ? -1 : 1), ry = base == 0 ? 0 : 1;
+    const int ay = p / W, ax = p - ay * W;
+    const int px = mirror ? ax + rx : ax - rx, py = mirror ? ay + ry : ay - ry;   // path predecessor
+    uint32_t d;
+    if (px < 0 || px >= W || py < 0 || py >= H) {
+        d = DESC_START | DESC_OK | (16u) | (16u << 10);
+    } else {
+        const double* mvxp = a.mv + f * 2 * (size_t)a.mvW * a.mvH;
+        const double* mvyp = mvxp + (size_t)a.mvW * a.mvH;
+        const double dx = __dsub_rn(mvxp[(size_t)ay * a.mvW + ax], mvxp[(size_t)py * a.mvW + px]);   // :213 etc.
+        const double dy = __dsub_rn(mvyp[(size_t)ay * a.mvW + ax], mvyp[(size_t)py * a.mvW + px]);
+        const uint8_t* If = a.I1 + f * (size_t)NP;
+        const int dI = abs((int)If[(size_t)W * ay + ax] - (int)If[(size_t)W * py + px]);
+        const int P2 = (a.adaptive && dI > 50) ? a.P2 / 8 : a.P2;                                    // :91-95
+        int kfx, nax, kfy, nay;
+        const bool okx = fit_shift(dx, a.Sx, kfx, nax);
+        const bool oky = fit_shift(dy, a.Sy, kfy, nay);
+        d = (uint32_t)(kfx + 16) | ((uint32_t)nax << 6) | ((uint32_t)(kfy + 16) << 10) | ((uint32_t)nay << 16) |
+            ((uint32_t)P2 << 20) | ((okx && oky) ? DESC_OK : 0u);
+    }
+    a.desc[(f * a.ndirs + slot) * (size_t)NP + p] = d;
+}
+
+// =============================================================================================
+// 2-D path aggregation  (calc_pyd_cost_sgm.cpp:34-89 sgm_step, :114-296 sgm2d), no-wrap penalties
+// (0 <= P1,P2, max C + P2 + max(P1,P2) <= 255: no u8 narrowing changes a value, so the centre cell
+// may take part in the "+P1" minimum and a cell outside the window is just 255).
+//
+// A wave advances 4 path lines (one per DPP row of 16 lanes) by one pixel per step.  The previous
+// pixel's path costs sit in LDS as bytes, one 52-byte row per candidate row with the Sy costs at
+// byte 16 and 0xFF around them (row 15 is all 0xFF).  Lane j reads row (j-2)+kfx at byte offset
+// kfy-2 -- the hint shift (:46-47) folded into the address -- as NW+2 dwords, realigns them with
+// v_alignbyte, and takes the 5-wide minimum along sy in packed u16 registers (even/odd split, as in
+// the 1-D kernels); the 5-wide minimum along sx is 4 DPP row shifts.  The second shift regime of a
+// truncating conversion (pyd_rows_desc_kernel) is a per-element select along sy and a one-lane DPP
+// shift along sx.  Steps whose shift table is irregular gather the 5x5 cells byte by byte.
+// =============================================================================================
+constexpr int ROWB = 52;                // bytes per LDS row (13 dwords: odd stride)
+constexpr int ROWDATA = 16;             // byte of sy = 0
+constexpr int ABSROW = 15;              // the all-0xFF row
+constexpr int ROWS_WAVE_BYTES = 2 * 4 * 16 * ROWB + 4 * 32 * 4;    // two buffers of 4 x 16 rows + gather tables
+
+template <int NW>
+__global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
+    extern __shared__ uint32_t sRows[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, slot4 = lane >> 4;
+    int slot = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++)
+        if (i < a.ndirs && (int)blockIdx.x >= a.blk_begin[i]) slot = i;
+    const int code = a.dir_code[slot];
+    const int base = code & 3;
+    const bool mirror = (code & 4) != 0;
+    const int W = a.W, H = a.H, Sx = a.Sx, Sy = a.Sy, RS = a.RS, PS = a.PS;
+    const int NP = W * H;
+    const int nlines = base == 0 ? H : W;
+    const int len = base == 0 ? W : H;
+    int line = ((int)blockIdx.x - a.blk_begin[slot]) * 16 + wave * 4 + slot4;
+    const bool active = line < nlines;
+    line = min(line, nlines - 1);
+    uint8_t* const wbase = (uint8_t*)sRows + (size_t)wave * ROWS_WAVE_BYTES;
+    for (int i = lane; i < 2 * 4 * 16 * ROWB / 4; i += 64) ((uint32_t*)wbase)[i] = 0xFFFFFFFFu;
+    uint8_t* pre = wbase + slot4 * 16 * ROWB;
+    uint8_t* cur = pre + 4 * 16 * ROWB;
+    int32_t* const tabs = (int32_t*)(wbase + 2 * 4 * 16 * ROWB) + slot4 * 32;   // gather path: xtab[16], ytab[16]
+    const size_t f = blockIdx.y;
+    const uint8_t* __restrict__ Cf = a.C + f * (size_t)NP * PS;
+    uint8_t* __restrict__ Lf = a.L + (f * a.ndirs + slot) * (size_t)NP * PS;
+    const uint32_t* __restrict__ Df = a.desc + (f * a.ndirs + slot) * (size_t)NP;
+    const int rx = base == 1 ? 0 : (base == 3 ? -1 : 1), ry = base == 0 ? 0 : 1;
+    const int sx = j - 2;                                    // candidate row this lane produces
+    const bool is_out = sx >= 0 && sx < Sx;
+    const int sxc = clampi(sx, 0, Sx - 1);
+    // padding slots (sy >= Sy) carry 0x00FF so that the row written back reads as "outside"; lanes
+    // that produce no row carry all ones so that they never win the minimum
+    uint32_t padE[NW], padO[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        padE[k] = is_out ? ((4 * k >= Sy ? 0x00FFu : 0u) | (4 * k + 2 >= Sy ? 0x00FF0000u : 0u)) : 0xFFFFFFFFu;
+        padO[k] = is_out ? ((4 * k + 1 >= Sy ? 0x00FFu : 0u) | (4 * k + 3 >= Sy ? 0x00FF0000u : 0u)) : 0xFFFFFFFFu;
+    }
+    const uint32_t P1_2 = dup16((uint32_t)a.P1);
+
+    // cursor in the pass-0 frame
+    int x = base == 0 ? 0 : line, y = base == 0 ? line : 0;
+    auto actual = [&](int cx, int cy, int& ax, int& ay) { ax = mirror ? W - 1 - cx : cx; ay = mirror ? H - 1 - cy : cy; };
+    auto advance = [&](int& cx, int& cy) {
+        if (base == 0) cx++;
+        else {
+            cy++;
+            if (base == 2) { cx++; if (cx == W) cx = 0; }
+            if (base == 3) { cx--; if (cx < 0) cx = W - 1; }
+        }
+    };
+    struct Fetch { uint32_t c[NW]; uint32_t desc; };
+    auto fetch = [&](int cx, int cy, Fetch& o) {
+        int ax, ay;
+        actual(cx, cy, ax, ay);
+        const size_t pix = (size_t)ay * W + ax;
+        const uint32_t* src = (const uint32_t*)(Cf + pix * PS + (size_t)sxc * RS);
+#pragma unroll
+        for (int k = 0; k < NW; k++) o.c[k] = src[k];
+        o.desc = Df[pix];
+    };
+
+    Fetch nxt;
+    fetch(x, y, nxt);
+    int xn = x, yn = y;
+    advance(xn, yn);
+    uint32_t m = 0;
+    // the first fetch lands before the loop: otherwise the loop header's wait has to cover it on every
+    // iteration and, counted from there, ends up waiting for the previous step's store as well
+    nxt.desc = opaque(nxt.desc);
+#pragma unroll
+    for (int k = 0; k < NW; k++) nxt.c[k] = opaque(nxt.c[k]);
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < len; t++) {
+        const Fetch now = nxt;
+        {                                                    // in flight while this step computes
+            const bool last = t + 1 >= len;
+            fetch(last ? x : xn, last ? y : yn, nxt);
+        }
+        const uint32_t d = now.desc;
+        const bool start = (d & DESC_START) != 0;
+        const int kfx = (int)(d & 63u) - 16, nax = (int)((d >> 6) & 15u);
+        const int kfy = (int)((d >> 10) & 63u) - 16, nay = (int)((d >> 16) & 15u);
+        const uint32_t P2 = (d >> 20) & 255u;
+        uint32_t ME[NW], MO[NW], CE[NW], CO[NW];            // 5x5 minimum / centre value per sy (even, odd sy)
+        const bool gather = __builtin_amdgcn_ballot_w64((d & DESC_OK) == 0) != 0;
+        if (!gather) {
+            const int R = sx + kfx;
+            const int rsel = (R >= 0 && R < Sx) ? R : ABSROW;
+            const int b0 = ROWDATA - 2 + kfy;
+            const uint32_t* qp = (const uint32_t*)(pre + rsel * ROWB + (b0 & ~3));
+            uint32_t q[NW + 2];
+#pragma unroll
+            for (int i = 0; i < NW + 2; i++) q[i] = qp[i];
+            const uint32_t sh = (uint32_t)b0 & 3u;
+            uint32_t E[NW + 1], O[NW + 1];                  // v[i] = Lpre(R, kfy-2+i): E[k] = (v[4k], v[4k+2]), O[k] = (v[4k+1], v[4k+3])
+#pragma unroll
+            for (int k = 0; k <= NW; k++) {
+                const uint32_t w = __builtin_amdgcn_alignbyte(q[k + 1], q[k], sh);
+                E[k] = w & 0x00FF00FFu;
+                O[k] = (w >> 8) & 0x00FF00FFu;
+            }
+            uint32_t A[NW + 1], B[NW + 1], Es[NW], Os[NW];  // pair minima a2[i] = min(v[i], v[i+1]); shifted views
+#pragma unroll
+            for (int k = 0; k <= NW; k++) A[k] = pk_min(E[k], O[k]);
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                Es[k] = align16(E[k + 1], E[k]);            // (v[4k+2], v[4k+4])
+                Os[k] = align16(O[k + 1], O[k]);            // (v[4k+3], v[4k+5])
+                B[k] = pk_min(O[k], Es[k]);
+            }
+            B[NW] = pk_min(O[NW], align16(E[NW], E[NW]));   // only its low half is used
+            uint32_t A5[NW], B5[NW];                        // a5[i] = min(v[i .. i+4]) at even / odd i
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                A5[k] = pk_min(pk_min(A[k], align16(A[k + 1], A[k])), E[k + 1]);
+                B5[k] = pk_min(pk_min(B[k], align16(B[k + 1], B[k])), O[k + 1]);
+            }
+            // regime B: centre sy + kfy -> window v[sy .. sy+4], centre v[sy+2]
+#pragma unroll
+            for (int k = 0; k < NW; k++) { ME[k] = A5[k]; MO[k] = B5[k]; CE[k] = Es[k]; CO[k] = Os[k]; }
+            if (__builtin_amdgcn_ballot_w64(nay != 0) != 0) {
+                // regime A (sy < nay): centre one further, window v[sy+1 .. sy+5], centre v[sy+3]
+                const uint32_t n2 = dup16((uint32_t)nay);
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    const uint32_t mE = opaque(pk_lt_mask((uint32_t)(4 * k) | ((uint32_t)(4 * k + 2) << 16), n2));
+                    const uint32_t mO = opaque(pk_lt_mask((uint32_t)(4 * k + 1) | ((uint32_t)(4 * k + 3) << 16), n2));
+                    const uint32_t A5s = align16(A5[k + 1 < NW ? k + 1 : k], A5[k]);   // (a5[4k+2], a5[4k+4]); the last high half is never used
+                    ME[k] = bfi(mE, B5[k], A5[k]);
+                    MO[k] = bfi(mO, A5s, B5[k]);
+                    CE[k] = bfi(mE, Os[k], Es[k]);
+                    CO[k] = bfi(mO, E[k + 1], Os[k]);
+                }
+            }
+            // 5-wide minimum along sx: lanes j-2 .. j+2 hold rows R-2 .. R+2.  Only lanes 2 .. 13 are
+            // consumed (producing lanes 2 .. Sx+1 <= 12, plus one for the second regime), and all their
+            // sources lie inside the DPP row.
+#pragma unroll
+            for (int k = 0; k < 2 * NW; k++) {
+                const uint32_t v = k < NW ? ME[k] : MO[k - NW];
+                const uint32_t t1 = dpp_shift0<DPP_ROW_SHR1>(v), t2 = dpp_shift0<DPP_ROW_SHL1>(v);
+                const uint32_t t3 = dpp_shift0<DPP_ROW_SHR2>(v), t4 = dpp_shift0<DPP_ROW_SHL2>(v);
+                const uint32_t h = pk_min(pk_min(v, t1), pk_min(pk_min(t2, t3), t4));
+                if (k < NW) ME[k] = h; else MO[k - NW] = h;
+            }
+            if (__builtin_amdgcn_ballot_w64(nax != 0) != 0) {
+                const bool regA = sx < nax;                  // centre row one further: take lane j+1's values
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    const uint32_t a1 = dpp_shift0<DPP_ROW_SHL1>(ME[k]), a2 = dpp_shift0<DPP_ROW_SHL1>(MO[k]);
+                    const uint32_t a3 = dpp_shift0<DPP_ROW_SHL1>(CE[k]), a4 = dpp_shift0<DPP_ROW_SHL1>(CO[k]);
+                    ME[k] = regA ? a1 : ME[k];
+                    MO[k] = regA ? a2 : MO[k];
+                    CE[k] = regA ? a3 : CE[k];
+                    CO[k] = regA ? a4 : CO[k];
+                }
+            }
+        } else {
+            // gather path: the reference's tables (:46-47), 25 cells per candidate
+            int ax, ay;
+            actual(x, y, ax, ay);
+            const int px = clampi(mirror ? ax + rx : ax - rx, 0, W - 1), py = clampi(mirror ? ay + ry : ay - ry, 0, H - 1);
+            const double* __restrict__ mvxp = a.mv + f * 2 * (size_t)a.mvW * a.mvH;
+            const double* __restrict__ mvyp = mvxp + (size_t)a.mvW * a.mvH;
+            const double dx = __dsub_rn(mvxp[(size_t)ay * a.mvW + ax], mvxp[(size_t)py * a.mvW + px]);
+            const double dy = __dsub_rn(mvyp[(size_t)ay * a.mvW + ax], mvyp[(size_t)py * a.mvW + px]);
+            tabs[j] = clampi(f64_to_i32_x86(__dadd_rn(__dadd_rn((double)j, dx), 0.5)), -3, Sx + 2);        // :47
+            tabs[16 + j] = clampi(f64_to_i32_x86(__dadd_rn(__dadd_rn((double)j, dy), 0.5)), -3, Sy + 2);   // :46
+            __builtin_amdgcn_wave_barrier();
+            const int cx = tabs[sxc];
+            auto rowp = [&](int tx) { return pre + ((tx >= 0 && tx < Sx) ? tx : ABSROW) * ROWB + ROWDATA; };
+#pragma unroll
+            for (int k = 0; k < NW; k++) { ME[k] = MO[k] = CE[k] = CO[k] = 0x00FF00FFu; }
+#pragma unroll
+            for (int s = 0; s < 4 * NW; s++) {
+                uint32_t ctr = 255, nb = 255;
+                if (s < Sy) {
+                    const int cy = tabs[16 + s];
+                    ctr = rowp(cx)[cy];
+#pragma unroll 1
+                    for (int mm = -2; mm <= 2; mm++) {
+                        const uint8_t* rp = rowp(cx + mm) + cy;
+                        nb = min(nb, min(min((uint32_t)rp[-2], (uint32_t)rp[-1]), min(min((uint32_t)rp[0], (uint32_t)rp[1]), (uint32_t)rp[2])));
+                    }
+                }
+                const int k = s >> 2;
+                const uint32_t shv = (s & 2) ? 16 : 0, keep = (s & 2) ? 0x0000FFFFu : 0xFFFF0000u;
+                if (s & 1) { MO[k] = (MO[k] & keep) | (nb << shv); CO[k] = (CO[k] & keep) | (ctr << shv); }
+                else       { ME[k] = (ME[k] & keep) | (nb << shv); CE[k] = (CE[k] & keep) | (ctr << shv); }
+            }
+        }
+        // best = min(m + P2, centre, 5x5 minimum + P1) (:50-80); L = C + best - m (:83)
+        const uint32_t jump2 = dup16(m + P2), m2 = dup16(m);
+        uint32_t LE[NW], LO[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const uint32_t cE = now.c[k] & 0x00FF00FFu, cO = (now.c[k] >> 8) & 0x00FF00FFu;
+            const uint32_t bE = pk_min(pk_min(jump2, CE[k]), pk_add(ME[k], P1_2));
+            const uint32_t bO = pk_min(pk_min(jump2, CO[k]), pk_add(MO[k], P1_2));
+            const uint32_t lE = pk_sub(pk_add(cE, bE), m2), lO = pk_sub(pk_add(cO, bO), m2);
+            LE[k] = (start ? cE : lE) | padE[k];                                 // path start: L = C (:153 etc.)
+            LO[k] = (start ? cO : lO) | padO[k];
+        }
+        uint32_t rmin = pk_min(LE[0], LO[0]);
+#pragma unroll
+        for (int k = 1; k < NW; k++) rmin = pk_min(rmin, pk_min(LE[k], LO[k]));
+        uint32_t lo = min(rmin & 0xFFFFu, rmin >> 16);
+        lo = group_min_u32<16>(lo);
+        m = start ? 0u : lo;                                                     // :88; stored minimum 0 at a start (:154)
+        {
+            // Straight-line stores: lanes that produce no row write LDS row 14 (never read) and a dump
+            // slot in HBM.  With one store per step at a fixed place in the instruction stream the
+            // wait for the prefetched loads is a counted s_waitcnt vmcnt(1), not a wait for the store.
+            int ax, ay;
+            actual(x, y, ax, ay);
+            uint32_t* dl = (uint32_t*)(cur + (is_out ? sx : 14) * ROWB + ROWDATA);
+            uint32_t* dg = (is_out && active) ? (uint32_t*)(Lf + ((size_t)ay * W + ax) * PS + (size_t)sx * RS) : a.dump;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const uint32_t w = LE[k] | (LO[k] << 8);
+                dl[k] = w;
+                dg[k] = w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint8_t* tmp = pre; pre = cur; cur = tmp;
+        x = xn; y = yn;
+        advance(xn, yn);
+    }
+}
+
+// =============================================================================================
+// WTA + y/x parabola  (calc_pyd_cost_sgm.cpp:298-364).  4 pixels per wave; lane j sums the path
+// costs of candidate row j in packed u16 (weights: a third pass repeats the mirrored one), the
+// first minimum in candidate order is the minimum of (sum << 8 | index) keys.
+// =============================================================================================
+template <int NW>
+__global__ __launch_bounds__(256) void pyd_rows_wta_kernel(PydWtaArgs a) {
+    __shared__ uint16_t sSum[4][4][16][4 * NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, slot4 = lane >> 4;
+    const int NP = a.W * a.H, Sy = a.Sy, Sx = a.Sx, D = Sx * Sy;
+    int p = (blockIdx.x * 4 + wave) * 4 + slot4;
+    const bool active = p < NP;
+    p = min(p, NP - 1);
+    const size_t f = blockIdx.y;
+    const size_t vol = (size_t)NP * a.PS;
+    const int sxc = min(j, Sx - 1);
+    const uint8_t* __restrict__ Lp = a.L + f * a.ndirs * vol + (size_t)p * a.PS + (size_t)sxc * a.RS;
+    uint32_t v[8][NW];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int k = 0; k < NW; k++) v[r][k] = r < a.ndirs ? ((const uint32_t*)(Lp + r * vol))[k] : 0u;
+    uint32_t SE[NW], SO[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) { SE[k] = 0; SO[k] = 0; }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t w2 = dup16(a.weight[r]);
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            SE[k] = pk_mad(v[r][k] & 0x00FF00FFu, w2, SE[k]);                    // :227-232 Sp += L
+            SO[k] = pk_mad((v[r][k] >> 8) & 0x00FF00FFu, w2, SO[k]);
+        }
+    }
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int s = 0; s < 4 * NW; s++) {
+        const uint32_t reg = (s & 1) ? SO[s >> 2] : SE[s >> 2];
+        const uint32_t val = (s & 2) ? reg >> 16 : reg & 0xFFFFu;
+        sSum[wave][slot4][j][s] = (uint16_t)val;
+        if (s < Sy && j < Sx) {
+            key = min(key, (val << 8) | (uint32_t)(j * Sy + s));                 // :302-311 first strict minimum
+            if (a.S && active) a.S[(f * NP + p) * (size_t)D + j * Sy + s] = val;
+        }
+    }
+    key = group_min_u32<16>(key);
+    __builtin_amdgcn_wave_barrier();
+    if (j == 0 && active) {
+        const uint32_t gidx = key & 0xFFu, glo = key >> 8;
+        a.bestD[f * NP + p] = gidx;
+        a.minC[f * NP + p] = glo;
+        double subx = 0.0, suby = 0.0;
+        if (a.subpixel) {
+            const double c0 = (double)glo;
+            const int dx = gidx / Sy, dy = gidx % Sy;                            // :333-334
+            const uint16_t(*S)[4 * NW] = sSum[wave][slot4];
+            if (dy > 0 && dy < Sy - 1) suby = pyd_parabola((double)S[dx][dy - 1], c0, (double)S[dx][dy + 1]);
+            if (dx > 0 && dx < Sx - 1) subx = pyd_parabola((double)S[dx - 1][dy], c0, (double)S[dx + 1][dy]);
+        }
+        a.mvSub[f * 2 * (size_t)NP + p] = subx;              // zero when subpixel is off (:476 zero-init output)
+        a.mvSub[f * 2 * (size_t)NP + NP + p] = suby;
+    }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+bool pyd_rows_cost_ok(const PydCostArgs& a) {
+    const int Sx = 2 * a.rX + 1, Sy = 2 * a.rY + 1;
+    return pyd_rows_layout(Sx, Sy) && a.RS == pyd_row_stride(Sx, Sy) && a.rAgg <= 2 && (long long)a.W * a.H < 2147483647LL;
+}
+
+bool pyd_rows_wta_ok(const PydWtaArgs& a) {
+    uint32_t wsum = 0;
+    for (int r = 0; r < a.ndirs; r++) wsum += a.weight[r];
+    return pyd_rows_layout(a.Sx, a.Sy) && a.RS == pyd_row_stride(a.Sx, a.Sy) && wsum * 255u <= 65535u;
+}
+
+#define FSGM_ROWS_DISPATCH(NWV, CALL)            \
+    do {                                         \
+        if ((NWV) == 1) { constexpr int NW = 1; CALL; } \
+        else if ((NWV) == 2) { constexpr int NW = 2; CALL; } \
+        else { constexpr int NW = 3; CALL; }     \
+    } while (0)
+
+void launch_pyd_rows_cost(hipStream_t st, const PydCostArgs& a, int frames) {
+    dim3 grid((unsigned)((a.W * a.H + 15) / 16), frames);
+    FSGM_ROWS_DISPATCH(a.RS / 4, hipLaunchKernelGGL((pyd_rows_cost_kernel<NW>), grid, dim3(256), 0, st, a));
+}
+
+void launch_pyd_rows_desc(hipStream_t st, const PydAggArgs& a, int frames) {
+    dim3 grid((unsigned)((a.W * a.H + 255) / 256), a.ndirs, frames);
+    hipLaunchKernelGGL(pyd_rows_desc_kernel, grid, dim3(256), 0, st, a);
+}
+
+void launch_pyd_rows_aggregate(hipStream_t st, const PydAggArgs& a, int frames) {
+    if (a.ndirs == 0) return;
+    dim3 grid(a.blk_begin[8], frames);
+    const size_t lds = (size_t)4 * ROWS_WAVE_BYTES;
+    FSGM_ROWS_DISPATCH(a.RS / 4, hipLaunchKernelGGL((pyd_rows_agg_kernel<NW>), grid, dim3(256), lds, st, a));
+}
+
+void launch_pyd_rows_wta(hipStream_t st, const PydWtaArgs& a, int frames) {
+    dim3 grid((unsigned)((a.W * a.H + 15) / 16), frames);
+    FSGM_ROWS_DISPATCH(a.RS / 4, hipLaunchKernelGGL((pyd_rows_wta_kernel<NW>), grid, dim3(256), 0, st, a));
+}
+
+}  // namespace fsgm

@@ -81,6 +81,8 @@ def hint_map(mvW, mvH, kind="zero", seed=21, amp=3.0):
     'zero'   : coarsest pyramid level (pyramidal_sgm.m:34).
     'even'   : 2*integer values in 2x2 blocks, what 2*imresize(mv,2,'nearest') hands the next
                level when sub-pixel refinement is off (pyramidal_sgm.m:72).
+    'int'    : integer hints that change from pixel to pixel (negative deltas: the truncating
+               conversion rounds those up, calc_pyd_cost_sgm.cpp:46-47).
     'general': fractional hints (exercise the +0.5 / truncation rules and the (-1,0) -> 0 case).
     """
     if kind == "zero":
@@ -89,6 +91,8 @@ def hint_map(mvW, mvH, kind="zero", seed=21, amp=3.0):
         h2, w2 = (mvH + 1) // 2, (mvW + 1) // 2
         coarse = np.floor(uniform_f64(seed, (2, h2, w2)) * (2 * amp + 1)) - amp
         return np.ascontiguousarray(2.0 * np.repeat(np.repeat(coarse, 2, axis=1), 2, axis=2)[:, :mvH, :mvW])
+    if kind == "int":                                                  # whole numbers of either sign, a new one per pixel
+        return np.ascontiguousarray(np.floor(uniform_f64(seed, (2, mvH, mvW)) * (2 * amp + 1)) - amp)
     if kind == "general":
         mv = (uniform_f64(seed, (2, mvH, mvW)) - 0.5) * 2 * amp
         mv[:, ::3, ::4] = np.round(mv[:, ::3, ::4] * 2) / 2          # exact halves

@@ -13,6 +13,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("W,H,mvW,mvH,rX,rY,rAgg,kind", [
     (40, 30, 40, 30, 2, 2, 2, "zero"), (37, 23, 41, 29, 3, 1, 2, "general"), (33, 21, 33, 21, 1, 3, 1, "even"),
     (24, 18, 25, 20, 5, 5, 2, "general"), (16, 12, 16, 12, 0, 0, 0, "general"),
+    (45, 19, 45, 19, 5, 5, 2, "int"), (31, 22, 31, 22, 4, 2, 1, "int"), (29, 17, 30, 18, 5, 3, 0, "general"),
+    (26, 14, 26, 14, 6, 5, 2, "general"), (26, 14, 26, 14, 2, 6, 2, "int"),       # 13-wide windows: compact layout
+    (23, 16, 23, 16, 2, 2, 3, "general"),                                         # aggregation radius 3: generic kernel
 ])
 def test_pyd_cost_volume_bit_exact(gpu_lib, oracle, W, H, mvW, mvH, rX, rY, rAgg, kind):
     I1, I2 = synth.image_pair(W, H, 16, seed=W)
@@ -35,6 +38,15 @@ AGG = [
     (21, 17, 2, 3, 6, 32, 24, 1, 1, 0, "general"),          # single pass
     (21, 17, 2, 3, 6, 32, 24, 1, 3, 0, "even"),             # third pass repeats the mirrored one
     (9, 1, 2, 2, 6, 32, 24, 1, 2, 0, "general"), (1, 9, 2, 2, 6, 32, 24, 1, 2, 0, "general"),
+    # row-packed kernels: every row stride (Sy 1/3, 5/7, 9/11), both shift regimes, shifts beyond the window
+    (50, 21, 5, 5, 6, 32, 24, 1, 2, 0, "int"), (50, 21, 5, 5, 6, 32, 24, 1, 2, 1, "even"),
+    (35, 18, 5, 4, 6, 64, 24, 1, 2, 0, "int"), (35, 18, 4, 3, 10, 40, 60, 1, 2, 1, "int"),
+    (35, 18, 3, 2, 6, 32, 24, 1, 2, 0, "general"), (35, 18, 2, 1, 6, 32, 24, 1, 2, 0, "int"),
+    (35, 18, 1, 0, 6, 32, 24, 1, 2, 0, "int"), (35, 18, 0, 5, 6, 32, 24, 0, 2, 0, "int"),
+    (19, 33, 5, 5, 0, 0, 24, 1, 2, 0, "int"), (19, 33, 5, 5, 6, 6, 24, 1, 3, 0, "general"),
+    (67, 13, 5, 5, 6, 32, 24, 1, 2, 0, "far"),
+    # 13-wide windows: compact layout, generic kernels
+    (22, 15, 6, 5, 6, 32, 24, 1, 2, 0, "int"), (22, 15, 2, 6, 6, 32, 24, 1, 2, 1, "general"),
 ]
 
 
@@ -43,7 +55,7 @@ def test_pyd_aggregate_and_wta_bit_exact(gpu_lib, oracle, W, H, rX, rY, P1, P2, 
     Sx, Sy = 2 * rX + 1, 2 * rY + 1
     I1, I2 = synth.image_pair(W, H, 16, seed=3)
     I1 = (I1.astype(np.int32) * 3 % 256).astype(np.uint8)            # larger gradients: adaptive P2 branch taken
-    mv = synth.hint_map(W + 2, H + 1, kind, seed=5, amp=4.0)
+    mv = synth.hint_map(W + 2, H + 1, "int" if kind == "far" else kind, seed=5, amp=14.0 if kind == "far" else 4.0)
     Cv = synth.cost_volume(W, H, Sx * Sy, seed=7, cmax=cmax)
     S = oracle.pyd_aggregate(I1, Cv, mv, Sx, Sy, P1, P2, diag, passes, adaptive)
     bd, mc, ms = oracle.pyd_wta(S, Sx, Sy, 1)
@@ -60,7 +72,8 @@ def test_pyd_aggregate_and_wta_bit_exact(gpu_lib, oracle, W, H, rX, rY, P1, P2, 
     np.testing.assert_array_equal(gms, ms)
 
 
-@pytest.mark.parametrize("W,H,kind,sub", [(64, 48, "zero", 0), (61, 47, "even", 1), (80, 56, "general", 1)])
+@pytest.mark.parametrize("W,H,kind,sub", [(64, 48, "zero", 0), (61, 47, "even", 1), (80, 56, "general", 1),
+                                          (311, 94, "even", 1), (150, 40, "int", 1)])
 def test_calc_pyd_cost_sgm_whole_mex(gpu_lib, oracle, W, H, kind, sub):
     """pyramidal_sgm.m:50 argument values: 5,5 search half sizes, agg 2, P1=6, P2=32, diagonals, 2 passes."""
     I1, I2 = synth.image_pair(W, H, 16, seed=9)
