@@ -8,5 +8,6 @@ Everything computes on the GPU through libfsgm_hip.so (C ABI in include/fsgm.h).
 """
 from .epi import calc_cost_sgm, calc_cost_sgm_batch, EpiPlan  # noqa: F401
 from .pyd import calc_pyd_cost_sgm, PydPlan  # noqa: F401
+from .pyramid import pyramidal_sgm, PyramidPlan  # noqa: F401
 from .ng import calc_pyd_cost_sgm_ng, calc_cost_sgm_ng  # noqa: F401
 from ._lib import FsgmError, load as load_library  # noqa: F401

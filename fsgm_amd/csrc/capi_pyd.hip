@@ -2,26 +2,13 @@
 #include "capi_common.h"
 #include "epi_kernels.h"
 #include "pyd_kernels.h"
+#include "pyd_plan.h"
 #include <mutex>
 #include <string.h>
 #include <vector>
 
 using namespace fsgm;
 
-struct fsgm_pyd_plan {
-    int W = 0, H = 0, mvW = 0, mvH = 0, rX = 0, rY = 0, rAgg = 0, batch = 0, device = 0;
-    int Sx = 0, Sy = 0, D = 0;
-    int RS = 0, PS = 0;                  // volume layout in HBM (pyd_kernels.h): row stride, bytes per pixel
-    int P1 = 6, P2 = 32, diagonal = 1, totalPass = 2, adaptive = 0, subpixel = 0;   // pyramidal_sgm.m:15-22
-    int cmax = 24;                       // upper bound of the values in dC
-    size_t NP = 0, N = 0, MV = 0;        // N = bytes of one volume (NP * PS)
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    uint8_t *dI1 = nullptr, *dI2 = nullptr, *dC = nullptr, *dL = nullptr;
-    uint32_t *dCen1 = nullptr, *dCen2 = nullptr, *dBestD = nullptr, *dMinC = nullptr, *dS = nullptr, *dDesc = nullptr;
-    std::vector<uint8_t> stage;          // host staging for layout conversion of debug volumes
-    double *dMv = nullptr, *dMvSub = nullptr;
-};
 
 extern "C" {
 
@@ -33,7 +20,7 @@ void fsgm_pyd_plan_destroy(fsgm_pyd_plan* p) {
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->stream && p->owns_stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
 
@@ -128,7 +115,9 @@ fsgm_status fsgm_pyd_plan_upload_cost(fsgm_pyd_plan* p, int32_t f, const uint8_t
     return FSGM_OK;
 }
 
-static fsgm_status pyd_enqueue(fsgm_pyd_plan* p, int stages, uint32_t* dS) {
+}  // extern "C"
+
+fsgm_status fsgm::pyd_enqueue(fsgm_pyd_plan* p, int stages, uint32_t* dS) {
     if (stages & FSGM_STAGE_COST) {
         launch_census(p->stream, p->dI1, p->dCen1, p->W, p->H, p->batch);       // :485-486
         launch_census(p->stream, p->dI2, p->dCen2, p->W, p->H, p->batch);
@@ -166,6 +155,8 @@ static fsgm_status pyd_enqueue(fsgm_pyd_plan* p, int stages, uint32_t* dS) {
     FSGM_HIP(hipGetLastError());
     return FSGM_OK;
 }
+
+extern "C" {
 
 fsgm_status fsgm_pyd_plan_run(fsgm_pyd_plan* p, int32_t stages) {
     FSGM_REQUIRE(p, "null plan");

@@ -1,0 +1,135 @@
+"""Host-side mirror of the reference's pyramidal driver pyramidal_sgm.m (the MATLAB function around the
+calc_pyd_cost_sgm MEX), on top of the C ABI: the whole level loop runs on the device.
+
+Arrays follow the memory order the reference's drivers hand a MEX (after permute([2 1 3])): images
+(height, width) or (3, height, width) uint8 C-contiguous, flows (2, height, width) float64, plane 0 = x.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import check, ptr
+
+
+class PyramidParams(C.Structure):
+    _fields_ = [("numPyd", C.c_int32), ("P1", C.c_int32), ("P2", C.c_int32), ("aggHalfWinSize", C.c_int32),
+                ("verSearchHalfWinSize", C.c_int32), ("horSearchHalfWinSize", C.c_int32), ("enableDiagonal", C.c_int32),
+                ("totalPass", C.c_int32), ("adaptiveP2", C.c_int32), ("device", C.c_int32)]
+
+
+def _bind(lib):
+    if getattr(lib, "_pyramid_bound", False):
+        return
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.fsgm_pyramid_params_default.restype = PyramidParams
+    lib.fsgm_pyramidal_sgm_host.argtypes = [vp, vp, i32, i32, i32, C.POINTER(PyramidParams), vp, vp, vp]
+    lib.fsgm_pyramid_plan_create.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(PyramidParams)]
+    lib.fsgm_pyramid_plan_destroy.argtypes = [vp]
+    lib.fsgm_pyramid_plan_destroy.restype = None
+    lib.fsgm_pyramid_plan_level_size.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.fsgm_pyramid_plan_upload.argtypes = [vp, vp, vp]
+    lib.fsgm_pyramid_plan_run.argtypes = [vp]
+    lib.fsgm_pyramid_plan_download.argtypes = [vp, i32, vp, vp]
+    lib.fsgm_pyramid_plan_download_gray.argtypes = [vp, i32, vp, vp]
+    lib.fsgm_pyramid_plan_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+    lib._pyramid_bound = True
+
+
+def _params(lib, numPyd, device, overrides):
+    prm = lib.fsgm_pyramid_params_default()
+    prm.numPyd, prm.device = int(numPyd), int(device)
+    for k, v in overrides.items():
+        if not hasattr(prm, k):
+            raise TypeError(f"unknown pyramidal_sgm parameter {k!r}")
+        setattr(prm, k, int(v))
+    return prm
+
+
+def _check_images(I0, I1):
+    I0, I1 = np.ascontiguousarray(I0), np.ascontiguousarray(I1)
+    if I0.dtype != np.uint8 or I1.dtype != np.uint8 or I0.shape != I1.shape:
+        raise TypeError("I0/I1 must be uint8 images of one shape")
+    if not (I0.ndim == 2 or (I0.ndim == 3 and I0.shape[0] == 3)):
+        raise TypeError("images must be (height, width) or (3, height, width)")
+    return I0, I1, (1 if I0.ndim == 2 else 3)
+
+
+def pyramidal_sgm(I0, I1, numPyd=5, *, device=0, **overrides):
+    """[mvCurLevel, mvPyd, minC] = pyramidal_sgm(I0, I1, numPyd) (pyramidal_sgm.m:1).  Keyword overrides
+    name the function's hard-coded parameters (P1, P2, aggHalfWinSize, verSearchHalfWinSize,
+    horSearchHalfWinSize, enableDiagonal, totalPass, adaptiveP2; pyramidal_sgm.m:15-22)."""
+    lib = _lib.load()
+    _bind(lib)
+    I0, I1, ch = _check_images(I0, I1)
+    H, W = I0.shape[-2:]
+    prm = _params(lib, numPyd, device, overrides)
+    mv = np.zeros((2, H, W), np.float64)
+    minC = np.zeros((H, W), np.uint32)
+    sizes = [(W, H)]
+    for _ in range(1, prm.numPyd):
+        sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+    mvPyd = [np.zeros((2, h, w), np.float64) for (w, h) in sizes]
+    ptrs = (C.c_void_p * len(mvPyd))(*[a.ctypes.data for a in mvPyd])
+    check(lib.fsgm_pyramidal_sgm_host(ptr(I0), ptr(I1), W, H, ch, C.byref(prm), ptr(mv), ptr(minC), ptrs))
+    return mv, mvPyd, minC
+
+
+class PyramidPlan:
+    """Device-resident pyramid for one image shape: upload a pair, run, download any level."""
+
+    def __init__(self, width, height, channels=1, numPyd=5, *, device=0, **overrides):
+        self.lib = _lib.load()
+        _bind(self.lib)
+        self.prm = _params(self.lib, numPyd, device, overrides)
+        self.W, self.H, self.channels = int(width), int(height), int(channels)
+        self._h = C.c_void_p()
+        check(self.lib.fsgm_pyramid_plan_create(C.byref(self._h), self.W, self.H, self.channels, C.byref(self.prm)))
+
+    def close(self):
+        if self._h:
+            self.lib.fsgm_pyramid_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        check(self.lib.fsgm_pyramid_plan_level_size(self._h, int(level), C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def upload(self, I0, I1):
+        I0, I1, ch = _check_images(I0, I1)
+        if ch != self.channels or I0.shape[-2:] != (self.H, self.W):
+            raise ValueError("shape mismatch with the plan")
+        check(self.lib.fsgm_pyramid_plan_upload(self._h, ptr(I0), ptr(I1)))
+
+    def run(self):
+        check(self.lib.fsgm_pyramid_plan_run(self._h))
+
+    def download(self, level=1):
+        w, h = self.level_size(level)
+        mv = np.empty((2, h, w), np.float64)
+        minC = np.empty((h, w), np.uint32)
+        check(self.lib.fsgm_pyramid_plan_download(self._h, int(level), ptr(mv), ptr(minC)))
+        return mv, minC
+
+    def download_gray(self, level=1):
+        """The gray image pair calc_pyd_cost_sgm saw at `level` (after impyramid / rgb2gray)."""
+        w, h = self.level_size(level)
+        g0, g1 = np.empty((h, w), np.uint8), np.empty((h, w), np.uint8)
+        check(self.lib.fsgm_pyramid_plan_download_gray(self._h, int(level), ptr(g0), ptr(g1)))
+        return g0, g1
+
+    def time(self, warmup=1, iters=5):
+        ms = C.c_float()
+        check(self.lib.fsgm_pyramid_plan_time(self._h, int(warmup), int(iters), C.byref(ms)))
+        return float(ms.value)

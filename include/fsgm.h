@@ -192,6 +192,56 @@ fsgm_status fsgm_pyd_plan_time(fsgm_pyd_plan* plan, int32_t stages, int32_t warm
                                int32_t iters, float* ms_avg);
 
 /* ------------------------------------------------------------------------------------------
+ * pyramidal_sgm  (pyramidal_sgm.m:1-77 -- the MATLAB driver around calc_pyd_cost_sgm)
+ *
+ * The whole level loop on the device: image pyramid (impyramid 'reduce', :28-31), rgb2gray (:44-45),
+ * one calc_pyd_cost_sgm per level from coarse to fine (:50), index -> motion vector + previous
+ * level's hint + sub-pixel part (:57-64), and 2*imresize(mv, 2, 'nearest') as the next level's hint
+ * map (:72).  One upload of the image pair, one download of the flow; the reference's loop crosses
+ * the MEX boundary once per level.
+ *
+ * Images: u8 [channels][height][width], channels = 1 (gray) or 3 (R, G, B planes), x fastest -- what
+ * permute(I, [2 1 3]) hands a MEX (pyramidal_sgm.m:44).  Flows: f64 [2][height][width], plane 0 = x.
+ * impyramid / rgb2gray / imresize are MATLAB toolbox functions that are not in the reference tree;
+ * they follow the published behaviour restated in oracle/fsgm_oracle_pyramid.cpp.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t numPyd;                 /* pyramid levels          (pyramidal_sgm.m:12, default 5; test_psgm.m:33 passes 3) */
+    int32_t P1, P2;                 /* penalties               (:15-16: 6, 32) */
+    int32_t aggHalfWinSize;         /* cost aggregation window (:17: 2) */
+    int32_t verSearchHalfWinSize;   /* search window, y        (:18: 5) */
+    int32_t horSearchHalfWinSize;   /* search window, x        (:19: 5) */
+    int32_t enableDiagonal;         /* :20: 1 */
+    int32_t totalPass;              /* :21: 2 */
+    int32_t adaptiveP2;             /* :22: 0 */
+    int32_t device;                 /* HIP device ordinal */
+} fsgm_pyramid_params;
+
+fsgm_pyramid_params fsgm_pyramid_params_default(void);
+
+/* [mvCurLevel, mvPyd, minC] = pyramidal_sgm(I0, I1, numPyd).  mv: level-1 flow f64 [2][H][W]; minC
+ * (may be NULL): level-1 minimum summed path cost u32 [H][W]; mvPyd (may be NULL): numPyd pointers,
+ * entry l-1 (if not NULL) receives level l's flow f64 [2][H_l][W_l], H_l = ceil(H_{l-1}/2). */
+fsgm_status fsgm_pyramidal_sgm_host(const uint8_t* I0, const uint8_t* I1, int32_t width, int32_t height,
+                                    int32_t channels, const fsgm_pyramid_params* prm,
+                                    double* mv, uint32_t* minC, double* const* mvPyd);
+
+typedef struct fsgm_pyramid_plan fsgm_pyramid_plan;
+fsgm_status fsgm_pyramid_plan_create(fsgm_pyramid_plan** plan, int32_t width, int32_t height,
+                                     int32_t channels, const fsgm_pyramid_params* prm);
+void        fsgm_pyramid_plan_destroy(fsgm_pyramid_plan* plan);
+/* size of pyramid level `level` (1 = full resolution) */
+fsgm_status fsgm_pyramid_plan_level_size(fsgm_pyramid_plan* plan, int32_t level, int32_t* width, int32_t* height);
+fsgm_status fsgm_pyramid_plan_upload(fsgm_pyramid_plan* plan, const uint8_t* I0, const uint8_t* I1);
+fsgm_status fsgm_pyramid_plan_run(fsgm_pyramid_plan* plan);              /* asynchronous */
+/* HBM -> host (synchronous): flow and/or minC of one level; either pointer may be NULL */
+fsgm_status fsgm_pyramid_plan_download(fsgm_pyramid_plan* plan, int32_t level, double* mv, uint32_t* minC);
+/* debug tap: the gray images calc_pyd_cost_sgm saw at one level (after impyramid and rgb2gray), u8 [H_l][W_l] */
+fsgm_status fsgm_pyramid_plan_download_gray(fsgm_pyramid_plan* plan, int32_t level, uint8_t* gray0, uint8_t* gray1);
+/* average milliseconds of one whole pyramid run (HIP events on the plan's stream) */
+fsgm_status fsgm_pyramid_plan_time(fsgm_pyramid_plan* plan, int32_t warmup, int32_t iters, float* ms_avg);
+
+/* ------------------------------------------------------------------------------------------
  * calc_pyd_cost_sgm_ng  (calc_pyd_cost_sgm_ng.cpp:448-523; same 8-argument list as the call in
  * ng_sgm.m:20, no caller in the reference tree)
  * ------------------------------------------------------------------------------------------ */

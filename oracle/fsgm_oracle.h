@@ -88,6 +88,17 @@ void fsgm_oracle_calc_pyd_cost_sgm(uint32_t* bestD, uint32_t* minC, double* mvSu
                                    int diagonal, int totalPass, int adaptiveP2,
                                    uint8_t* C_out, uint32_t* S_out);
 
+/* ---- pyramidal driver: pyramidal_sgm.m (fsgm_oracle_pyramid.cpp; the MATLAB toolbox functions it
+ * calls -- impyramid, rgb2gray, imresize -- are restated from their published behaviour) ---- */
+void fsgm_oracle_impyramid_reduce(uint8_t* out, const uint8_t* in, int W, int H);   /* out: ceil(W/2) x ceil(H/2) */
+void fsgm_oracle_rgb2gray(uint8_t* out, const uint8_t* rgb, int W, int H);          /* rgb: [3][H][W] */
+/* pyramidal_sgm.m:1-77.  I0/I1 u8 [channels][H][W]; mv f64 [2][H][W]; minC u32 [H][W]; mvPyd NULL or
+ * numPyd pointers (entry l-1 = level l flow, f64 [2][H_l][W_l], H_l = ceil(H_{l-1}/2)). */
+void fsgm_oracle_pyramidal_sgm(double* mv, uint32_t* minC, double** mvPyd,
+                               const uint8_t* I0, const uint8_t* I1, int W, int H, int channels, int numPyd,
+                               int P1, int P2, int aggHalfWinSize, int verSearchHalfWinSize, int horSearchHalfWinSize,
+                               int enableDiagonal, int totalPass, int adaptiveP2);
+
 /* ---- neighbour-guided candidate-list variant: calc_pyd_cost_sgm_ng.cpp ---- */
 typedef struct { int32_t mvx, mvy, cost; } fsgm_oracle_cand;   /* calc_pyd_cost_sgm_ng.cpp:32-37 */
 

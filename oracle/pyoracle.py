@@ -157,6 +157,45 @@ def calc_pyd_cost_sgm(I1, I2, preMv, rX, rY, rAgg, subpixel, P1, P2, diagonal=1,
     return (bestD, minC, mvSub, Cv, S) if want_volumes else (bestD, minC, mvSub)
 
 
+# ---------------------------------------------------------------- pyramidal_sgm.m
+def impyramid_reduce(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.zeros(((H + 1) // 2, (W + 1) // 2), np.uint8)
+    lib().fsgm_oracle_impyramid_reduce(_p(out), _p(img), W, H)
+    return out
+
+
+def rgb2gray(rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    _, H, W = rgb.shape
+    out = np.zeros((H, W), np.uint8)
+    lib().fsgm_oracle_rgb2gray(_p(out), _p(rgb), W, H)
+    return out
+
+
+def pyramid_sizes(W, H, numPyd):
+    sizes = [(W, H)]
+    for _ in range(1, numPyd):
+        sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+    return sizes
+
+
+def pyramidal_sgm(I0, I1, numPyd=5, P1=6, P2=32, aggHalfWinSize=2, ver=5, hor=5, diagonal=1, totalPass=2, adaptiveP2=0):
+    """pyramidal_sgm.m: I0/I1 uint8 (H, W) or (3, H, W).  Returns (mv (2,H,W), minC (H,W), [mv per level])."""
+    I0 = np.ascontiguousarray(I0, np.uint8)
+    I1 = np.ascontiguousarray(I1, np.uint8)
+    ch = 1 if I0.ndim == 2 else I0.shape[0]
+    H, W = I0.shape[-2:]
+    mv = np.zeros((2, H, W), np.float64)
+    minC = np.zeros((H, W), np.uint32)
+    lv = [np.zeros((2, h, w), np.float64) for (w, h) in pyramid_sizes(W, H, numPyd)]
+    ptrs = (C.c_void_p * numPyd)(*[a.ctypes.data for a in lv])
+    lib().fsgm_oracle_pyramidal_sgm(_p(mv), _p(minC), ptrs, _p(I0), _p(I1), W, H, ch, int(numPyd), int(P1), int(P2),
+                                    int(aggHalfWinSize), int(ver), int(hor), int(diagonal), int(totalPass), int(adaptiveP2))
+    return mv, minC, lv
+
+
 # ---------------------------------------------------------------- calc_pyd_cost_sgm_ng
 CAND = np.dtype([("mvx", np.int32), ("mvy", np.int32), ("cost", np.int32)])
 

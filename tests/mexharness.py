@@ -70,7 +70,7 @@ def call(name, nlhs, *args):
     lib = C.CDLL(os.path.join(MEXDIR, f"{name}.mexstub.so"))
     fn = C.cast(lib.mexFunction, C.c_void_p)
     prhs = (C.c_void_p * max(1, len(args)))(*[to_mx(a) for a in args])
-    plhs = (C.c_void_p * max(1, nlhs, 4))()
+    plhs = (C.c_void_p * max(1, nlhs, 20))()
     rc = s.mexstub_call(fn, nlhs, plhs, len(args), prhs)
     printed = s.mexstub_printed().decode()
     try:

@@ -517,3 +517,94 @@ def fb_check(D1, pd0, nd, off, vMax, n, thr=2):         # calc_cost_sgm.cpp:429-
             elif abs(int(D1[y, x]) - int(D2[p2y, p2x])) > thr:
                 conf[y, x] = 0
     return conf, D2.astype(np.uint32)
+
+
+# =====================================================================================
+# pyramidal_sgm.m -- second restatement of the driver.  The toolbox functions it calls are restated
+# in the form of imresize's own algorithm (contribution tables in floating point, one dimension at
+# a time), not in the integer form the oracle uses.
+# =====================================================================================
+def _pyr_kernel(x):                                     # impyramid's piecewise-constant 'reduce' kernel
+    for brk, val in ((3.5, 0.0), (2.5, 0.0625), (1.5, 0.25), (0.5, 0.375), (-0.5, 0.25), (-1.5, 0.0625)):
+        if x >= brk:
+            return val
+    return 0.0
+
+
+def _contributions(in_len, out_len, scale, kernel, kernel_width):
+    """imresize's contributions(): per output sample, the input indices (0-based, mirrored) and weights."""
+    table = []
+    P = int(np.ceil(kernel_width)) + 2
+    for x in range(1, out_len + 1):
+        u = x / scale + 0.5 * (1 - 1 / scale)
+        left = int(np.floor(u - kernel_width / 2))
+        idx = [left + k for k in range(P)]
+        wts = [kernel(u - i) for i in idx]
+        tot = sum(wts)
+        wts = [w / tot for w in wts]
+        aux = list(range(1, in_len + 1)) + list(range(in_len, 0, -1))
+        idx = [aux[(i - 1) % len(aux)] - 1 for i in idx]
+        table.append([(i, w) for i, w in zip(idx, wts) if w != 0.0])
+    return table
+
+
+def _resize_along(img, axis, table):
+    out_shape = list(img.shape)
+    out_shape[axis] = len(table)
+    out = np.zeros(out_shape, np.uint8)
+    src = np.moveaxis(img, axis, 0).astype(np.float64)
+    dst = np.moveaxis(out, axis, 0)
+    for o, taps in enumerate(table):
+        acc = np.zeros(src.shape[1:])
+        for i, w in taps:
+            acc = acc + w * src[i]
+        dst[o] = np.clip(np.floor(acc + 0.5), 0, 255).astype(np.uint8)      # uint8(): round, saturate
+    return out
+
+
+def impyramid_reduce(img):                              # impyramid(A, 'reduce'), one channel, (H, W)
+    H, W = img.shape
+    t = _resize_along(img, 0, _contributions(H, (H + 1) // 2, 0.5, _pyr_kernel, 5))      # dimension 1 first
+    return _resize_along(t, 1, _contributions(W, (W + 1) // 2, 0.5, _pyr_kernel, 5))
+
+
+def rgb2gray(rgb):                                      # (3, H, W) uint8
+    T = np.linalg.inv(np.array([[1.0, 0.956, 0.621], [1.0, -0.272, -0.647], [1.0, -1.106, 1.703]]))
+    c = T[0]
+    v = c[0] * rgb[0].astype(np.float64) + c[1] * rgb[1].astype(np.float64) + c[2] * rgb[2].astype(np.float64)
+    return np.floor(v + 0.5).astype(np.uint8)
+
+
+def resize2_nearest(a):                                 # imresize(a, 2, 'nearest') on (H, W)
+    box = lambda x: 1.0 if -0.5 <= x < 0.5 else 0.0
+    H, W = a.shape
+    ty = [t[0][0] for t in _contributions(H, 2 * H, 2.0, box, 1.0)]
+    tx = [t[0][0] for t in _contributions(W, 2 * W, 2.0, box, 1.0)]
+    return a[np.ix_(ty, tx)]
+
+
+def pyramidal_sgm(I0, I1, numPyd, P1=6, P2=32, agg=2, ver=5, hor=5, diag=1, totalPass=2, adaptive=0):   # :1-77
+    chans = (lambda a: [a] if a.ndim == 2 else list(a))
+    p0, p1 = [chans(I0)], [chans(I1)]
+    for _ in range(1, numPyd):                                                       # :28-31
+        p0.append([impyramid_reduce(c) for c in p0[-1]])
+        p1.append([impyramid_reduce(c) for c in p1[-1]])
+    gray = lambda cs: cs[0] if len(cs) == 1 else rgb2gray(np.stack(cs))
+    Hc, Wc = p0[-1][0].shape
+    mvPre = np.zeros((2, Hc, Wc))                                                    # :34
+    Sx, Sy = 2 * hor + 1, 2 * ver + 1
+    levels = [None] * numPyd
+    minC = None
+    for l in range(numPyd - 1, -1, -1):                                              # :37
+        g0, g1 = gray(p0[l]), gray(p1[l])
+        h, w = g0.shape
+        C = pyd_cost(census(g0), census(g1), mvPre, agg, hor, ver)                   # :50 (the MEX)
+        Sp = pyd_sgm2d(g0, C, mvPre, Sx, Sy, P1, P2, diag, totalPass, adaptive)
+        bestD, minC, mvSub = pyd_wta(Sp, Sx, Sy, l == 0)
+        idx = bestD.astype(np.int64)
+        mvx, mvy = idx // Sy - hor, idx % Sy - ver                                   # :57-60
+        cur = np.stack([mvx, mvy]).astype(np.float64) + mvPre[:, :h, :w] + mvSub     # :62-64
+        levels[l] = cur
+        if l > 0:
+            mvPre = 2 * np.stack([resize2_nearest(cur[0]), resize2_nearest(cur[1])])  # :72
+    return levels[0], minC, levels

@@ -73,3 +73,21 @@ def test_ng_gateways_as_ng_sgm_calls_them(gpu_lib, oracle):
     assert printed == "dMax : 108\n"
     np.testing.assert_array_equal(minC, rmc)
     np.testing.assert_array_equal(flow, rfl)
+
+
+def test_fsgm_pyramidal_sgm_gateway_as_a_drop_in_pyramidal_sgm_would_call_it(gpu_lib, oracle):
+    """[mv, minC, mvPyd1..3] = fsgm_pyramidal_sgm(permute(I0,[2 1 3]), permute(I1,[2 1 3]), 3) -- the
+    argument values of test_psgm.m:33-34 (RGB pair, three levels)."""
+    W, H = 85, 47
+    g0, g1 = synth.image_pair(W, H, 12, seed=4)
+    I0 = np.stack([g0, 255 - g0, g0 // 3 + 80])
+    I1 = np.stack([g1, 255 - g1, g1 // 3 + 80])
+    outs, _ = mh.call("fsgm_pyramidal_sgm", 5, I0, I1, 3)
+    want_mv, want_minC, want_lv = oracle.pyramidal_sgm(I0, I1, 3)
+    assert outs[0].shape == (2, H, W) and outs[0].dtype == np.float64 and outs[1].dtype == np.uint32
+    np.testing.assert_array_equal(outs[0], want_mv)
+    np.testing.assert_array_equal(outs[1], want_minC)
+    for l in range(3):
+        np.testing.assert_array_equal(outs[2 + l], want_lv[l])
+    (only,), _ = mh.call("fsgm_pyramidal_sgm", 1, g0, g1)                       # gray pair, default numPyd = 5
+    np.testing.assert_array_equal(only, oracle.pyramidal_sgm(g0, g1, 5)[0])

@@ -1,0 +1,93 @@
+"""GPU parity tests for the pyramidal driver (pyramidal_sgm.m:1-77 as one device-resident call):
+fsgm_pyramidal_sgm / PyramidPlan through the C ABI vs the CPU oracle (oracle/fsgm_oracle_pyramid.cpp).
+Everything is compared exactly: gray pyramids (u8), flows of every level (fp64, same IEEE operations
+in the same order), minC (u32)."""
+import numpy as np
+import pytest
+
+from fsgm_amd import synth, pyramidal_sgm, PyramidPlan
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(W, H, ch, seed):
+    I0, I1 = synth.image_pair(W, H, 12, seed=seed)
+    if ch == 3:
+        n0 = synth.uniform_u8(seed + 50, (3, H, W), hi=40).astype(np.int32)
+        I0 = np.clip(np.stack([I0, I0 // 2 + 60, 255 - I0]).astype(np.int32) + n0 - 20, 0, 255).astype(np.uint8)
+        I1 = np.clip(np.stack([I1, I1 // 2 + 60, 255 - I1]).astype(np.int32) + n0 - 20, 0, 255).astype(np.uint8)
+    return I0, I1
+
+
+@pytest.mark.parametrize("W,H,ch,numPyd", [(64, 48, 1, 3), (61, 47, 3, 3), (150, 71, 3, 4), (33, 21, 1, 1),
+                                           (40, 30, 1, 5), (97, 17, 3, 2), (2, 3, 1, 2)])
+def test_pyramidal_sgm_bit_exact(gpu_lib, oracle, W, H, ch, numPyd):
+    I0, I1 = _pair(W, H, ch, seed=W + numPyd)
+    want_mv, want_minC, want_lv = oracle.pyramidal_sgm(I0, I1, numPyd)
+    mv, mvPyd, minC = pyramidal_sgm(I0, I1, numPyd)
+    for l in range(numPyd - 1, -1, -1):                   # coarse to fine: the first difference is the informative one
+        np.testing.assert_array_equal(mvPyd[l], want_lv[l], err_msg=f"level {l + 1}")
+    np.testing.assert_array_equal(mv, want_mv)
+    np.testing.assert_array_equal(minC, want_minC)
+
+
+@pytest.mark.parametrize("over", [dict(verSearchHalfWinSize=3, horSearchHalfWinSize=4), dict(adaptiveP2=1, P2=64),
+                                  dict(enableDiagonal=0, totalPass=1), dict(aggHalfWinSize=1, P1=10, P2=40),
+                                  dict(verSearchHalfWinSize=6, horSearchHalfWinSize=2)])
+def test_pyramidal_sgm_parameter_overrides(gpu_lib, oracle, over):
+    I0, I1 = _pair(57, 39, 3, seed=11)
+    I0 = (I0.astype(np.int32) * 5 % 256).astype(np.uint8)        # strong gradients: adaptive P2 switches
+    o = dict(P1=6, P2=32, aggHalfWinSize=2, verSearchHalfWinSize=5, horSearchHalfWinSize=5, enableDiagonal=1, totalPass=2, adaptiveP2=0)
+    o.update(over)
+    want_mv, want_minC, want_lv = oracle.pyramidal_sgm(I0, I1, 3, o["P1"], o["P2"], o["aggHalfWinSize"], o["verSearchHalfWinSize"],
+                                                       o["horSearchHalfWinSize"], o["enableDiagonal"], o["totalPass"], o["adaptiveP2"])
+    mv, mvPyd, minC = pyramidal_sgm(I0, I1, 3, **over)
+    for l in range(2, -1, -1):
+        np.testing.assert_array_equal(mvPyd[l], want_lv[l], err_msg=f"level {l + 1}")
+    np.testing.assert_array_equal(minC, want_minC)
+
+
+def test_pyramid_plan_gray_pyramid_and_reuse(gpu_lib, oracle):
+    """impyramid 'reduce' + rgb2gray on the device vs the oracle, level by level; the plan is reused for a
+    second pair (nothing of the first run may leak into it)."""
+    W, H, n = 131, 77, 4
+    with PyramidPlan(W, H, 3, n) as plan:
+        for seed in (5, 6):
+            I0, I1 = _pair(W, H, 3, seed=seed)
+            plan.upload(I0, I1)
+            plan.run()
+            c0, c1 = I0, I1
+            for l in range(1, n + 1):
+                if l > 1:
+                    c0 = np.stack([oracle.impyramid_reduce(c) for c in c0])
+                    c1 = np.stack([oracle.impyramid_reduce(c) for c in c1])
+                g0, g1 = plan.download_gray(l)
+                np.testing.assert_array_equal(g0, oracle.rgb2gray(c0), err_msg=f"level {l}")
+                np.testing.assert_array_equal(g1, oracle.rgb2gray(c1), err_msg=f"level {l}")
+                assert plan.level_size(l) == (c0.shape[2], c0.shape[1])
+            want_mv, want_minC, _ = oracle.pyramidal_sgm(I0, I1, n)
+            mv, minC = plan.download(1)
+            np.testing.assert_array_equal(mv, want_mv)
+            np.testing.assert_array_equal(minC, want_minC)
+
+
+def test_pyramidal_sgm_kitti_shape_level_sizes(gpu_lib, oracle):
+    """BASELINE config 4 shape: 1242x375, 3 levels -> 621x188, 311x94 (ceil(size/2), test_psgm.m:33)."""
+    with PyramidPlan(1242, 375, 3, 3) as plan:
+        assert [plan.level_size(l) for l in (1, 2, 3)] == [(1242, 375), (621, 188), (311, 94)]
+        I0, I1 = _pair(1242, 375, 3, seed=1)
+        plan.upload(I0, I1)
+        plan.run()
+        mv, minC = plan.download(1)
+        assert mv.shape == (2, 375, 1242) and np.isfinite(mv).all()
+        # coarse levels are cheap enough for the oracle: compare the level-3 flow (311x94) exactly
+        c0, c1 = I0, I1
+        for _ in range(2):
+            c0 = np.stack([oracle.impyramid_reduce(c) for c in c0])
+            c1 = np.stack([oracle.impyramid_reduce(c) for c in c1])
+        g0, g1 = oracle.rgb2gray(c0), oracle.rgb2gray(c1)
+        bd, mc, ms = oracle.calc_pyd_cost_sgm(g0, g1, np.zeros((2, 94, 311)), 5, 5, 2, 0, 6, 32, 1, 2, 0)
+        lv3, mc3 = plan.download(3)
+        np.testing.assert_array_equal(mc3, mc)
+        np.testing.assert_array_equal(lv3[0], (bd // 11).astype(np.float64) - 5)
+        np.testing.assert_array_equal(lv3[1], (bd % 11).astype(np.float64) - 5)

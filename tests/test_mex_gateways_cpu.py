@@ -1,4 +1,4 @@
-"""The four mexFunction gateways: they load, export mexFunction, and validate arguments loudly
+"""The mexFunction gateways (the reference's four MEX names and the pyramidal driver): they load, export mexFunction, and validate arguments loudly
 (no GPU needed: validation happens before the library is asked to compute)."""
 import ctypes
 import os
@@ -8,7 +8,7 @@ import pytest
 from fsgm_amd import synth, _lib
 from tests import mexharness as mh
 
-GATEWAYS = ["calc_cost_sgm", "calc_pyd_cost_sgm", "calc_pyd_cost_sgm_ng", "calc_cost_sgm_ng"]
+GATEWAYS = ["calc_cost_sgm", "calc_pyd_cost_sgm", "calc_pyd_cost_sgm_ng", "calc_cost_sgm_ng", "fsgm_pyramidal_sgm"]
 
 
 @pytest.mark.parametrize("name", GATEWAYS)
@@ -62,6 +62,25 @@ def test_pyd_gateway_validation():
     with pytest.raises(mh.MexError) as e:
         mh.call("calc_pyd_cost_sgm_ng", 2, I1, I2, mv, 1, 2, 0, 6)
     assert e.value.ident == "fsgm:nrhs"
+
+
+def test_pyramid_gateway_validation():
+    I0, I1 = synth.image_pair(20, 16, 8)
+    with pytest.raises(mh.MexError) as e:
+        mh.call("fsgm_pyramidal_sgm", 2, I0)
+    assert e.value.ident == "fsgm:nrhs"
+    with pytest.raises(mh.MexError) as e:                  # two planes: neither gray nor RGB
+        mh.call("fsgm_pyramidal_sgm", 2, np.stack([I0, I0]), np.stack([I1, I1]), 3)
+    assert e.value.ident == "fsgm:size"
+    with pytest.raises(mh.MexError) as e:
+        mh.call("fsgm_pyramidal_sgm", 2, I0, I1[:, :-1], 3)
+    assert e.value.ident == "fsgm:size"
+    with pytest.raises(mh.MexError) as e:
+        mh.call("fsgm_pyramidal_sgm", 2, I0, I1, 0)
+    assert e.value.ident == "fsgm:range"
+    with pytest.raises(mh.MexError) as e:                  # more outputs than mv, minC and one flow per level
+        mh.call("fsgm_pyramidal_sgm", 6, I0, I1, 3)
+    assert e.value.ident == "fsgm:nlhs"
 
 
 def test_no_gpu_is_a_mex_error_not_a_fallback():
