@@ -5,6 +5,7 @@
 #include "pyd_plan.h"
 #include <mutex>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 using namespace fsgm;
@@ -117,6 +118,12 @@ fsgm_status fsgm_pyd_plan_upload_cost(fsgm_pyd_plan* p, int32_t f, const uint8_t
 
 }  // extern "C"
 
+// FSGM_PYD_WIDE: 0 = never use the wide mapping, 1 = automatic (default), 2 = always (tests)
+static int fsgm_env_wide() {
+    const char* e = getenv("FSGM_PYD_WIDE");
+    return (e && *e) ? atoi(e) : 1;
+}
+
 fsgm_status fsgm::pyd_enqueue(fsgm_pyd_plan* p, int stages, uint32_t* dS) {
     if (stages & FSGM_STAGE_COST) {
         launch_census(p->stream, p->dI1, p->dCen1, p->W, p->H, p->batch);       // :485-486
@@ -137,7 +144,10 @@ fsgm_status fsgm::pyd_enqueue(fsgm_pyd_plan* p, int stages, uint32_t* dS) {
     const int cm = p->cmax;
     const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + (p->P1 > p->P2 ? p->P1 : p->P2) <= 255;
     const bool rows = nowrap && p->dDesc != nullptr;        // row-packed aggregation (pyd_rows.hip)
-    plan_pyd_dirs(g, p->diagonal, p->totalPass, w.weight, rows ? 16 : 4);
+    // A single landscape frame is bounded by its longest serial chains, the horizontal lines: those take
+    // the kernel's one-line-per-wave mapping (fewer instructions per step); batches keep the packed one.
+    const bool wide_rows = rows && p->batch <= 2 && p->W > p->H && fsgm_env_wide() != 0;
+    plan_pyd_dirs(g, p->diagonal, p->totalPass, w.weight, rows ? 16 : 4, wide_rows || (rows && fsgm_env_wide() == 2));
     if (stages & FSGM_STAGE_AGGREGATE) {
         if (rows) {
             launch_pyd_rows_desc(p->stream, g, p->batch);

@@ -33,6 +33,7 @@ struct PydAggArgs {
     int ndirs;              // path slots
     int blk_begin[9];
     int dir_code[8];        // as AggArgs
+    int wide_mask;          // bit s: slot s runs the one-line-per-wave mapping of the row-packed kernel
 };
 
 struct PydWtaArgs {
@@ -55,8 +56,10 @@ inline bool pyd_rows_layout(int Sx, int Sy) { return Sx <= 11 && Sy <= 11; }
 inline int  pyd_row_stride(int Sx, int Sy) { return pyd_rows_layout(Sx, Sy) ? 4 * ((Sy + 3) / 4) : Sy; }
 
 void launch_pyd_cost(hipStream_t st, const PydCostArgs& a, int frames);
-// returns the number of path slots it planned (nd or 2*nd); lines_per_block = 4 (generic kernel) or 16 (row-packed)
-int  plan_pyd_dirs(PydAggArgs& a, int diagonal, int totalPass, uint32_t weight[8], int lines_per_block);
+// returns the number of path slots it planned (nd or 2*nd); lines_per_block = 4 (generic kernel) or 16
+// (row-packed); wide_rows: the horizontal slots of the row-packed kernel take its one-line-per-wave
+// mapping (4 lines per block)
+int  plan_pyd_dirs(PydAggArgs& a, int diagonal, int totalPass, uint32_t weight[8], int lines_per_block, bool wide_rows = false);
 // wrap = false: penalties in the no-wrap range (0 <= P1,P2, max C + P2 + max(P1,P2) <= 255)
 void launch_pyd_aggregate(hipStream_t st, const PydAggArgs& a, int frames, bool wrap);
 void launch_pyd_wta(hipStream_t st, const PydWtaArgs& a, int frames);

@@ -367,18 +367,22 @@ void launch_pyd_cost(hipStream_t st, const PydCostArgs& a, int frames) {
     hipLaunchKernelGGL(pyd_cost_kernel, grid, dim3(256), 0, st, a);
 }
 
-int plan_pyd_dirs(PydAggArgs& a, int diagonal, int totalPass, uint32_t weight[8], int lines_per_block) {
+int plan_pyd_dirs(PydAggArgs& a, int diagonal, int totalPass, uint32_t weight[8], int lines_per_block, bool wide_rows) {
     // pass 0: along x, along y, (+1,+1), (-1,+1); later passes: their point mirrors, all identical
     // (calc_pyd_cost_sgm.cpp:142-151 sets the mirrored start/step once at pass==1)
     static const int fwd[4] = {0, 1, 2, 3};
     const int nd = diagonal ? 4 : 2;
     int n = 0, acc = 0;
+    a.wide_mask = 0;
     auto add = [&](int code, uint32_t w) {
         a.dir_code[n] = code;
         a.blk_begin[n] = acc;
         weight[n] = w;
         const int nlines = (code & 3) == 0 ? a.H : a.W;
-        acc += (nlines + lines_per_block - 1) / lines_per_block;
+        const bool wide = wide_rows && (code & 3) == 0;
+        if (wide) a.wide_mask |= 1 << n;
+        const int lpb = wide ? 4 : lines_per_block;
+        acc += (nlines + lpb - 1) / lpb;
         n++;
     };
     if (totalPass >= 1) for (int k = 0; k < nd; k++) add(fwd[k], 1u);

@@ -225,29 +225,35 @@ __global__ __launch_bounds__(256) void pyd_rows_desc_kernel(PydAggArgs a) {
 // (0 <= P1,P2, max C + P2 + max(P1,P2) <= 255: no u8 narrowing changes a value, so the centre cell
 // may take part in the "+P1" minimum and a cell outside the window is just 255).
 //
-// A wave advances 4 path lines (one per DPP row of 16 lanes) by one pixel per step.  The previous
-// pixel's path costs sit in LDS as bytes, one 52-byte row per candidate row with the Sy costs at
-// byte 16 and 0xFF around them (row 15 is all 0xFF).  Lane j reads row (j-2)+kfx at byte offset
-// kfy-2 -- the hint shift (:46-47) folded into the address -- as NW+2 dwords, realigns them with
-// v_alignbyte, and takes the 5-wide minimum along sy in packed u16 registers (even/odd split, as in
-// the 1-D kernels); the 5-wide minimum along sx is 4 DPP row shifts.  The second shift regime of a
-// truncating conversion (pyd_rows_desc_kernel) is a per-element select along sy and a one-lane DPP
-// shift along sx.  Steps whose shift table is irregular gather the 5x5 cells byte by byte.
+// The previous pixel's path costs sit in LDS as bytes, one 52-byte row per candidate row with the
+// Sy costs at byte 16 and 0xFF around them (row 15 is all 0xFF).  Lane j of a 16-lane DPP row reads
+// candidate row (j-2)+kfx at byte offset kfy-2 -- the hint shift (:46-47) folded into the address --
+// realigns the dwords with v_alignbyte, and takes the 5-wide minimum along sy in packed u16
+// registers (even/odd split, as in the 1-D kernels); the 5-wide minimum along sx is 4 DPP row
+// shifts.  The second shift regime of a truncating conversion (pyd_rows_desc_kernel) is a
+// per-element select along sy and a one-lane DPP shift along sx.  Steps whose shift table is
+// irregular gather the 5x5 cells byte by byte.
+//
+// Two mappings of the same step:
+//   packed (WIDE = false): a wave advances 4 path lines, one per DPP row; a lane owns a whole
+//          candidate row (NW dwords).  Least work per pixel: used when there are many lines.
+//   wide   (WIDE = true):  a wave advances ONE line; DPP row q owns the sy quarter 4q..4q+3 of every
+//          candidate row (1 dword per lane).  2.5x fewer instructions per step: used for the long
+//          horizontal lines of a single frame, whose serial length bounds the whole stage.
 // =============================================================================================
 constexpr int ROWB = 52;                // bytes per LDS row (13 dwords: odd stride)
 constexpr int ROWDATA = 16;             // byte of sy = 0
 constexpr int ABSROW = 15;              // the all-0xFF row
+constexpr int DUMPROW = 14;             // written by lanes without a candidate row, never read
 constexpr int ROWS_WAVE_BYTES = 2 * 4 * 16 * ROWB + 4 * 32 * 4;    // two buffers of 4 x 16 rows + gather tables
 
-template <int NW>
-__global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
-    extern __shared__ uint32_t sRows[];
+template <int NW, bool WIDE>
+__device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int slot, uint32_t* sRows) {
+    constexpr int PF = 4;                                    // prefetch distance in steps
+    constexpr int NL = WIDE ? 1 : NW;                        // dwords of a candidate row this lane owns
+    constexpr int NE = NL + (WIDE ? 2 : 1);                  // realigned dwords of the previous row it needs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 15, slot4 = lane >> 4;
-    int slot = 0;
-#pragma unroll
-    for (int i = 1; i < 8; i++)
-        if (i < a.ndirs && (int)blockIdx.x >= a.blk_begin[i]) slot = i;
+    const int j = lane & 15, row4 = lane >> 4;
     const int code = a.dir_code[slot];
     const int base = code & 3;
     const bool mirror = (code & 4) != 0;
@@ -255,121 +261,137 @@ __global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
     const int NP = W * H;
     const int nlines = base == 0 ? H : W;
     const int len = base == 0 ? W : H;
-    int line = ((int)blockIdx.x - a.blk_begin[slot]) * 16 + wave * 4 + slot4;
+    int line = ((int)blockIdx.x - a.blk_begin[slot]) * (WIDE ? 4 : 16) + (WIDE ? wave : wave * 4 + row4);
     const bool active = line < nlines;
     line = min(line, nlines - 1);
+    const int q = WIDE ? min(row4, NW - 1) : 0;              // sy quarter (wide); rows beyond the last quarter idle
+    const bool qlive = !WIDE || row4 < NW;
     uint8_t* const wbase = (uint8_t*)sRows + (size_t)wave * ROWS_WAVE_BYTES;
     for (int i = lane; i < 2 * 4 * 16 * ROWB / 4; i += 64) ((uint32_t*)wbase)[i] = 0xFFFFFFFFu;
-    uint8_t* pre = wbase + slot4 * 16 * ROWB;
+    uint8_t* pre = wbase + (WIDE ? 0 : row4) * 16 * ROWB;
     uint8_t* cur = pre + 4 * 16 * ROWB;
-    int32_t* const tabs = (int32_t*)(wbase + 2 * 4 * 16 * ROWB) + slot4 * 32;   // gather path: xtab[16], ytab[16]
+    int32_t* const tabs = (int32_t*)(wbase + 2 * 4 * 16 * ROWB) + (WIDE ? 0 : row4) * 32;   // gather path: xtab[16], ytab[16]
     const size_t f = blockIdx.y;
     const uint8_t* __restrict__ Cf = a.C + f * (size_t)NP * PS;
     uint8_t* __restrict__ Lf = a.L + (f * a.ndirs + slot) * (size_t)NP * PS;
     const uint32_t* __restrict__ Df = a.desc + (f * a.ndirs + slot) * (size_t)NP;
-    const int rx = base == 1 ? 0 : (base == 3 ? -1 : 1), ry = base == 0 ? 0 : 1;
     const int sx = j - 2;                                    // candidate row this lane produces
-    const bool is_out = sx >= 0 && sx < Sx;
+    const bool is_out = sx >= 0 && sx < Sx && qlive;
     const int sxc = clampi(sx, 0, Sx - 1);
+    const uint32_t rowoff = (uint32_t)(sxc * RS + 4 * q);    // this lane's bytes inside a pixel
     // padding slots (sy >= Sy) carry 0x00FF so that the row written back reads as "outside"; lanes
-    // that produce no row carry all ones so that they never win the minimum
-    uint32_t padE[NW], padO[NW];
+    // that produce nothing carry all ones so that they never win the minimum
+    uint32_t padE[NL], padO[NL];
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-        padE[k] = is_out ? ((4 * k >= Sy ? 0x00FFu : 0u) | (4 * k + 2 >= Sy ? 0x00FF0000u : 0u)) : 0xFFFFFFFFu;
-        padO[k] = is_out ? ((4 * k + 1 >= Sy ? 0x00FFu : 0u) | (4 * k + 3 >= Sy ? 0x00FF0000u : 0u)) : 0xFFFFFFFFu;
+    for (int k = 0; k < NL; k++) {
+        const int s0 = 4 * (k + q);
+        padE[k] = is_out ? ((s0 >= Sy ? 0x00FFu : 0u) | (s0 + 2 >= Sy ? 0x00FF0000u : 0u)) : 0xFFFFFFFFu;
+        padO[k] = is_out ? ((s0 + 1 >= Sy ? 0x00FFu : 0u) | (s0 + 3 >= Sy ? 0x00FF0000u : 0u)) : 0xFFFFFFFFu;
     }
     const uint32_t P1_2 = dup16((uint32_t)a.P1);
 
-    // cursor in the pass-0 frame
-    int x = base == 0 ? 0 : line, y = base == 0 ? line : 0;
-    auto actual = [&](int cx, int cy, int& ax, int& ay) { ax = mirror ? W - 1 - cx : cx; ay = mirror ? H - 1 - cy : cy; };
-    auto advance = [&](int& cx, int& cy) {
-        if (base == 0) cx++;
-        else {
-            cy++;
-            if (base == 2) { cx++; if (cx == W) cx = 0; }
-            if (base == 3) { cx--; if (cx < 0) cx = W - 1; }
+    // Walk of the line as increments of the pixel index.  Pass-0 frame: step (+1,0), (0,+1), (+1,+1)
+    // or (-1,+1); a diagonal that leaves the image re-enters at the opposite border (a path start),
+    // so every line has `len` steps.  The mirrored passes run the same walk through the point mirror.
+    const int sgn = mirror ? -1 : 1;
+    const int dstep = sgn * (base == 0 ? 1 : base == 1 ? W : base == 2 ? W + 1 : W - 1);
+    const int dwrap = sgn * (base == 2 ? -W : W);            // extra increment when the diagonal wraps
+    const int dcx = base == 3 ? -1 : 1;
+    const int cwrap = base == 2 ? W : -1, creset = base == 2 ? 0 : W - 1;
+    int cx = base == 0 ? 0 : line;                           // pass-0 column (diagonals only)
+    int pix = base == 0 ? line * W : line;                   // first pixel: (0, line) for rows, (line, 0) otherwise
+    if (mirror) pix = NP - 1 - pix;                          // (shadowed inside the loop by the current step's pixel)
+    auto advance = [&](int& p, int& c) {
+        p += dstep;
+        if (base >= 2) {
+            c += dcx;
+            if (c == cwrap) { c = creset; p += dwrap; }
         }
     };
-    struct Fetch { uint32_t c[NW]; uint32_t desc; };
-    auto fetch = [&](int cx, int cy, Fetch& o) {
-        int ax, ay;
-        actual(cx, cy, ax, ay);
-        const size_t pix = (size_t)ay * W + ax;
-        const uint32_t* src = (const uint32_t*)(Cf + pix * PS + (size_t)sxc * RS);
+    // Prefetch ring: costs and descriptor of step t+PF are requested while step t computes (HBM latency
+    // is several steps long).  The ring rotates by unrolling, not by copying: a copy would wait for
+    // the load it copies.  The fetch cursor runs PF steps ahead of the step being computed; steps past
+    // the end of the line re-read the first pixel and store into the dump slot.
+    struct Fetch { uint32_t c[NL]; uint32_t desc; int pix; };
+    const int pix0 = pix;
+    int fpix = pix, fcx = cx, ft = 0;
+    auto issue = [&](Fetch& o) {
+        const int p = ft < len ? fpix : pix0;
+        const uint32_t* src = (const uint32_t*)(Cf + (size_t)p * PS + rowoff);
 #pragma unroll
-        for (int k = 0; k < NW; k++) o.c[k] = src[k];
-        o.desc = Df[pix];
+        for (int k = 0; k < NL; k++) o.c[k] = src[k];
+        o.desc = Df[p];
+        o.pix = p;
+        ft++;
+        advance(fpix, fcx);
     };
-
-    Fetch nxt;
-    fetch(x, y, nxt);
-    int xn = x, yn = y;
-    advance(xn, yn);
+    Fetch ring[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) issue(ring[k]);
     uint32_t m = 0;
-    // the first fetch lands before the loop: otherwise the loop header's wait has to cover it on every
-    // iteration and, counted from there, ends up waiting for the previous step's store as well
-    nxt.desc = opaque(nxt.desc);
-#pragma unroll
-    for (int k = 0; k < NW; k++) nxt.c[k] = opaque(nxt.c[k]);
     __builtin_amdgcn_wave_barrier();
-    for (int t = 0; t < len; t++) {
-        const Fetch now = nxt;
-        {                                                    // in flight while this step computes
-            const bool last = t + 1 >= len;
-            fetch(last ? x : xn, last ? y : yn, nxt);
-        }
+    for (int t0 = 0; t0 < len; t0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int t = t0 + u;
+        const Fetch now = ring[u];
+        const int pix = now.pix;
+        issue(ring[u]);                                      // step t+PF, in flight while steps t .. t+PF-1 compute
         const uint32_t d = now.desc;
         const bool start = (d & DESC_START) != 0;
         const int kfx = (int)(d & 63u) - 16, nax = (int)((d >> 6) & 15u);
         const int kfy = (int)((d >> 10) & 63u) - 16, nay = (int)((d >> 16) & 15u);
         const uint32_t P2 = (d >> 20) & 255u;
-        uint32_t ME[NW], MO[NW], CE[NW], CO[NW];            // 5x5 minimum / centre value per sy (even, odd sy)
+        uint32_t ME[NL], MO[NL], CE[NL], CO[NL];            // 5x5 minimum / centre value per sy (even, odd sy)
         const bool gather = __builtin_amdgcn_ballot_w64((d & DESC_OK) == 0) != 0;
         if (!gather) {
             const int R = sx + kfx;
             const int rsel = (R >= 0 && R < Sx) ? R : ABSROW;
-            const int b0 = ROWDATA - 2 + kfy;
+            const int b0 = ROWDATA - 2 + kfy + 4 * q;
             const uint32_t* qp = (const uint32_t*)(pre + rsel * ROWB + (b0 & ~3));
-            uint32_t q[NW + 2];
+            uint32_t qd[NE + 1];
 #pragma unroll
-            for (int i = 0; i < NW + 2; i++) q[i] = qp[i];
+            for (int i = 0; i < NE + 1; i++) qd[i] = qp[i];
             const uint32_t sh = (uint32_t)b0 & 3u;
-            uint32_t E[NW + 1], O[NW + 1];                  // v[i] = Lpre(R, kfy-2+i): E[k] = (v[4k], v[4k+2]), O[k] = (v[4k+1], v[4k+3])
+            // v[i] = Lpre(R, kfy-2+4q+i): E[k] = (v[4k], v[4k+2]), O[k] = (v[4k+1], v[4k+3])
+            uint32_t E[NE], O[NE];
 #pragma unroll
-            for (int k = 0; k <= NW; k++) {
-                const uint32_t w = __builtin_amdgcn_alignbyte(q[k + 1], q[k], sh);
+            for (int k = 0; k < NE; k++) {
+                const uint32_t w = __builtin_amdgcn_alignbyte(qd[k + 1], qd[k], sh);
                 E[k] = w & 0x00FF00FFu;
                 O[k] = (w >> 8) & 0x00FF00FFu;
             }
-            uint32_t A[NW + 1], B[NW + 1], Es[NW], Os[NW];  // pair minima a2[i] = min(v[i], v[i+1]); shifted views
+            uint32_t A[NL + 1], B[NL + 1], Es[NL], Os[NL];  // pair minima a2[i] = min(v[i], v[i+1]); shifted views
 #pragma unroll
-            for (int k = 0; k <= NW; k++) A[k] = pk_min(E[k], O[k]);
+            for (int k = 0; k <= NL; k++) A[k] = pk_min(E[k], O[k]);
 #pragma unroll
-            for (int k = 0; k < NW; k++) {
+            for (int k = 0; k < NL; k++) {
                 Es[k] = align16(E[k + 1], E[k]);            // (v[4k+2], v[4k+4])
                 Os[k] = align16(O[k + 1], O[k]);            // (v[4k+3], v[4k+5])
                 B[k] = pk_min(O[k], Es[k]);
             }
-            B[NW] = pk_min(O[NW], align16(E[NW], E[NW]));   // only its low half is used
-            uint32_t A5[NW], B5[NW];                        // a5[i] = min(v[i .. i+4]) at even / odd i
+            B[NL] = pk_min(O[NL], align16(E[NL], E[NL]));   // only its low half is used
+            uint32_t A5[NL + 1], B5[NL];                    // a5[i] = min(v[i .. i+4]) at even / odd i
 #pragma unroll
-            for (int k = 0; k < NW; k++) {
+            for (int k = 0; k < NL; k++) {
                 A5[k] = pk_min(pk_min(A[k], align16(A[k + 1], A[k])), E[k + 1]);
                 B5[k] = pk_min(pk_min(B[k], align16(B[k + 1], B[k])), O[k + 1]);
             }
+            // a5[4*NL] (low half): the second regime's last odd element.  The packed mapping never
+            // consumes it (that slot is padding); the wide one does.
+            A5[NL] = WIDE ? pk_min(pk_min(A[NL], align16(A[NL], A[NL])), E[NE - 1]) : A5[NL - 1];
             // regime B: centre sy + kfy -> window v[sy .. sy+4], centre v[sy+2]
 #pragma unroll
-            for (int k = 0; k < NW; k++) { ME[k] = A5[k]; MO[k] = B5[k]; CE[k] = Es[k]; CO[k] = Os[k]; }
+            for (int k = 0; k < NL; k++) { ME[k] = A5[k]; MO[k] = B5[k]; CE[k] = Es[k]; CO[k] = Os[k]; }
             if (__builtin_amdgcn_ballot_w64(nay != 0) != 0) {
                 // regime A (sy < nay): centre one further, window v[sy+1 .. sy+5], centre v[sy+3]
                 const uint32_t n2 = dup16((uint32_t)nay);
 #pragma unroll
-                for (int k = 0; k < NW; k++) {
-                    const uint32_t mE = opaque(pk_lt_mask((uint32_t)(4 * k) | ((uint32_t)(4 * k + 2) << 16), n2));
-                    const uint32_t mO = opaque(pk_lt_mask((uint32_t)(4 * k + 1) | ((uint32_t)(4 * k + 3) << 16), n2));
-                    const uint32_t A5s = align16(A5[k + 1 < NW ? k + 1 : k], A5[k]);   // (a5[4k+2], a5[4k+4]); the last high half is never used
+                for (int k = 0; k < NL; k++) {
+                    const uint32_t s0 = (uint32_t)(4 * (k + q));
+                    const uint32_t mE = opaque(pk_lt_mask(s0 | ((s0 + 2) << 16), n2));
+                    const uint32_t mO = opaque(pk_lt_mask((s0 + 1) | ((s0 + 3) << 16), n2));
+                    const uint32_t A5s = align16(A5[k + 1], A5[k]);              // (a5[4k+2], a5[4k+4])
                     ME[k] = bfi(mE, B5[k], A5[k]);
                     MO[k] = bfi(mO, A5s, B5[k]);
                     CE[k] = bfi(mE, Os[k], Es[k]);
@@ -380,17 +402,17 @@ __global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
             // consumed (producing lanes 2 .. Sx+1 <= 12, plus one for the second regime), and all their
             // sources lie inside the DPP row.
 #pragma unroll
-            for (int k = 0; k < 2 * NW; k++) {
-                const uint32_t v = k < NW ? ME[k] : MO[k - NW];
+            for (int k = 0; k < 2 * NL; k++) {
+                const uint32_t v = k < NL ? ME[k] : MO[k - NL];
                 const uint32_t t1 = dpp_shift0<DPP_ROW_SHR1>(v), t2 = dpp_shift0<DPP_ROW_SHL1>(v);
                 const uint32_t t3 = dpp_shift0<DPP_ROW_SHR2>(v), t4 = dpp_shift0<DPP_ROW_SHL2>(v);
                 const uint32_t h = pk_min(pk_min(v, t1), pk_min(pk_min(t2, t3), t4));
-                if (k < NW) ME[k] = h; else MO[k - NW] = h;
+                if (k < NL) ME[k] = h; else MO[k - NL] = h;
             }
             if (__builtin_amdgcn_ballot_w64(nax != 0) != 0) {
                 const bool regA = sx < nax;                  // centre row one further: take lane j+1's values
 #pragma unroll
-                for (int k = 0; k < NW; k++) {
+                for (int k = 0; k < NL; k++) {
                     const uint32_t a1 = dpp_shift0<DPP_ROW_SHL1>(ME[k]), a2 = dpp_shift0<DPP_ROW_SHL1>(MO[k]);
                     const uint32_t a3 = dpp_shift0<DPP_ROW_SHL1>(CE[k]), a4 = dpp_shift0<DPP_ROW_SHL1>(CO[k]);
                     ME[k] = regA ? a1 : ME[k];
@@ -401,8 +423,8 @@ __global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
             }
         } else {
             // gather path: the reference's tables (:46-47), 25 cells per candidate
-            int ax, ay;
-            actual(x, y, ax, ay);
+            const int rx = base == 1 ? 0 : (base == 3 ? -1 : 1), ry = base == 0 ? 0 : 1;
+            const int ay = pix / W, ax = pix - ay * W;
             const int px = clampi(mirror ? ax + rx : ax - rx, 0, W - 1), py = clampi(mirror ? ay + ry : ay - ry, 0, H - 1);
             const double* __restrict__ mvxp = a.mv + f * 2 * (size_t)a.mvW * a.mvH;
             const double* __restrict__ mvyp = mvxp + (size_t)a.mvW * a.mvH;
@@ -411,19 +433,20 @@ __global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
             tabs[j] = clampi(f64_to_i32_x86(__dadd_rn(__dadd_rn((double)j, dx), 0.5)), -3, Sx + 2);        // :47
             tabs[16 + j] = clampi(f64_to_i32_x86(__dadd_rn(__dadd_rn((double)j, dy), 0.5)), -3, Sy + 2);   // :46
             __builtin_amdgcn_wave_barrier();
-            const int cx = tabs[sxc];
+            const int cxr = tabs[sxc];
             auto rowp = [&](int tx) { return pre + ((tx >= 0 && tx < Sx) ? tx : ABSROW) * ROWB + ROWDATA; };
 #pragma unroll
-            for (int k = 0; k < NW; k++) { ME[k] = MO[k] = CE[k] = CO[k] = 0x00FF00FFu; }
+            for (int k = 0; k < NL; k++) { ME[k] = MO[k] = CE[k] = CO[k] = 0x00FF00FFu; }
 #pragma unroll
-            for (int s = 0; s < 4 * NW; s++) {
+            for (int s = 0; s < 4 * NL; s++) {
                 uint32_t ctr = 255, nb = 255;
-                if (s < Sy) {
-                    const int cy = tabs[16 + s];
-                    ctr = rowp(cx)[cy];
+                const int sy = s + 4 * q;
+                if (sy < Sy) {
+                    const int cy = tabs[16 + sy];
+                    ctr = rowp(cxr)[cy];
 #pragma unroll 1
                     for (int mm = -2; mm <= 2; mm++) {
-                        const uint8_t* rp = rowp(cx + mm) + cy;
+                        const uint8_t* rp = rowp(cxr + mm) + cy;
                         nb = min(nb, min(min((uint32_t)rp[-2], (uint32_t)rp[-1]), min(min((uint32_t)rp[0], (uint32_t)rp[1]), (uint32_t)rp[2])));
                     }
                 }
@@ -433,34 +456,37 @@ __global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
                 else       { ME[k] = (ME[k] & keep) | (nb << shv); CE[k] = (CE[k] & keep) | (ctr << shv); }
             }
         }
-        // best = min(m + P2, centre, 5x5 minimum + P1) (:50-80); L = C + best - m (:83)
-        const uint32_t jump2 = dup16(m + P2), m2 = dup16(m);
-        uint32_t LE[NW], LO[NW];
+        // best = min(m + P2, centre, 5x5 minimum + P1) (:50-80); L = C + best - m (:83).  At a path
+        // start L = C (:153 etc.): best and m forced to 0 (every other operand of the minimum is >= 0).
+        const uint32_t jump2 = start ? 0u : dup16(m + P2), m2 = start ? 0u : dup16(m);
+        uint32_t LE[NL], LO[NL];
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
+        for (int k = 0; k < NL; k++) {
             const uint32_t cE = now.c[k] & 0x00FF00FFu, cO = (now.c[k] >> 8) & 0x00FF00FFu;
             const uint32_t bE = pk_min(pk_min(jump2, CE[k]), pk_add(ME[k], P1_2));
             const uint32_t bO = pk_min(pk_min(jump2, CO[k]), pk_add(MO[k], P1_2));
-            const uint32_t lE = pk_sub(pk_add(cE, bE), m2), lO = pk_sub(pk_add(cO, bO), m2);
-            LE[k] = (start ? cE : lE) | padE[k];                                 // path start: L = C (:153 etc.)
-            LO[k] = (start ? cO : lO) | padO[k];
+            LE[k] = pk_sub(pk_add(cE, bE), m2) | padE[k];
+            LO[k] = pk_sub(pk_add(cO, bO), m2) | padO[k];
         }
         uint32_t rmin = pk_min(LE[0], LO[0]);
 #pragma unroll
-        for (int k = 1; k < NW; k++) rmin = pk_min(rmin, pk_min(LE[k], LO[k]));
+        for (int k = 1; k < NL; k++) rmin = pk_min(rmin, pk_min(LE[k], LO[k]));
         uint32_t lo = min(rmin & 0xFFFFu, rmin >> 16);
         lo = group_min_u32<16>(lo);
-        m = start ? 0u : lo;                                                     // :88; stored minimum 0 at a start (:154)
+        if (WIDE) {                                          // one line per wave: the minimum is wave-uniform
+            const uint32_t l0 = __builtin_amdgcn_readlane(lo, 0), l1 = __builtin_amdgcn_readlane(lo, 16);
+            const uint32_t l2 = __builtin_amdgcn_readlane(lo, 32), l3 = __builtin_amdgcn_readlane(lo, 48);
+            lo = min(min(l0, l1), min(l2, l3));
+        }
+        m = start ? 0u : lo;                                 // :88; stored minimum 0 at a start (:154)
         {
-            // Straight-line stores: lanes that produce no row write LDS row 14 (never read) and a dump
+            // Straight-line stores: lanes that produce nothing write LDS row 14 (never read) and a dump
             // slot in HBM.  With one store per step at a fixed place in the instruction stream the
             // wait for the prefetched loads is a counted s_waitcnt vmcnt(1), not a wait for the store.
-            int ax, ay;
-            actual(x, y, ax, ay);
-            uint32_t* dl = (uint32_t*)(cur + (is_out ? sx : 14) * ROWB + ROWDATA);
-            uint32_t* dg = (is_out && active) ? (uint32_t*)(Lf + ((size_t)ay * W + ax) * PS + (size_t)sx * RS) : a.dump;
+            uint32_t* dl = (uint32_t*)(cur + (is_out ? sx : DUMPROW) * ROWB + ROWDATA + 4 * q);
+            uint32_t* dg = (is_out && active && t < len) ? (uint32_t*)(Lf + (size_t)pix * PS + rowoff) : a.dump;
 #pragma unroll
-            for (int k = 0; k < NW; k++) {
+            for (int k = 0; k < NL; k++) {
                 const uint32_t w = LE[k] | (LO[k] << 8);
                 dl[k] = w;
                 dg[k] = w;
@@ -468,9 +494,19 @@ __global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
         uint8_t* tmp = pre; pre = cur; cur = tmp;
-        x = xn; y = yn;
-        advance(xn, yn);
+      }
     }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
+    extern __shared__ uint32_t sRows[];
+    int slot = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++)
+        if (i < a.ndirs && (int)blockIdx.x >= a.blk_begin[i]) slot = i;
+    if ((a.wide_mask >> slot) & 1) pyd_rows_agg_body<NW, true>(a, slot, sRows);
+    else                           pyd_rows_agg_body<NW, false>(a, slot, sRows);
 }
 
 // =============================================================================================

@@ -50,8 +50,16 @@ AGG = [
 ]
 
 
+@pytest.fixture(params=["0", "2"], ids=["packed", "wide-rows"])
+def wide_mode(request, monkeypatch):
+    """FSGM_PYD_WIDE: both mappings of the row-packed aggregation kernel for the horizontal lines
+    (0 = four lines per wave, 2 = one line per wave; the default picks by frame shape and batch)."""
+    monkeypatch.setenv("FSGM_PYD_WIDE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("W,H,rX,rY,P1,P2,cmax,diag,passes,adaptive,kind", AGG)
-def test_pyd_aggregate_and_wta_bit_exact(gpu_lib, oracle, W, H, rX, rY, P1, P2, cmax, diag, passes, adaptive, kind):
+def test_pyd_aggregate_and_wta_bit_exact(gpu_lib, oracle, wide_mode, W, H, rX, rY, P1, P2, cmax, diag, passes, adaptive, kind):
     Sx, Sy = 2 * rX + 1, 2 * rY + 1
     I1, I2 = synth.image_pair(W, H, 16, seed=3)
     I1 = (I1.astype(np.int32) * 3 % 256).astype(np.uint8)            # larger gradients: adaptive P2 branch taken
