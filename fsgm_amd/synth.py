@@ -99,3 +99,20 @@ def hint_map(mvW, mvH, kind="zero", seed=21, amp=3.0):
         mv[0, 1::5, 1::6] = -0.75                                     # lands in (-1, 0) near the left border
         return np.ascontiguousarray(mv)
     raise ValueError(kind)
+
+
+def vz_index_map(W, H, D, seed=11, invalid=0.08, speckles=0.04):
+    """A vz-index map like MATLAB sgm's D1 (test.m:36): smooth sub-pixel indices in [0, D-1], a share of
+    isolated outliers (speckles), NaN holes (single pixels, runs, whole rows/columns at the borders)."""
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    base = (np.sin(xx / 23.0) * np.cos(yy / 17.0) * 0.5 + 0.5) * (D - 1) * 0.6
+    base = np.round(base * 4) / 4                                   # quarter steps: exact ties in |a-b| < maxDiff
+    r = uniform_f64(seed, (H, W))
+    out = np.where(r < speckles, np.floor(uniform_f64(seed + 1, (H, W)) * (D - 1)), base)
+    hole = uniform_f64(seed + 2, (H, W)) < invalid
+    hole[:, : max(1, W // 16)] |= uniform_f64(seed + 3, (H, max(1, W // 16))) < 0.6
+    if H > 6:
+        hole[H // 3, W // 4: W // 2] = True                         # a long run inside a row
+        hole[0, :] = True                                           # a whole row: only the column pass reaches it
+    out[hole] = np.nan
+    return np.ascontiguousarray(out)

@@ -242,6 +242,58 @@ fsgm_status fsgm_pyramid_plan_download_gray(fsgm_pyramid_plan* plan, int32_t lev
 fsgm_status fsgm_pyramid_plan_time(fsgm_pyramid_plan* plan, int32_t warmup, int32_t iters, float* ms_avg);
 
 /* ------------------------------------------------------------------------------------------
+ * Post-processing  (SURVEY 8(f) N3): the MATLAB functions the evaluation script chains after SGM
+ * (test.m:45-50) -- speckle_filter.m, calc_disp_from_first.m, forward_backward_check.m,
+ * scanline_in_fill.m, vzInd2Disp.m -- one entry point per function, same argument meaning.
+ *
+ * Maps are f64 [height][width], x fastest; NaN = invalid (MATLAB's NaN).  Pd0 / normDirect are
+ * f64 [2][height][width] with plane 0 = x, Pd0 in MATLAB's 1-based pixel coordinates; O is
+ * offsetFromPosD0; n = dMax + 1 (test.m:6).  (These are the epipolar maps of calc_cost_sgm above.)
+ * ------------------------------------------------------------------------------------------ */
+/* speckle_filter.m:1 [imageFiltered, labelImage] = speckle_filter(image, maxDiff, maxSpeckleSize): every
+ * 4-connected region (neighbours joined when both valid and |a-b| < maxDiff) of fewer than
+ * maxSpeckleSize pixels becomes NaN.  labelImage (may be NULL): i32 [H][W], regions numbered in raster
+ * order of their first pixel, 0 where the input is NaN.  Defaults of the original: 2, 100. */
+fsgm_status fsgm_speckle_filter_host(const double* image, int32_t width, int32_t height, double maxDiff,
+                                     double maxSpeckleSize, double* imageFiltered, int32_t* labelImage,
+                                     int32_t device);
+/* calc_disp_from_first.m:1 D2 = calc_disp_from_first(D1, Pd0, normDirect, O, vMax, n): -1 where no pixel
+ * of D1 lands.  D1 must hold non-negative values or NaN (vz indices are): checked. */
+fsgm_status fsgm_calc_disp_from_first_host(const double* D1, int32_t width, int32_t height, const double* Pd0,
+                                           const double* normDirect, const double* O, double vMax, double n,
+                                           double* D2, int32_t device);
+/* forward_backward_check.m:1 D1 = forward_backward_check(D1, D2, Pd0, normDirect, O, vMax, n), threshold 2.0 (:6) */
+fsgm_status fsgm_forward_backward_check_host(const double* D1, const double* D2, int32_t width, int32_t height,
+                                             const double* Pd0, const double* normDirect, const double* O,
+                                             double vMax, double n, double* D1checked, int32_t device);
+/* scanline_in_fill.m:2 output = scanline_in_fill(input), one channel (test.m:49 passes a 2-D map) */
+fsgm_status fsgm_scanline_in_fill_host(const double* input, int32_t width, int32_t height, double* output,
+                                       int32_t device);
+/* vzInd2Disp.m:1 D = vzInd2Disp(w, O, vMax, n) */
+fsgm_status fsgm_vzind2disp_host(const double* w, const double* O, int32_t width, int32_t height, double vMax,
+                                 double n, double* D, int32_t device);
+/* test.m:45-50 in one call, intermediates resident in HBM:
+ *   filterD1 = speckle_filter(D1, 2, 100); filterD2 = calc_disp_from_first(filterD1, ...);
+ *   filterD1 = forward_backward_check(filterD1, filterD2, ...); filterD1 = speckle_filter(filterD1, dMax, rows*cols/10);
+ *   filterD1 = scanline_in_fill(filterD1); disp = vzInd2Disp(filterD1, O, vMax, n)
+ * filterD2 and disp may be NULL. */
+fsgm_status fsgm_epi_postprocess_host(const double* D1, int32_t width, int32_t height, const double* Pd0,
+                                      const double* normDirect, const double* O, double vMax, double n,
+                                      double dMax, double* filterD1, double* filterD2, double* disp,
+                                      int32_t device);
+
+typedef struct fsgm_post_plan fsgm_post_plan;
+fsgm_status fsgm_post_plan_create(fsgm_post_plan** plan, int32_t width, int32_t height, int32_t device);
+void        fsgm_post_plan_destroy(fsgm_post_plan* plan);
+/* host -> HBM; any pointer may be NULL to keep what the plan holds */
+fsgm_status fsgm_post_plan_upload(fsgm_post_plan* plan, const double* D1, const double* Pd0,
+                                  const double* normDirect, const double* O);
+fsgm_status fsgm_post_plan_run(fsgm_post_plan* plan, double vMax, double n, double dMax);   /* test.m:45-50, asynchronous */
+fsgm_status fsgm_post_plan_download(fsgm_post_plan* plan, double* filterD1, double* filterD2, double* disp);
+fsgm_status fsgm_post_plan_time(fsgm_post_plan* plan, double vMax, double n, double dMax, int32_t warmup,
+                                int32_t iters, float* ms_avg);
+
+/* ------------------------------------------------------------------------------------------
  * calc_pyd_cost_sgm_ng  (calc_pyd_cost_sgm_ng.cpp:448-523; same 8-argument list as the call in
  * ng_sgm.m:20, no caller in the reference tree)
  * ------------------------------------------------------------------------------------------ */

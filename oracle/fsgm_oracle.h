@@ -99,6 +99,18 @@ void fsgm_oracle_pyramidal_sgm(double* mv, uint32_t* minC, double** mvPyd,
                                int P1, int P2, int aggHalfWinSize, int verSearchHalfWinSize, int horSearchHalfWinSize,
                                int enableDiagonal, int totalPass, int adaptiveP2);
 
+/* ---- post-processing chain of test.m:45-50 (fsgm_oracle_post.cpp): maps f64 [H][W], NaN = invalid ---- */
+void fsgm_oracle_vzind2disp(double* D, const double* w, const double* O, int n_px, double vMax, double n);   /* vzInd2Disp.m */
+void fsgm_oracle_speckle_filter(double* out, int32_t* labels_out, const double* image, int W, int H,
+                                double maxDiff, double maxSpeckleSize);                                     /* speckle_filter.m */
+void fsgm_oracle_calc_disp_from_first(double* D2, const double* D1, int W, int H, const double* Pd0,
+                                      const double* nd, const double* O, double vMax, double n);            /* calc_disp_from_first.m */
+void fsgm_oracle_forward_backward_check(double* out, const double* D1, const double* D2, int W, int H,
+                                        const double* Pd0, const double* nd, const double* O, double vMax, double n);
+void fsgm_oracle_scanline_in_fill(double* out, const double* in, int W, int H);                             /* scanline_in_fill.m */
+void fsgm_oracle_postprocess(double* filterD1, double* filterD2, double* disp, const double* D1, int W, int H,
+                             const double* Pd0, const double* nd, const double* O, double vMax, double n, double dMax);
+
 /* ---- neighbour-guided candidate-list variant: calc_pyd_cost_sgm_ng.cpp ---- */
 typedef struct { int32_t mvx, mvy, cost; } fsgm_oracle_cand;   /* calc_pyd_cost_sgm_ng.cpp:32-37 */
 

@@ -196,6 +196,61 @@ def pyramidal_sgm(I0, I1, numPyd=5, P1=6, P2=32, aggHalfWinSize=2, ver=5, hor=5,
     return mv, minC, lv
 
 
+# ---------------------------------------------------------------- post-processing (test.m:45-50)
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def vzind2disp(w, O, vMax, n):
+    w, O = _f64(w), _f64(O)
+    D = np.zeros_like(w)
+    lib().fsgm_oracle_vzind2disp(_p(D), _p(w), _p(O), int(w.size), C.c_double(vMax), C.c_double(n))
+    return D
+
+
+def speckle_filter(image, maxDiff=2, maxSpeckleSize=100):
+    image = _f64(image)
+    H, W = image.shape
+    out = np.zeros_like(image)
+    labels = np.zeros((H, W), np.int32)
+    lib().fsgm_oracle_speckle_filter(_p(out), _p(labels), _p(image), W, H, C.c_double(maxDiff), C.c_double(maxSpeckleSize))
+    return out, labels
+
+
+def calc_disp_from_first(D1, Pd0, nd, O, vMax, n):
+    D1 = _f64(D1)
+    H, W = D1.shape
+    D2 = np.zeros_like(D1)
+    lib().fsgm_oracle_calc_disp_from_first(_p(D2), _p(D1), W, H, _p(_f64(Pd0)), _p(_f64(nd)), _p(_f64(O)), C.c_double(vMax), C.c_double(n))
+    return D2
+
+
+def forward_backward_check(D1, D2, Pd0, nd, O, vMax, n):
+    D1 = _f64(D1)
+    H, W = D1.shape
+    out = np.zeros_like(D1)
+    lib().fsgm_oracle_forward_backward_check(_p(out), _p(D1), _p(_f64(D2)), W, H, _p(_f64(Pd0)), _p(_f64(nd)), _p(_f64(O)),
+                                             C.c_double(vMax), C.c_double(n))
+    return out
+
+
+def scanline_in_fill(a):
+    a = _f64(a)
+    H, W = a.shape
+    out = np.zeros_like(a)
+    lib().fsgm_oracle_scanline_in_fill(_p(out), _p(a), W, H)
+    return out
+
+
+def postprocess(D1, Pd0, nd, O, vMax, n, dMax):
+    D1 = _f64(D1)
+    H, W = D1.shape
+    f1, f2, disp = np.zeros_like(D1), np.zeros_like(D1), np.zeros_like(D1)
+    lib().fsgm_oracle_postprocess(_p(f1), _p(f2), _p(disp), _p(D1), W, H, _p(_f64(Pd0)), _p(_f64(nd)), _p(_f64(O)),
+                                  C.c_double(vMax), C.c_double(n), C.c_double(dMax))
+    return f1, f2, disp
+
+
 # ---------------------------------------------------------------- calc_pyd_cost_sgm_ng
 CAND = np.dtype([("mvx", np.int32), ("mvy", np.int32), ("cost", np.int32)])
 

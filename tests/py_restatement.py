@@ -608,3 +608,116 @@ def pyramidal_sgm(I0, I1, numPyd, P1=6, P2=32, agg=2, ver=5, hor=5, diag=1, tota
         if l > 0:
             mvPre = 2 * np.stack([resize2_nearest(cur[0]), resize2_nearest(cur[1])])  # :72
     return levels[0], minC, levels
+
+
+# =====================================================================================
+# post-processing (test.m:45-50) -- second restatements.  speckle_filter: NOT a flood fill like the
+# original and the oracle but label propagation to a fixed point (regions = connected components of
+# the symmetric "valid and |a-b| < maxDiff" relation); the rest literal loops in MATLAB's 1-based terms.
+# =====================================================================================
+def speckle_filter(image, maxDiff, maxSpeckleSize):     # speckle_filter.m
+    H, W = image.shape
+    valid = ~np.isnan(image)
+    lab = np.where(valid, np.arange(H * W).reshape(H, W), -1)
+    right = np.zeros((H, W), bool)
+    down = np.zeros((H, W), bool)
+    with np.errstate(invalid="ignore"):
+        right[:, :-1] = valid[:, :-1] & valid[:, 1:] & (np.abs(image[:, :-1] - image[:, 1:]) < maxDiff)
+        down[:-1, :] = valid[:-1, :] & valid[1:, :] & (np.abs(image[:-1, :] - image[1:, :]) < maxDiff)
+    while True:                                         # every pixel takes the smallest label among itself and its joined neighbours
+        new = lab.copy()
+        r, d = right[:, :-1], down[:-1, :]
+        new[:, :-1][r] = np.minimum(new[:, :-1][r], lab[:, 1:][r])
+        new[:, 1:][r] = np.minimum(new[:, 1:][r], lab[:, :-1][r])
+        new[:-1, :][d] = np.minimum(new[:-1, :][d], lab[1:, :][d])
+        new[1:, :][d] = np.minimum(new[1:, :][d], lab[:-1, :][d])
+        if np.array_equal(new, lab):
+            break
+        lab = new
+    out = image.copy()
+    labels = np.zeros((H, W), np.int32)
+    roots = np.unique(lab[valid])                       # ascending = raster order of each region's first pixel
+    for k, r in enumerate(roots):
+        region = lab == r
+        labels[region] = k + 1
+        if region.sum() < maxSpeckleSize:
+            out[region] = np.nan
+    return out, labels
+
+
+def vzInd2Disp(w, O, vMax, n):                          # vzInd2Disp.m
+    vzRatio = w / n * vMax
+    return O * (vzRatio / (1 - vzRatio))
+
+
+def calc_disp_from_first(D1, Pd0, nd, O, vMax, n):      # calc_disp_from_first.m
+    rows, cols = D1.shape
+    D2 = -np.ones((rows, cols))
+    for j in range(1, rows + 1):
+        for i in range(1, cols + 1):
+            v = D1[j - 1, i - 1]
+            disp = vzInd2Disp(v, O[j - 1, i - 1], vMax, n)
+            p2 = (Pd0[0, j - 1, i - 1] + disp * nd[0, j - 1, i - 1], Pd0[1, j - 1, i - 1] + disp * nd[1, j - 1, i - 1])
+            if np.isnan(p2[0]) or np.isnan(p2[1]):
+                continue
+            sx0, sy0 = np.floor(p2[0]), np.floor(p2[1])
+            for sx, sy in ((sx0, sy0), (sx0 + 1, sy0), (sx0, sy0 + 1), (sx0 + 1, sy0 + 1)):
+                if 1 <= sx <= cols and 1 <= sy <= rows:
+                    t = D2[int(sy) - 1, int(sx) - 1]
+                    if t == 0 or t < v:
+                        D2[int(sy) - 1, int(sx) - 1] = v
+    return D2
+
+
+def forward_backward_check(D1, D2, Pd0, nd, O, vMax, n):   # forward_backward_check.m
+    rows, cols = D1.shape
+    out = D1.copy()
+    rnd = lambda v: np.floor(abs(v) + 0.5) * (1 if v >= 0 else -1)       # MATLAB round: half away from zero
+    for j in range(rows):
+        for i in range(cols):
+            v = out[j, i]
+            if np.isnan(v):
+                continue
+            disp = vzInd2Disp(v, O[j, i], vMax, n)
+            px, py = rnd(Pd0[0, j, i] + disp * nd[0, j, i]), rnd(Pd0[1, j, i] + disp * nd[1, j, i])
+            if px < 1 or px > cols or py < 1 or py > rows:
+                out[j, i] = np.nan
+                continue
+            d2 = D2[int(py) - 1, int(px) - 1]
+            if d2 == -1 or abs(v - d2) > 2.0:
+                out[j, i] = np.nan
+    return out
+
+
+def scanline_in_fill(a):                                # scanline_in_fill.m, literal
+    a = a.copy()
+    H, W = a.shape
+    for v in range(H):
+        count = 0
+        for u in range(1, W + 1):
+            if not np.isnan(a[v, u - 1]):
+                if count >= 1:
+                    u1, u2 = u - count, u - 1
+                    if u1 > 1 and u2 < W:
+                        a[v, u1 - 1:u2] = min(a[v, u1 - 2], a[v, u2])
+                count = 0
+            else:
+                count += 1
+        for u in range(W):
+            if not np.isnan(a[v, u]):
+                a[v, :u] = a[v, u]
+                break
+        for u in range(W - 1, -1, -1):
+            if not np.isnan(a[v, u]):
+                a[v, u + 1:] = a[v, u]
+                break
+    for u in range(W):
+        for v in range(H):
+            if not np.isnan(a[v, u]):
+                a[:v, u] = a[v, u]
+                break
+        for v in range(H - 1, -1, -1):
+            if not np.isnan(a[v, u]):
+                a[v + 1:, u] = a[v, u]
+                break
+    return a
