@@ -58,10 +58,22 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const double* __restrict
 
 __global__ __launch_bounds__(256) void ccl_count_kernel(const double* __restrict__ img, int32_t* parent, int32_t* size, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || isnan(img[i])) return;
-    const int r = ccl_find(parent, i);
-    parent[i] = r;                                               // only ever replaces an ancestor by the root
-    atomicAdd(&size[r], 1);                                      // :48 regionPixelNum
+    const bool valid = i < n && !isnan(img[i]);
+    int r = -1;
+    if (valid) {
+        r = ccl_find(parent, i);
+        parent[i] = r;                                           // only ever replaces an ancestor by the root
+    }
+    // :48 regionPixelNum.  Neighbouring pixels mostly share a root, and one big region would otherwise
+    // serialise hundreds of thousands of atomics on a single counter: add once per distinct root per wave.
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int lr = __builtin_amdgcn_readlane(r, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(valid && r == lr) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size[lr], __popcll(same));
+        todo &= ~same;
+    }
 }
 
 __global__ __launch_bounds__(256) void speckle_apply_kernel(const double* __restrict__ img, double* __restrict__ out,
