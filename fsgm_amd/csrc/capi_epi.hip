@@ -35,7 +35,8 @@ struct fsgm_epi_plan {
     // fused-sweep aggregation (epi_sweep.hip): horizontal path costs, u16 sums, block-boundary states
     // (see enqueue(): horizontal kernel on stream_h; the frames split into two lanes that sweep
     // down then up on stream / stream_b)
-    uint8_t *dLh = nullptr, *dX = nullptr, *dXup = nullptr, *dState = nullptr;
+    uint8_t *dLh = nullptr, *dX = nullptr, *dXup = nullptr, *dState = nullptr, *dCkpt = nullptr;
+    int lh_planes = 1;                   // 1: horizontal pair as its excess sum X_h (hpair kernels); 2: two path volumes
     uint4* dRec = nullptr;
     uint16_t* dS0 = nullptr;
     size_t state_stride = 0;
@@ -102,7 +103,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dState, p->dRec, p->dS0};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dState, p->dCkpt, p->dRec, p->dS0};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -243,7 +244,11 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     if (p->dX) return FSGM_OK;
     const size_t B = p->batch;
     p->state_stride = sweep_state_bytes(p->W, p->D);
-    FSGM_HIP(hipMalloc((void**)&p->dLh, B * p->N * 2));
+    // FSGM_EPI_HPAIR: 1 = horizontal pair as one excess sum by checkpoint-and-recompute (default),
+    // 0 = the two path volumes of the per-direction kernel (A/B switch)
+    { const char* e = getenv("FSGM_EPI_HPAIR"); p->lh_planes = (e && *e && atoi(e) == 0) ? 2 : 1; }
+    FSGM_HIP(hipMalloc((void**)&p->dLh, B * p->N * p->lh_planes));
+    if (p->lh_planes == 1) FSGM_HIP(hipMalloc((void**)&p->dCkpt, B * hpair_ckpt_bytes(p->W, p->H, p->D)));
     FSGM_HIP(hipMalloc((void**)&p->dState, 2 * B * p->state_stride));
     FSGM_HIP(hipMalloc((void**)&p->dRec, B * p->NP * sizeof(uint4)));
     FSGM_HIP(hipMalloc((void**)&p->dS0, B * p->NP * sizeof(uint16_t)));
@@ -282,11 +287,19 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         FSGM_HIP(hipEventRecord(p->ev_fork, p->stream));
         FSGM_HIP(hipStreamWaitEvent(p->stream_h, p->ev_fork, 0));
         if (nB) FSGM_HIP(hipStreamWaitEvent(p->stream_b, p->ev_fork, 0));
-        AggArgs a;                                   // the two horizontal paths: per-direction kernel, 2 slots
-        a.C = p->dC; a.L = p->dLh;
-        a.c_frame_stride = p->N; a.l_frame_stride = p->N * 2; a.l_dir_stride = p->N;
-        a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
-        launch_aggregate(p->stream_h, a, 2, p->batch, AGG_PACKED_NOWRAP);
+        if (p->lh_planes == 1) {                     // the two horizontal paths as one excess sum X_h
+            HpairArgs h;
+            h.C = p->dC; h.c_frame_stride = p->N; h.Xh = p->dLh; h.xh_frame_stride = p->N;
+            h.ckpt = p->dCkpt; h.ckpt_frame_stride = hpair_ckpt_bytes(p->W, p->H, p->D);
+            h.W = p->W; h.H = p->H; h.D = p->D; h.P1 = p->P1; h.P2 = p->P2;
+            launch_hpair(p->stream_h, h, p->batch);
+        } else {                                     // per-direction kernel, 2 slots
+            AggArgs a;
+            a.C = p->dC; a.L = p->dLh;
+            a.c_frame_stride = p->N; a.l_frame_stride = p->N * 2; a.l_dir_stride = p->N;
+            a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
+            launch_aggregate(p->stream_h, a, 2, p->batch, AGG_PACKED_NOWRAP);
+        }
         FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
         for (int lane = 0; lane < 2; lane++) {
             const int f0 = lane ? nA : 0, nf = lane ? nB : nA;
@@ -295,7 +308,8 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
             SweepArgs w;
             w.C = p->dC + (size_t)f0 * p->N; w.c_frame_stride = p->N;
             w.X = p->dX + (size_t)f0 * p->N; w.x_frame_stride = p->N;
-            w.Lh = p->dLh + (size_t)f0 * p->N * 2; w.lh_frame_stride = p->N * 2; w.lh_dir_stride = p->N;
+            w.Lh = p->dLh + (size_t)f0 * p->N * p->lh_planes; w.lh_frame_stride = p->N * p->lh_planes; w.lh_dir_stride = p->N;
+            w.lh_planes = p->lh_planes;
             w.rec = p->dRec + (size_t)f0 * p->NP; w.s0 = p->dS0 + (size_t)f0 * p->NP;
             w.state_in = w.state_out = p->dState + (size_t)2 * f0 * p->state_stride;
             w.state_frame_stride = p->state_stride;
@@ -443,7 +457,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         SweepArgs w;
         w.C = p->dC + (size_t)f * p->N; w.c_frame_stride = p->N;
         w.X = p->dXup; w.x_frame_stride = p->N;
-        w.Lh = nullptr; w.lh_frame_stride = 0; w.lh_dir_stride = 0; w.rec = nullptr; w.s0 = nullptr;
+        w.Lh = nullptr; w.lh_frame_stride = 0; w.lh_dir_stride = 0; w.lh_planes = p->lh_planes; w.rec = nullptr; w.s0 = nullptr;
         w.state_in = w.state_out = p->dState + (size_t)2 * f * p->state_stride;   // idle now: scratch for one frame
         w.state_frame_stride = p->state_stride;
         w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
@@ -455,7 +469,8 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
         SweepSumArgs q;
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX + (size_t)f * p->N; q.Xup = p->dXup; q.v_frame_stride = p->N;
-        q.Lh = p->dLh + (size_t)f * p->N * 2; q.lh_frame_stride = p->N * 2; q.lh_dir_stride = p->N; q.Sdbg = p->dS;
+        q.Lh = p->dLh + (size_t)f * p->N * p->lh_planes; q.lh_frame_stride = p->N * p->lh_planes; q.lh_dir_stride = p->N;
+        q.lh_planes = p->lh_planes; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));

@@ -50,8 +50,9 @@ struct SweepArgs {
     size_t c_frame_stride;
     uint8_t* X;               // [frames] u8 excess sums: written by modes 0/1, read (the down sweep's) by mode 2
     size_t x_frame_stride;
-    const uint8_t* Lh;        // mode 2: [frames][2] horizontal path costs (from the left, from the right)
-    size_t lh_frame_stride, lh_dir_stride;
+    const uint8_t* Lh;        // mode 2: horizontal pair, lh_planes = 2: [frames][2] path costs (from the left, from the
+    size_t lh_frame_stride, lh_dir_stride;    // right); lh_planes = 1: [frames] their excess sum X_h (hpair kernels)
+    int lh_planes;
     uint4* rec;               // mode 2: [frames][NP] {best, minC, S[best-1], S[best+1]}
     uint16_t* s0;             // mode 2: [frames][NP] S[0] of every pixel
     const uint8_t* state_in;  // [frames][3][W][D] normalised path states of the row above this block
@@ -67,9 +68,21 @@ struct SweepSumArgs {          // what wta_sweep_kernel adds up (all u8 volumes,
     const uint8_t* Xdn;       // excess sums of the down sweep
     const uint8_t* Xup;       // excess sums of the up sweep
     size_t v_frame_stride;
-    const uint8_t* Lh;        // [frames][2] horizontal path costs (from the left, from the right)
+    const uint8_t* Lh;        // [frames][2] horizontal path costs (from the left, from the right), or [frames] X_h
     size_t lh_frame_stride, lh_dir_stride;
+    int lh_planes;            // 2 or 1, as in SweepArgs
     uint32_t* Sdbg;           // optional natural-order u32 dump of S [frames][NP][D]
+};
+
+struct HpairArgs {             // horizontal pair as one excess sum (epi_sweep.hip, hpair kernels)
+    const uint8_t* C;         // [frames] cost volumes
+    size_t c_frame_stride;
+    uint8_t* Xh;              // [frames] u8: (L_left - C) + (L_right - C)
+    size_t xh_frame_stride;
+    uint8_t* ckpt;            // [frames][H][ntiles-1][D] normalised from-the-right states at the tile boundaries
+    size_t ckpt_frame_stride;
+    int W, H, D;
+    int P1, P2;
 };
 
 struct FbArgs {                // forward-backward check (calc_cost_sgm.cpp:429-536)
@@ -94,6 +107,8 @@ void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
 int    sweep_rows_per_launch(int D);
 size_t sweep_state_bytes(int W, int D);   // one state buffer of one frame
 void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode);   // 0 down, 1 up, 2 up + fused WTA
+size_t hpair_ckpt_bytes(int W, int H, int D);               // per frame
+void launch_hpair(hipStream_t st, const HpairArgs& a, int frames);
 void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames);
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);
 void launch_fb_check(hipStream_t st, const FbArgs& a, int frames);

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
             const uint32_t off = vox_off(gxc, y);
             curX = *(const uint4*)(Xf + off);
             curL0 = *(const uint4*)(Lhf + off);
-            curL1 = *(const uint4*)(Lhf + a.lh_dir_stride + off);
+            if (a.lh_planes == 2) curL1 = *(const uint4*)(Lhf + a.lh_dir_stride + off);
         }
         uint32_t CE[4], CO[4], XE[4], XO[4], SE[4], SO[4];
         unpack16(cOwn, CE, CO);
@@ -240,16 +240,20 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
             if (own_ok) *(uint4*)(Xf + vox_off(gx, y)) = pack16(SE, SO);
         } else {
             // S = X_up (registers) + X_dn + 6*C + from-the-left + from-the-right, all at this pixel
+            // (lh_planes = 1: the horizontal pair arrives as its excess sum X_h, so 8*C)
             uint32_t E2[4], O2[4];
+            const uint32_t nC = a.lh_planes == 2 ? 6u : 8u;
             unpack16(curX, E2, O2);                                               // X_dn
 #pragma unroll
-            for (int q = 0; q < 4; q++) { SE[q] += E2[q] + 6u * CE[q]; SO[q] += O2[q] + 6u * CO[q]; }
+            for (int q = 0; q < 4; q++) { SE[q] += E2[q] + nC * CE[q]; SO[q] += O2[q] + nC * CO[q]; }
             unpack16(curL0, E2, O2);
 #pragma unroll
             for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
-            unpack16(curL1, E2, O2);
+            if (a.lh_planes == 2) {
+                unpack16(curL1, E2, O2);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
+                for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
+            }
             // WTA: first minimum over d (:263-271) via (S << 8 | d) keys
             uint32_t key = 0xFFFFFFFFu;
             uint32_t* row = sRow + (size_t)(tid / LPP) * (D / 2) + j * 8;
@@ -336,8 +340,9 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
     const uint8_t* Lh = q.Lh + f * q.lh_frame_stride;
     uint32_t E[4], O[4], E2[4], O2[4];
     unpack16(*(const uint4*)(q.C + f * q.v_frame_stride + bo), E, O);
+    const uint32_t nC = q.lh_planes == 2 ? 6u : 8u;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { E[k] *= 6u; O[k] *= 6u; }
+    for (int k = 0; k < 4; k++) { E[k] *= nC; O[k] *= nC; }
     unpack16(*(const uint4*)(q.Xdn + f * q.v_frame_stride + bo), E2, O2);
 #pragma unroll
     for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
@@ -347,9 +352,11 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
     unpack16(*(const uint4*)(Lh + bo), E2, O2);
 #pragma unroll
     for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
-    unpack16(*(const uint4*)(Lh + q.lh_dir_stride + bo), E2, O2);
+    if (q.lh_planes == 2) {
+        unpack16(*(const uint4*)(Lh + q.lh_dir_stride + bo), E2, O2);
 #pragma unroll
-    for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
+        for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
+    }
 
     uint32_t key = 0xFFFFFFFFu;
     uint32_t* row = sS + (size_t)(tid / LPP) * (D / 2) + j * 8;
@@ -376,10 +383,145 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
             if (best + 1 < (uint32_t)D) c1 = srow[best + 1];
             else if (p + 1 < NP) {                                           // next pixel's d=0 (:296)
                 const size_t nb = f * q.v_frame_stride + (size_t)(p + 1) * D;
-                c1 = 6u * q.C[nb] + q.Xdn[nb] + q.Xup[nb] + Lh[(size_t)(p + 1) * D] + Lh[q.lh_dir_stride + (size_t)(p + 1) * D];
+                c1 = nC * q.C[nb] + q.Xdn[nb] + q.Xup[nb] + Lh[(size_t)(p + 1) * D] +
+                     (q.lh_planes == 2 ? (uint32_t)Lh[q.lh_dir_stride + (size_t)(p + 1) * D] : 0u);
             }
         }
         wta_finish(a, f, p, best, minc, c_1, c1);
+    }
+}
+
+// =============================================================================================
+// Horizontal pair as ONE excess sum  X_h = (L_left - C) + (L_right - C)  (<= 2*P2, one byte).
+// The two horizontal paths (calc_cost_sgm.cpp:183-192 and its pass-1 mirror) run in opposite
+// directions along a row, so their values for a pixel exist at different times; writing both path
+// volumes and reading them back in the final sweep costs 6 B per voxel (C twice, 2 writes, 2 reads).
+// Checkpoint-and-recompute brings that to ~4.25 B:
+//   pass A (hpair_ckpt_kernel)  right -> left, keeps nothing but the normalised from-the-right state at
+//          every HP_TC-th column (1/HP_TC B per voxel);
+//   pass B (hpair_sum_kernel)   left -> right in tiles of HP_TC columns: the tile's from-the-right
+//          excesses are recomputed from the checkpoint on its right edge into registers, then the
+//          from-the-left path crosses the tile, adds them and stores X_h.  The tile's C stays in
+//          registers between the two.
+// The final sweep then adds X_h + 8*C instead of L_left + L_right + 6*C.  Same lane layout as
+// agg_packed_kernel: LPP lanes x 16 d per pixel, 64/LPP rows per wave.
+// =============================================================================================
+constexpr int HP_TC = 8;
+
+template <int LPP>
+__global__ __launch_bounds__(256) void hpair_ckpt_kernel(HpairArgs a) {
+    constexpr int PXW = 64 / LPP, D = LPP * 16, PF = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / LPP, j = lane % LPP;
+    const int W = a.W, H = a.H;
+    const int lg = (int)blockIdx.x * 4 + wave;
+    if (lg * PXW >= H) return;                                  // wave-uniform
+    const int l = min(lg * PXW + g, H - 1);                     // rows past the last redo the last (same bytes, same addresses)
+    const int NT = (W + HP_TC - 1) / HP_TC;
+    if (NT < 2) return;                                         // a single tile starts at the border: no checkpoint
+    const size_t f = blockIdx.y;
+    const uint8_t* __restrict__ Crow = a.C + f * a.c_frame_stride + ((size_t)l * W) * D + (size_t)j * 16;
+    uint8_t* __restrict__ Krow = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * (NT - 1)) * D + (size_t)j * 16;
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
+    uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};
+    auto load_c = [&](int x) -> uint4 { return *(const uint4*)(Crow + (size_t)max(x, 0) * D); };
+    uint4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) ring[i] = load_c(W - 1 - i);
+    const int last = HP_TC;                                     // the leftmost checkpoint column
+    for (int x0 = W - 1; x0 >= last; x0 -= PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const int x = x0 - i;
+            const uint4 cw = ring[i];
+            ring[i] = load_c(x - PF);
+            uint32_t CE[4], CO[4], XE[4], XO[4];
+            unpack16(cw, CE, CO);
+            step_norm<LPP>(LE, LO, CE, CO, XE, XO, x == W - 1, P1pk, P2pk, j);
+            // columns below `last` in the final group are computed but not needed; x >= 0 always holds there
+            if (x >= last && (x % HP_TC) == 0) *(uint4*)(Krow + (size_t)(x / HP_TC - 1) * D) = pack16(LE, LO);
+        }
+    }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void hpair_sum_kernel(HpairArgs a) {
+    constexpr int PXW = 64 / LPP, D = LPP * 16, TC = HP_TC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / LPP, j = lane % LPP;
+    const int W = a.W, H = a.H;
+    const int lg = (int)blockIdx.x * 4 + wave;
+    if (lg * PXW >= H) return;
+    const int l = min(lg * PXW + g, H - 1);
+    const int NT = (W + TC - 1) / TC;
+    const size_t f = blockIdx.y;
+    const uint8_t* __restrict__ Crow = a.C + f * a.c_frame_stride + ((size_t)l * W) * D + (size_t)j * 16;
+    uint8_t* __restrict__ Xrow = a.Xh + f * a.xh_frame_stride + ((size_t)l * W) * D + (size_t)j * 16;
+    const uint8_t* __restrict__ Krow = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * max(NT - 1, 1)) * D + (size_t)j * 16;
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
+    uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};          // from-the-left state, carried across tiles
+    auto load_c = [&](int x) -> uint4 { return *(const uint4*)(Crow + (size_t)min(x, W - 1) * D); };
+    auto load_k = [&](int t) -> uint4 { return *(const uint4*)(Krow + (size_t)min(t, max(NT - 2, 0)) * D); };
+    uint4 cT[TC], cN[TC], kT = load_k(0), kN;
+#pragma unroll
+    for (int c = 0; c < TC; c++) cT[c] = load_c(c);
+    for (int t = 0; t < NT; t++) {
+        const int xb = t * TC;
+#pragma unroll
+        for (int c = 0; c < TC; c++) cN[c] = load_c(xb + TC + c);      // next tile, in flight while this one computes
+        kN = load_k(t + 1);
+        // from the right, through the tile: columns past the image come first and are wiped by the path
+        // start at x = W-1 (:152-180); a tile inside the image starts from its checkpoint
+        uint32_t RE[4], RO[4];
+        unpack16(kT, RE, RO);
+        uint4 exR[TC];
+#pragma unroll
+        for (int c = TC - 1; c >= 0; c--) {
+            const int x = xb + c;
+            uint32_t CE[4], CO[4], XE[4], XO[4];
+            unpack16(cT[c], CE, CO);
+            step_norm<LPP>(RE, RO, CE, CO, XE, XO, x >= W - 1, P1pk, P2pk, j);
+            exR[c] = pack16(XE, XO);
+        }
+        // from the left, adding the two excesses
+#pragma unroll
+        for (int c = 0; c < TC; c++) {
+            const int x = xb + c;
+            uint32_t CE[4], CO[4], XE[4], XO[4], E2[4], O2[4];
+            unpack16(cT[c], CE, CO);
+            step_norm<LPP>(LE, LO, CE, CO, XE, XO, x == 0, P1pk, P2pk, j);
+            unpack16(exR[c], E2, O2);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { XE[q] += E2[q]; XO[q] += O2[q]; }
+            if (x < W) *(uint4*)(Xrow + (size_t)x * D) = pack16(XE, XO);
+        }
+#pragma unroll
+        for (int c = 0; c < TC; c++) cT[c] = cN[c];
+        kT = kN;
+    }
+}
+
+size_t hpair_ckpt_bytes(int W, int H, int D) {
+    const int NT = (W + HP_TC - 1) / HP_TC;
+    return (size_t)H * (size_t)(NT > 1 ? NT - 1 : 1) * D;
+}
+
+template <int LPP>
+static void launch_hpair_t(hipStream_t st, const HpairArgs& a, int frames) {
+    constexpr int PXW = 64 / LPP;
+    dim3 grid((a.H + 4 * PXW - 1) / (4 * PXW), frames);
+    hipLaunchKernelGGL(hpair_ckpt_kernel<LPP>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(hpair_sum_kernel<LPP>, grid, dim3(256), 0, st, a);
+}
+
+void launch_hpair(hipStream_t st, const HpairArgs& a, int frames) {
+    switch (agg_packed_lpp(a.D)) {
+        case 1: launch_hpair_t<1>(st, a, frames); break;
+        case 2: launch_hpair_t<2>(st, a, frames); break;
+        case 4: launch_hpair_t<4>(st, a, frames); break;
+        case 8: launch_hpair_t<8>(st, a, frames); break;
+        case 16: launch_hpair_t<16>(st, a, frames); break;
+        default: break;
     }
 }
 
