@@ -24,7 +24,7 @@ P1, P2, VMAX = 6, 64, 0.3
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM/fabric bytes per voxel of the sweep pipeline from rocprofv3 PMC passes (FETCH_SIZE doubled as
 # MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, + WRITE_SIZE), profiles/r01_pmc_traffic.md
-TRAFFIC_BYTES_PER_VOXEL = 11.4
+TRAFFIC_BYTES_PER_VOXEL = 9.65
 
 
 def cpu_baseline(sample_rows=48):
@@ -207,10 +207,11 @@ def main():
             "config": {"workload": "KITTI 1242x375 D=128, 8 paths, aggregation stage (C resident in HBM -> bestD/minC)",
                        "frames_per_gpu": B, "P1": P1, "P2": P2, "kernel": plan.kernel_name,
                        "step": "aggregate(8 paths) + sum/WTA/subpixel", "sharding": "frames, no collective"},
-            # the aggregation is one stage of three kernel types that run concurrently on three
-            # streams (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane, agg_packed_kernel<8>
-            # for the horizontal pair): the roofline is taken over the stage, HIP events fork->join
-            "roofline": {"bound": "hbm", "kernel": "aggregation stage: sweep_kernel<8,0> + sweep_kernel<8,2> + agg_packed_kernel<8,false>(2 paths)",
+            # the aggregation is one stage of four kernel types that run concurrently on three streams
+            # (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane; hpair_ckpt_kernel<8> +
+            # hpair_sum_kernel<8> for the horizontal pair): the roofline is taken over the stage, HIP
+            # events fork->join
+            "roofline": {"bound": "hbm", "kernel": "aggregation stage: sweep_kernel<8,0> + sweep_kernel<8,2> + hpair_ckpt_kernel<8> + hpair_sum_kernel<8>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES_PER_VOXEL * B * W * H * D if plan.kernel_name.startswith("sweep") else None,
                          "algorithmic_bytes": alg_bytes_launch, "stage_ms": agg_ms, "finish_ms": wta_ms},

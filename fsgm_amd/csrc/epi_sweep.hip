@@ -6,19 +6,22 @@
 // (+1,+1) and from above-right (-1,+1), calc_cost_sgm.cpp:193-226 -- are computed TOGETHER for the
 // same pixel, so C is read once per sweep and only their sum leaves the chip:
 //
-//   horizontal kernel (agg_packed_kernel, 2 slots)   C -> L_left, L_right                      (u8)
+//   hpair kernels           C -> X_h  = (L_left - C) + (L_right - C), the two horizontal paths      (u8)
+//                           (checkpoint-and-recompute, see the hpair section below)
 //   down sweep   (MODE 0)   C -> X_dn = sum over the three pass-0 paths from above of (L_r - C)  (u8)
 //   final sweep  (MODE 2)   on the point-mirrored frame (pass 1): its own three paths, then in
-//                           registers S = X_up + X_dn + 6*C + L_left + L_right and the WTA;
+//                           registers S = X_up + X_dn + X_h + 8*C and the WTA;
 //                           writes one 18-byte record per PIXEL
 //   sweep_finish_kernel     parabola / vz->disparity from the records -> bestD, minC
 //
 // Every path cost satisfies C <= L_r <= C + P2 when nothing wraps, so the EXCESS L_r - C of three
-// paths fits a byte whenever 3*P2 <= 255 (the reference uses P2 = 64 and 32): X_dn costs 1 B per
-// voxel, and neither X_up nor S (u32 in the reference) ever reaches HBM.  10 B per voxel by design
-// (11.4 measured) instead of 24.  One sweep launch alone -- strips x frames workgroups -- is too
-// small to fill 256 CUs, so the host forks the work over three streams: the horizontal kernel, and
-// two lanes of frames that each sweep down and then up (capi_epi.hip).
+// paths fits a byte whenever 3*P2 <= 255 (the reference uses P2 = 64 and 32): X_dn and X_h cost
+// 1 B per voxel each, and neither X_up nor S (u32 in the reference) ever reaches HBM.  8.25 B per
+// voxel by design (9.65 measured) instead of 24.  One sweep launch alone -- strips x frames
+// workgroups -- is too small to fill 256 CUs, so the host forks the work over three streams: the
+// hpair kernels, and two lanes of frames that each sweep down and then up (capi_epi.hip).
+// (lh_planes = 2 keeps the earlier form: both horizontal path volumes from agg_packed_kernel,
+// S = ... + 6*C + L_left + L_right; FSGM_EPI_HPAIR=0, for A/B runs.)
 // MODE 1 (plain up sweep writing X_up) and wta_sweep_kernel exist for the debug tap that
 // rebuilds S in natural order (fsgm_epi_plan_download_sum).
 //
@@ -406,7 +409,10 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
 // The final sweep then adds X_h + 8*C instead of L_left + L_right + 6*C.  Same lane layout as
 // agg_packed_kernel: LPP lanes x 16 d per pixel, 64/LPP rows per wave.
 // =============================================================================================
-constexpr int HP_TC = 8;
+#ifndef FSGM_HP_TC
+#define FSGM_HP_TC 8            // tile width = checkpoint spacing in columns (A/B knob)
+#endif
+constexpr int HP_TC = FSGM_HP_TC;
 
 template <int LPP>
 __global__ __launch_bounds__(256) void hpair_ckpt_kernel(HpairArgs a) {
