@@ -2,6 +2,8 @@
 // points (what the calc_cost_sgm mexFunction gateway calls).  See include/fsgm.h.
 #include "capi_common.h"
 #include "epi_kernels.h"
+#include "geometry_kernels.h"
+#include "pyramid_kernels.h"
 #include <algorithm>
 #include <mutex>
 #include <stdlib.h>
@@ -36,6 +38,9 @@ struct fsgm_epi_plan {
     // (see enqueue(): horizontal kernel on stream_h; the frames split into two lanes that sweep
     // down then up on stream / stream_b)
     uint8_t *dLh = nullptr, *dX = nullptr, *dXup = nullptr, *dState = nullptr, *dCkpt = nullptr;
+    // epipolar driver (fsgm_epipolar_sgm_of_host): rotation flow, composed flow, RGB staging
+    double *dRflow = nullptr, *dFlow = nullptr;
+    uint8_t* dRgb = nullptr;
     int lh_planes = 1;                   // 1: horizontal pair as its excess sum X_h (hpair kernels); 2: two path volumes
     uint4* dRec = nullptr;
     uint16_t* dS0 = nullptr;
@@ -103,7 +108,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dState, p->dCkpt, p->dRec, p->dS0};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dState, p->dCkpt, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -615,6 +620,79 @@ fsgm_status fsgm_calc_cost_sgm_batch_host(int32_t n, const fsgm_epi_in* in, cons
 
 fsgm_status fsgm_calc_cost_sgm_host(const fsgm_epi_in* in, const fsgm_epi_out* out, const fsgm_epi_params* prm) {
     return fsgm_calc_cost_sgm_batch_host(1, in, out, prm);
+}
+
+// ---- the dense half of the epipolar driver (dense part only) ----
+static EpiGeomArgs geom_args(const fsgm_epi_geometry* g, int W, int H, double* Pd0, double* nd, double* off, double* rflow) {
+    EpiGeomArgs a;
+    for (int i = 0; i < 9; i++) { a.F[i] = g->F[i]; a.Hm[i] = g->H[i]; }
+    a.ex = g->epipole[0]; a.ey = g->epipole[1]; a.direction = g->direction != 0;
+    a.Pd0 = Pd0; a.nd = nd; a.off = off; a.rflow = rflow; a.W = W; a.H = H;
+    return a;
+}
+
+static fsgm_status ensure_driver_buffers(fsgm_epi_plan* p, int channels) {
+    if (!p->dRflow) FSGM_HIP(hipMalloc((void**)&p->dRflow, (size_t)p->batch * p->NP * 16));
+    if (!p->dFlow) FSGM_HIP(hipMalloc((void**)&p->dFlow, (size_t)p->batch * p->NP * 24));
+    if (channels == 3 && !p->dRgb) FSGM_HIP(hipMalloc((void**)&p->dRgb, p->NP * 3 * 2));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epipolar_maps_host(const fsgm_epi_geometry* g, int32_t W, int32_t H, double* Pd0, double* normDirect,
+                                    double* Offset, double* Rflow, int32_t device) {
+    FSGM_REQUIRE(g && Pd0 && normDirect && Offset && Rflow, "fsgm_epipolar_maps: null argument");
+    FSGM_REQUIRE(W >= 1 && H >= 1, "width/height must be >= 1 (got %d x %d)", W, H);
+    fsgm_epi_params pr = fsgm_epi_params_default();
+    pr.device = device;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    fsgm_epi_plan* p = nullptr;
+    fsgm_status st = cached_plan(&p, W, H, 16, 1, pr);           // any dMax: only the map buffers are used
+    if (st != FSGM_OK) return st;
+    FSGM_HIP(hipSetDevice(device));
+    if ((st = ensure_driver_buffers(p, 1)) != FSGM_OK) return st;
+    launch_epi_maps(p->stream, geom_args(g, W, H, p->dPd0, p->dNd, p->dOff, p->dRflow));
+    FSGM_HIP(hipGetLastError());
+    FSGM_HIP(hipMemcpyAsync(Pd0, p->dPd0, p->NP * 16, hipMemcpyDeviceToHost, p->stream));
+    FSGM_HIP(hipMemcpyAsync(normDirect, p->dNd, p->NP * 16, hipMemcpyDeviceToHost, p->stream));
+    FSGM_HIP(hipMemcpyAsync(Offset, p->dOff, p->NP * 8, hipMemcpyDeviceToHost, p->stream));
+    FSGM_HIP(hipMemcpyAsync(Rflow, p->dRflow, p->NP * 16, hipMemcpyDeviceToHost, p->stream));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epipolar_sgm_of_host(const uint8_t* I0, const uint8_t* I1, int32_t W, int32_t H, int32_t channels,
+                                      const fsgm_epi_geometry* g, int32_t dMax, double vMax, const fsgm_epi_params* prm,
+                                      double* flow, uint32_t* minC) {
+    FSGM_REQUIRE(I0 && I1 && g && flow, "fsgm_epipolar_sgm_of: null argument");
+    FSGM_REQUIRE(W >= 1 && H >= 1, "width/height must be >= 1 (got %d x %d)", W, H);
+    FSGM_REQUIRE(channels == 1 || channels == 3, "channels must be 1 (gray) or 3 (RGB planes), got %d", channels);
+    fsgm_epi_params pr = prm ? *prm : fsgm_epi_params_default();
+    FSGM_REQUIRE(pr.vz_to_disp && !pr.fb_check, "fsgm_epipolar_sgm_of: the flow needs disparities (vz_to_disp = 1, fb_check = 0)");
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    fsgm_epi_plan* p = nullptr;
+    fsgm_status st = cached_plan(&p, W, H, dMax, 1, pr);
+    if (st != FSGM_OK) return st;
+    FSGM_HIP(hipSetDevice(pr.device));
+    if ((st = fsgm_epi_plan_set_penalties(p, 6, 64, vMax)) != FSGM_OK) return st;        // epipolar_sgm_of.m:19
+    if ((st = ensure_driver_buffers(p, channels)) != FSGM_OK) return st;
+    const size_t NP = p->NP;
+    if (channels == 3) {                                                                 // epipolar_sgm_of.m:35-38
+        FSGM_HIP(hipMemcpyAsync(p->dRgb, I0, 3 * NP, hipMemcpyHostToDevice, p->stream));
+        FSGM_HIP(hipMemcpyAsync(p->dRgb + 3 * NP, I1, 3 * NP, hipMemcpyHostToDevice, p->stream));
+        launch_pyr_gray(p->stream, p->dRgb, p->dI1, W, H);
+        launch_pyr_gray(p->stream, p->dRgb + 3 * NP, p->dI2, W, H);
+    } else {
+        FSGM_HIP(hipMemcpyAsync(p->dI1, I0, NP, hipMemcpyHostToDevice, p->stream));
+        FSGM_HIP(hipMemcpyAsync(p->dI2, I1, NP, hipMemcpyHostToDevice, p->stream));
+    }
+    launch_epi_maps(p->stream, geom_args(g, W, H, p->dPd0, p->dNd, p->dOff, p->dRflow));  // epipolar_sgm_of.m:24
+    if ((st = enqueue(p, FSGM_STAGE_ALL)) != FSGM_OK) return st;                          // :45
+    launch_epi_flow(p->stream, p->dBestD, p->dNd, p->dRflow, p->dFlow, W, H);             // :46-51
+    FSGM_HIP(hipGetLastError());
+    FSGM_HIP(hipMemcpyAsync(flow, p->dFlow, NP * 24, hipMemcpyDeviceToHost, p->stream));
+    if (minC) FSGM_HIP(hipMemcpyAsync(minC, p->dMinC, NP * 4, hipMemcpyDeviceToHost, p->stream));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    return FSGM_OK;
 }
 
 }  // extern "C"

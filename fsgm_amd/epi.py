@@ -170,3 +170,67 @@ class EpiPlan:
     @property
     def kernel_name(self):
         return self.lib.fsgm_epi_plan_kernel_name(self._h).decode()
+
+
+# ---------------------------------------------------------------------------------------------
+# epipolar driver, dense half (epipolar_geometry.m:99-115, rotation_motion.m, epipolar_sgm_of.m:33-51)
+# ---------------------------------------------------------------------------------------------
+class EpiGeometry(C.Structure):
+    """What the sparse half of epipolar_geometry.m (:30-96, not built here) hands over."""
+    _fields_ = [("F", C.c_double * 9), ("H", C.c_double * 9), ("epipole", C.c_double * 2), ("direction", C.c_int32)]
+
+
+def _geometry(F, H, epipole, direction):
+    F, H = np.asarray(F, np.float64), np.asarray(H, np.float64)
+    if F.shape != (3, 3) or H.shape != (3, 3):
+        raise TypeError("F and H must be 3x3 matrices")
+    g = EpiGeometry()
+    g.F[:] = list(F.reshape(-1))
+    g.H[:] = list(H.reshape(-1))
+    g.epipole[:] = [float(epipole[0]), float(epipole[1])]
+    g.direction = int(bool(direction))
+    return g
+
+
+def _bind_driver(lib):
+    if getattr(lib, "_epi_driver_bound", False):
+        return
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.fsgm_epipolar_maps_host.argtypes = [C.POINTER(EpiGeometry), i32, i32, vp, vp, vp, vp, i32]
+    lib.fsgm_epipolar_sgm_of_host.argtypes = [vp, vp, i32, i32, i32, C.POINTER(EpiGeometry), i32, C.c_double,
+                                              C.POINTER(_lib.EpiParams), vp, vp]
+    lib._epi_driver_bound = True
+
+
+def epipolar_maps(F, H, epipole, direction, width, height, *, device=0):
+    """(PrefD0, NormlizeDirection, Offset, Rflow) of epipolar_geometry.m:99-115 from F, H = K*R/K, the
+    epipole in image 2 and the expansion/contraction flag."""
+    lib = _lib.load()
+    _bind_driver(lib)
+    g = _geometry(F, H, epipole, direction)
+    Wd, Hd = int(width), int(height)
+    Pd0, nd, rflow = (np.empty((2, Hd, Wd), np.float64) for _ in range(3))
+    off = np.empty((Hd, Wd), np.float64)
+    check(lib.fsgm_epipolar_maps_host(C.byref(g), Wd, Hd, ptr(Pd0), ptr(nd), ptr(off), ptr(rflow), int(device)))
+    return Pd0, nd, off, rflow
+
+
+def epipolar_sgm_of(I0, I1, F, H, epipole, direction, dMax=64, vMax=0.3, *, paths=4, device=0):
+    """[flow, minC] = epipolar_sgm_of(I0, I1, K, dMax, vMax) from epipolar_sgm_of.m:33 on, with the sparse
+    geometry (F, H, epipole, direction) given.  I0/I1: (height, width) or (3, height, width) uint8;
+    flow: (3, height, width) float64, third plane 1."""
+    lib = _lib.load()
+    _bind_driver(lib)
+    I0, I1 = np.ascontiguousarray(I0), np.ascontiguousarray(I1)
+    if I0.dtype != np.uint8 or I1.dtype != np.uint8 or I0.shape != I1.shape:
+        raise TypeError("I0/I1 must be uint8 images of one shape")
+    if not (I0.ndim == 2 or (I0.ndim == 3 and I0.shape[0] == 3)):
+        raise TypeError("images must be (height, width) or (3, height, width)")
+    Hd, Wd = I0.shape[-2:]
+    g = _geometry(F, H, epipole, direction)
+    prm = _params(paths, 1, 1, device, 0)
+    flow = np.empty((3, Hd, Wd), np.float64)
+    minC = np.empty((Hd, Wd), np.uint32)
+    check(lib.fsgm_epipolar_sgm_of_host(ptr(I0), ptr(I1), Wd, Hd, 1 if I0.ndim == 2 else 3, C.byref(g), int(dMax), float(vMax),
+                                        C.byref(prm), ptr(flow), ptr(minC)))
+    return flow, minC

@@ -116,3 +116,22 @@ def vz_index_map(W, H, D, seed=11, invalid=0.08, speckles=0.04):
         hole[0, :] = True                                           # a whole row: only the column pass reaches it
     out[hole] = np.nan
     return np.ascontiguousarray(out)
+
+
+def epi_geometry(W, H, kind="forward"):
+    """A plausible sparse geometry for the epipolar driver: (F, H, epipole, direction).  'forward': camera
+    moving forward with a small rotation -- epipole near the image centre, expansion; 'contract': the
+    reverse.  H = K R K^-1 for a rotation of about half a degree per axis, F consistent with the epipole
+    (F = [e']_x H, so that every rotated point's epipolar line passes through e')."""
+    f = 0.58 * W
+    K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1.0]])
+    ax, ay, az = 0.004, -0.007, 0.003
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    Hm = K @ (Rz @ Ry @ Rx) @ np.linalg.inv(K)
+    e = np.array([W * 0.47 + 3.3, H * 0.55 - 1.7, 1.0])
+    ex = np.array([[0, -e[2], e[1]], [e[2], 0, -e[0]], [-e[1], e[0], 0]])
+    F = ex @ Hm
+    F = F / np.abs(F).max()
+    return F, Hm, (float(e[0]), float(e[1])), (1 if kind == "contract" else 0)

@@ -141,6 +141,34 @@ const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* plan);
 fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps);
 
 /* ------------------------------------------------------------------------------------------
+ * epipolar_sgm_of with the dense maps made on the device  (dense half only)
+ *
+ * epipolar_geometry.m has a sparse half -- SURF features, an LMedS fundamental matrix, two SVDs and
+ * the expansion vote (:30-96), all MATLAB toolbox calls, NOT built here -- and a dense half: the
+ * per-pixel maps Pd0 / normlizeDirection / Offset / Rflow from F, H, the epipole and the direction
+ * flag (:99-115, rotation_motion.m).  The dense half and the tail of epipolar_sgm_of.m (:33-51: gray
+ * conversion, calc_cost_sgm, flow = disparity * direction + rotation flow) run on the device, so a
+ * call uploads the image pair and 21 numbers instead of 18.6 MB of fp64 maps per 1242x375 frame.
+ * Matrices are row-major (F[3*i+j] = F(i+1,j+1)); pixel coordinates as in MATLAB (1-based outputs).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    double F[9];          /* fundamental matrix                                   (epipolar_geometry.m:30) */
+    double H[9];          /* rotation-compensating homography K*R/K               (:62) */
+    double epipole[2];    /* epipole in image 2, epi(1:2)                          (:43-45) */
+    int32_t direction;    /* 0 = expansion, 1 = contraction (directions negated)  (:92-96,:108-110) */
+} fsgm_epi_geometry;
+
+/* [PrefD0, NormlizeDirection, Offset, Rflow] of epipolar_geometry.m:99-115: f64 [2][H][W] / [H][W] */
+fsgm_status fsgm_epipolar_maps_host(const fsgm_epi_geometry* g, int32_t width, int32_t height, double* Pd0,
+                                    double* normDirect, double* Offset, double* Rflow, int32_t device);
+/* [flow, minC] = epipolar_sgm_of(I0, I1, K, dMax, vMax) from :33 on, the geometry given.  Images u8
+ * [channels][H][W] (1 or 3 planes, x fastest); flow f64 [3][H][W] (third plane 1, :51); minC (may be
+ * NULL) u32 [H][W].  P1 = 6, P2 = 64 (:19).  prm (may be NULL): paths etc. as for calc_cost_sgm. */
+fsgm_status fsgm_epipolar_sgm_of_host(const uint8_t* I0, const uint8_t* I1, int32_t width, int32_t height,
+                                      int32_t channels, const fsgm_epi_geometry* g, int32_t dMax, double vMax,
+                                      const fsgm_epi_params* prm, double* flow, uint32_t* minC);
+
+/* ------------------------------------------------------------------------------------------
  * calc_pyd_cost_sgm  (calc_pyd_cost_sgm.cpp:439-510, called from pyramidal_sgm.m:50)
  * ------------------------------------------------------------------------------------------ */
 typedef struct {

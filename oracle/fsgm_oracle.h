@@ -99,6 +99,14 @@ void fsgm_oracle_pyramidal_sgm(double* mv, uint32_t* minC, double** mvPyd,
                                int P1, int P2, int aggHalfWinSize, int verSearchHalfWinSize, int horSearchHalfWinSize,
                                int enableDiagonal, int totalPass, int adaptiveP2);
 
+/* ---- dense half of the epipolar driver (fsgm_oracle_geometry.cpp): rotation_motion.m,
+ * epipolar_geometry.m:99-115, epipolar_sgm_of.m:33-51.  F, Hm row-major 3x3. ---- */
+void fsgm_oracle_epipolar_maps(double* Pd0, double* nd, double* off, double* rflow, const double* F, const double* Hm,
+                               double ex, double ey, int direction, int W, int H);
+void fsgm_oracle_epipolar_sgm_of(double* flow, uint32_t* minC, const uint8_t* I0, const uint8_t* I1, int W, int H,
+                                 int channels, const double* F, const double* Hm, double ex, double ey, int direction,
+                                 int dMax, double vMax, int paths);
+
 /* ---- post-processing chain of test.m:45-50 (fsgm_oracle_post.cpp): maps f64 [H][W], NaN = invalid ---- */
 void fsgm_oracle_vzind2disp(double* D, const double* w, const double* O, int n_px, double vMax, double n);   /* vzInd2Disp.m */
 void fsgm_oracle_speckle_filter(double* out, int32_t* labels_out, const double* image, int W, int H,

@@ -196,6 +196,28 @@ def pyramidal_sgm(I0, I1, numPyd=5, P1=6, P2=32, aggHalfWinSize=2, ver=5, hor=5,
     return mv, minC, lv
 
 
+# ---------------------------------------------------------------- epipolar driver, dense half
+def epipolar_maps(F, Hm, epipole, direction, W, H):
+    F, Hm = np.ascontiguousarray(F, np.float64), np.ascontiguousarray(Hm, np.float64)
+    Pd0, nd, rflow = (np.zeros((2, H, W)) for _ in range(3))
+    off = np.zeros((H, W))
+    lib().fsgm_oracle_epipolar_maps(_p(Pd0), _p(nd), _p(off), _p(rflow), _p(F), _p(Hm), C.c_double(epipole[0]),
+                                    C.c_double(epipole[1]), int(direction), W, H)
+    return Pd0, nd, off, rflow
+
+
+def epipolar_sgm_of(I0, I1, F, Hm, epipole, direction, dMax=64, vMax=0.3, paths=4):
+    I0, I1 = np.ascontiguousarray(I0, np.uint8), np.ascontiguousarray(I1, np.uint8)
+    ch = 1 if I0.ndim == 2 else 3
+    H, W = I0.shape[-2:]
+    F, Hm = np.ascontiguousarray(F, np.float64), np.ascontiguousarray(Hm, np.float64)
+    flow = np.zeros((3, H, W))
+    minC = np.zeros((H, W), np.uint32)
+    lib().fsgm_oracle_epipolar_sgm_of(_p(flow), _p(minC), _p(I0), _p(I1), W, H, ch, _p(F), _p(Hm), C.c_double(epipole[0]),
+                                      C.c_double(epipole[1]), int(direction), int(dMax), C.c_double(vMax), int(paths))
+    return flow, minC
+
+
 # ---------------------------------------------------------------- post-processing (test.m:45-50)
 def _f64(a):
     return np.ascontiguousarray(a, np.float64)

@@ -721,3 +721,28 @@ def scanline_in_fill(a):                                # scanline_in_fill.m, li
                 a[v + 1:, u] = a[v, u]
                 break
     return a
+
+
+# =====================================================================================
+# dense half of the epipolar driver -- second restatement, whole-array numpy in the originals' terms
+# (rotation_motion.m, epipolar_geometry.m:99-115); products written out element by element (no BLAS)
+# =====================================================================================
+def epipolar_maps(F, Hm, epi, direction, W, H):
+    xx, yy = np.meshgrid(np.arange(1, W + 1, dtype=np.float64), np.arange(1, H + 1, dtype=np.float64))
+    x0, y0 = xx - 1, yy - 1                                                      # rotation_motion.m:11-13
+    mul = lambda M, i: (M[i, 0] * x0 + M[i, 1] * y0) + M[i, 2]
+    l = [mul(F, i) for i in range(3)]                                            # :49
+    nf = np.sqrt(l[0] * l[0] + l[1] * l[1])
+    nf[nf < 1e-6] = 1.0                                                          # :51
+    l = [v / nf for v in l]
+    q = [mul(Hm, i) for i in range(3)]                                           # :21
+    p1 = [q[0] / q[2], q[1] / q[2], q[2] / q[2]]                                 # :22
+    off = [p1[0] - x0, p1[1] - y0]                                               # :23
+    coef = -((l[0] * p1[0] + l[1] * p1[1]) + l[2] * p1[2])                       # :27
+    rflow = np.stack([off[0] + coef * l[0], off[1] + coef * l[1]])               # :28
+    Pd0 = np.stack([xx, yy]) + rflow                                             # epipolar_geometry.m:106
+    direct = Pd0 - np.array([epi[0], epi[1]]).reshape(2, 1, 1)                   # :107
+    if direction:
+        direct = -direct
+    offset = np.sqrt(direct[0] * direct[0] + direct[1] * direct[1])              # :112
+    return Pd0, direct / offset, offset, rflow
