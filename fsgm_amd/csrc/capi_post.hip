@@ -233,6 +233,25 @@ fsgm_status fsgm_vzind2disp_host(const double* w, const double* O, int32_t W, in
     return FSGM_OK;
 }
 
+fsgm_status fsgm_vmf_host(const double* flow, int32_t W, int32_t H, int32_t channels, double* flowMed, int32_t device) {
+    FSGM_REQUIRE(flow && flowMed, "fsgm_vmf: null argument");
+    FSGM_REQUIRE(channels >= 1 && channels <= 3, "fsgm_vmf: 1..3 channels (got %d)", channels);
+    std::lock_guard<std::mutex> lk(g_post_mu);
+    fsgm_post_plan* p;
+    fsgm_status st = cached_plan(&p, W, H, device);
+    if (st != FSGM_OK) return st;
+    double* src[3] = {p->dIn, p->dA, p->dB};                     // one plane per scratch map
+    double* dst[3] = {p->dOut, p->dD2, p->dDisp};
+    for (int c = 0; c < channels; c++) {
+        FSGM_HIP(hipMemcpyAsync(src[c], flow + (size_t)c * p->NP, p->NP * 8, hipMemcpyHostToDevice, p->stream));
+        launch_vmf(p->stream, src[c], dst[c], W, H, 1);
+        FSGM_HIP(hipMemcpyAsync(flowMed + (size_t)c * p->NP, dst[c], p->NP * 8, hipMemcpyDeviceToHost, p->stream));
+    }
+    FSGM_HIP(hipGetLastError());
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    return FSGM_OK;
+}
+
 fsgm_status fsgm_epi_postprocess_host(const double* D1, int32_t W, int32_t H, const double* Pd0, const double* normDirect,
                                       const double* O, double vMax, double n, double dMax,
                                       double* filterD1, double* filterD2, double* disp, int32_t device) {

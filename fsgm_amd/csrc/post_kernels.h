@@ -26,6 +26,7 @@ void launch_disp_from_first(hipStream_t st, const double* D1, double* D2, const 
 void launch_fb_check(hipStream_t st, const double* D1, const double* D2, double* out, const PostGeom& g, int W, int H);
 // left: i32 [H*W] scratch
 void launch_scanline_in_fill(hipStream_t st, const double* in, double* out, int32_t* left, int W, int H);
+void launch_vmf(hipStream_t st, const double* in, double* out, int W, int H, int channels);   // vmf.m: 5x5 median per plane
 void launch_vzind2disp(hipStream_t st, const double* w, const double* O, double* D, size_t n_px, double vMax, double n);
 
 }  // namespace fsgm

@@ -279,6 +279,40 @@ __global__ __launch_bounds__(256) void infill_cols_kernel(double* io, int W, int
 }
 
 // =============================================================================================
+// vmf.m:1-14: a 5x5 median per channel (medfilt2, zero padding): the 13th smallest of 25.  One thread
+// per pixel; the minimum of the remaining values is removed 12 times, the 13th minimum is the median
+// (selection by repeated min/max exchange over a register array: no data-dependent indexing).
+// =============================================================================================
+__global__ __launch_bounds__(256) void vmf_kernel(const double* __restrict__ in, double* __restrict__ out, int W, int H) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t plane = (size_t)blockIdx.z * W * H;
+    double w[25];
+#pragma unroll
+    for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+        for (int dx = -2; dx <= 2; dx++) {
+            const int yy = y + dy, xx = x + dx;
+            const bool in_img = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            w[(dy + 2) * 5 + dx + 2] = in_img ? in[plane + (size_t)(in_img ? yy : 0) * W + (in_img ? xx : 0)] : 0.0;   // zero padding
+        }
+    // partial selection sort: after pass i, w[i] holds the (i+1)-th smallest
+#pragma unroll
+    for (int i = 0; i < 13; i++)
+#pragma unroll
+        for (int j = i + 1; j < 25; j++) {
+            const double a = w[i], b = w[j];
+            w[i] = fmin(a, b);
+            w[j] = fmax(a, b);
+        }
+    out[plane + (size_t)y * W + x] = w[12];
+}
+
+void launch_vmf(hipStream_t st, const double* in, double* out, int W, int H, int channels) {
+    hipLaunchKernelGGL(vmf_kernel, dim3((W + 63) / 64, (H + 3) / 4, channels), dim3(256), 0, st, in, out, W, H);
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 void launch_speckle_filter(hipStream_t st, const double* image, double* out, int32_t* labels, int32_t* parent,

@@ -20,6 +20,7 @@ def _bind(lib):
     lib.fsgm_forward_backward_check_host.argtypes = [vp, vp, i32, i32, vp, vp, vp, f64, f64, vp, i32]
     lib.fsgm_scanline_in_fill_host.argtypes = [vp, i32, i32, vp, i32]
     lib.fsgm_vzind2disp_host.argtypes = [vp, vp, i32, i32, f64, f64, vp, i32]
+    lib.fsgm_vmf_host.argtypes = [vp, i32, i32, i32, vp, i32]
     lib.fsgm_epi_postprocess_host.argtypes = [vp, i32, i32, vp, vp, vp, f64, f64, f64, vp, vp, vp, i32]
     lib.fsgm_post_plan_create.argtypes = [C.POINTER(vp), i32, i32, i32]
     lib.fsgm_post_plan_destroy.argtypes = [vp]
@@ -108,6 +109,18 @@ def vzInd2Disp(w, O, vMax, n, *, device=0):
     D = np.empty_like(w)
     check(lib.fsgm_vzind2disp_host(ptr(w), ptr(O), W, H, float(vMax), float(n), ptr(D), int(device)))
     return D
+
+
+def vmf(flow, *, device=0):
+    """flowMed = vmf(flow)  (vmf.m:1): 5x5 median per channel; flow (channels, height, width) float64"""
+    lib = _lib_bound()
+    flow = np.ascontiguousarray(flow)
+    if flow.dtype != np.float64 or flow.ndim != 3 or not 1 <= flow.shape[0] <= 3:
+        raise TypeError("flow must be float64 of shape (1..3, height, width)")
+    ch, H, W = flow.shape
+    out = np.empty_like(flow)
+    check(lib.fsgm_vmf_host(ptr(flow), W, H, ch, ptr(out), int(device)))
+    return out
 
 
 def epi_postprocess(D1, Pd0, normDirect, O, vMax, n, dMax, *, device=0):

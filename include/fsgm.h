@@ -300,6 +300,10 @@ fsgm_status fsgm_scanline_in_fill_host(const double* input, int32_t width, int32
 /* vzInd2Disp.m:1 D = vzInd2Disp(w, O, vMax, n) */
 fsgm_status fsgm_vzind2disp_host(const double* w, const double* O, int32_t width, int32_t height, double vMax,
                                  double n, double* D, int32_t device);
+/* vmf.m:1 flowMed = vmf(flow): medfilt2(flow(:,:,c), [5 5]) per channel (zero padding, 13th smallest of 25);
+ * flow f64 [channels][H][W], 1..3 channels (test.m:76 passes the 3-plane flow) */
+fsgm_status fsgm_vmf_host(const double* flow, int32_t width, int32_t height, int32_t channels, double* flowMed,
+                          int32_t device);
 /* test.m:45-50 in one call, intermediates resident in HBM:
  *   filterD1 = speckle_filter(D1, 2, 100); filterD2 = calc_disp_from_first(filterD1, ...);
  *   filterD1 = forward_backward_check(filterD1, filterD2, ...); filterD1 = speckle_filter(filterD1, dMax, rows*cols/10);

@@ -116,6 +116,7 @@ void fsgm_oracle_calc_disp_from_first(double* D2, const double* D1, int W, int H
 void fsgm_oracle_forward_backward_check(double* out, const double* D1, const double* D2, int W, int H,
                                         const double* Pd0, const double* nd, const double* O, double vMax, double n);
 void fsgm_oracle_scanline_in_fill(double* out, const double* in, int W, int H);                             /* scanline_in_fill.m */
+void fsgm_oracle_vmf(double* out, const double* flow, int W, int H, int channels);                           /* vmf.m (medfilt2 5x5) */
 void fsgm_oracle_postprocess(double* filterD1, double* filterD2, double* disp, const double* D1, int W, int H,
                              const double* Pd0, const double* nd, const double* O, double vMax, double n, double dMax);
 

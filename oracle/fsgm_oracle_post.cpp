@@ -152,6 +152,30 @@ void fsgm_oracle_scanline_in_fill(double* out, const double* in, int W, int H) {
     }
 }
 
+/* vmf.m:1-14: medfilt2(flow(:,:,c), [5 5]) per channel.  medfilt2 (toolbox, not in the reference tree)
+ * pads with zeros and returns the median of the 25 window values: the 13th smallest. */
+void fsgm_oracle_vmf(double* out, const double* flow, int W, int H, int channels) {
+    const size_t NP = (size_t)W * H;
+    for (int c = 0; c < channels; c++)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                double w[25];
+                int k = 0;
+                for (int dy = -2; dy <= 2; dy++)
+                    for (int dx = -2; dx <= 2; dx++) {
+                        const int yy = y + dy, xx = x + dx;
+                        w[k++] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? flow[c * NP + (size_t)yy * W + xx] : 0.0;
+                    }
+                for (int i = 1; i < 25; i++) {                         /* insertion sort */
+                    const double v = w[i];
+                    int j = i - 1;
+                    while (j >= 0 && w[j] > v) { w[j + 1] = w[j]; j--; }
+                    w[j + 1] = v;
+                }
+                out[c * NP + (size_t)y * W + x] = w[12];
+            }
+}
+
 /* test.m:45-50: the chain the evaluation script runs on the vz-index map D1.  filterD2 (may be NULL)
  * receives calc_disp_from_first's map; disp (may be NULL) receives vzInd2Disp of the result. */
 void fsgm_oracle_postprocess(double* filterD1, double* filterD2, double* disp, const double* D1, int W, int H,

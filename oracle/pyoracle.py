@@ -264,6 +264,14 @@ def scanline_in_fill(a):
     return out
 
 
+def vmf(flow):
+    flow = _f64(flow)
+    ch, H, W = flow.shape
+    out = np.zeros_like(flow)
+    lib().fsgm_oracle_vmf(_p(out), _p(flow), W, H, ch)
+    return out
+
+
 def postprocess(D1, Pd0, nd, O, vMax, n, dMax):
     D1 = _f64(D1)
     H, W = D1.shape

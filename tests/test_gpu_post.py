@@ -103,3 +103,10 @@ def test_postprocess_after_calc_cost_sgm(gpu_lib, oracle):
     got = fsgm_amd.epi_postprocess(D1, pd0, nd, off, vMax, D + 1, D)
     for g, w in zip(got, want):
         _same(g, w)
+
+
+@pytest.mark.parametrize("W,H,ch", [(27, 19, 3), (5, 3, 1), (1, 1, 2), (1242, 375, 3)])
+def test_vmf_bit_exact(gpu_lib, oracle, W, H, ch):
+    flow = (synth.uniform_f64(W, (ch, H, W)) - 0.5) * 40
+    flow[-1] = 1.0
+    np.testing.assert_array_equal(fsgm_amd.vmf(flow), oracle.vmf(flow))

@@ -86,3 +86,15 @@ def test_postprocess_chain_is_the_composition(oracle):
     _same(f2, d2)
     _same(f1, e)
     _same(disp, R.vzInd2Disp(e, off, vMax, D + 1))                               # :50
+
+
+def test_vmf_vs_scipy_median_filter(oracle):
+    """vmf.m = medfilt2 5x5 per channel with zero padding: scipy's median_filter(mode='constant') is the
+    same definition (independent implementation)."""
+    from scipy.ndimage import median_filter
+    flow = (synth.uniform_f64(3, (3, 19, 27)) - 0.5) * 40
+    flow[2] = 1.0
+    got = oracle.vmf(flow)
+    for c in range(3):
+        np.testing.assert_array_equal(got[c], median_filter(flow[c], size=5, mode="constant", cval=0.0))
+    assert got[2, 0, 0] == 0.0 and got[2, 9, 9] == 1.0      # corner: 16 of 25 window cells are padding zeros
