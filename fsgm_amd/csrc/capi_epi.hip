@@ -45,8 +45,9 @@ struct fsgm_epi_plan {
     uint4* dRec = nullptr;
     uint16_t* dS0 = nullptr;
     size_t state_stride = 0;
-    hipStream_t stream_h = nullptr, stream_b = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_h = nullptr, ev_b = nullptr;
+    hipStream_t stream_h = nullptr, stream_b = nullptr, stream_c = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_h = nullptr, ev_b = nullptr, ev_c = nullptr;
+    int lanes = 2;                       // frame lanes of the sweeps (FSGM_EPI_LANES, 1..3)
     std::vector<int> cmax;               // per frame: upper bound of the cost values in dC
     bool vz_valid = false;
     int agg_mode = 0;                    // 0 auto, 1 per-direction line kernels, 2 fused sweeps (if eligible)
@@ -115,9 +116,9 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     for (auto& g : p->graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    for (hipEvent_t e : {p->ev_fork, p->ev_h, p->ev_b})
+    for (hipEvent_t e : {p->ev_fork, p->ev_h, p->ev_b, p->ev_c})
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {p->stream, p->stream_h, p->stream_b})
+    for (hipStream_t st : {p->stream, p->stream_h, p->stream_b, p->stream_c})
         if (st) (void)hipStreamDestroy(st);
     delete p;
 }
@@ -259,9 +260,12 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     FSGM_HIP(hipMalloc((void**)&p->dS0, B * p->NP * sizeof(uint16_t)));
     FSGM_HIP(hipStreamCreateWithFlags(&p->stream_h, hipStreamNonBlocking));
     FSGM_HIP(hipStreamCreateWithFlags(&p->stream_b, hipStreamNonBlocking));
+    FSGM_HIP(hipStreamCreateWithFlags(&p->stream_c, hipStreamNonBlocking));
     FSGM_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     FSGM_HIP(hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming));
     FSGM_HIP(hipEventCreateWithFlags(&p->ev_b, hipEventDisableTiming));
+    FSGM_HIP(hipEventCreateWithFlags(&p->ev_c, hipEventDisableTiming));
+    { const char* e = getenv("FSGM_EPI_LANES"); const int v = (e && *e) ? atoi(e) : 2; p->lanes = v < 1 ? 1 : (v > 3 ? 3 : v); }
     FSGM_HIP(hipMalloc((void**)&p->dX, B * p->N));           // last: marks the set complete
     return FSGM_OK;
 }
@@ -288,10 +292,12 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         // One sweep launch (strips x frames workgroups) cannot fill 256 CUs, so the work is forked:
         // the horizontal pair runs on stream_h, and the frames split into two lanes, each sweeping
         // down and then up (the final up sweep needs its lane's X_dn and the horizontal pair).
-        const int nA = (p->batch + 1) / 2, nB = p->batch - nA;
+        const int NLN = std::min(p->lanes, p->batch);
+        hipStream_t lane_stream[3] = {p->stream, p->stream_b, p->stream_c};
+        hipEvent_t lane_done[3] = {nullptr, p->ev_b, p->ev_c};
         FSGM_HIP(hipEventRecord(p->ev_fork, p->stream));
         FSGM_HIP(hipStreamWaitEvent(p->stream_h, p->ev_fork, 0));
-        if (nB) FSGM_HIP(hipStreamWaitEvent(p->stream_b, p->ev_fork, 0));
+        for (int l = 1; l < NLN; l++) FSGM_HIP(hipStreamWaitEvent(lane_stream[l], p->ev_fork, 0));
         if (p->lh_planes == 1) {                     // the two horizontal paths as one excess sum X_h
             HpairArgs h;
             h.C = p->dC; h.c_frame_stride = p->N; h.Xh = p->dLh; h.xh_frame_stride = p->N;
@@ -306,10 +312,9 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
             launch_aggregate(p->stream_h, a, 2, p->batch, AGG_PACKED_NOWRAP);
         }
         FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
-        for (int lane = 0; lane < 2; lane++) {
-            const int f0 = lane ? nA : 0, nf = lane ? nB : nA;
-            if (!nf) continue;
-            hipStream_t st = lane ? p->stream_b : p->stream;
+        for (int lane = 0, f0 = 0; lane < NLN; lane++) {
+            const int nf = p->batch / NLN + (lane < p->batch % NLN ? 1 : 0);
+            hipStream_t st = lane_stream[lane];
             SweepArgs w;
             w.C = p->dC + (size_t)f0 * p->N; w.c_frame_stride = p->N;
             w.X = p->dX + (size_t)f0 * p->N; w.x_frame_stride = p->N;
@@ -322,10 +327,11 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
             launch_sweep(st, w, nf, 0);                              // pass-0 paths from above -> X_dn
             FSGM_HIP(hipStreamWaitEvent(st, p->ev_h, 0));
             launch_sweep(st, w, nf, 2);                              // pass-1 paths + everything else + WTA
-        }
-        if (nB) {
-            FSGM_HIP(hipEventRecord(p->ev_b, p->stream_b));
-            FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_b, 0));
+            if (lane) {
+                FSGM_HIP(hipEventRecord(lane_done[lane], st));
+                FSGM_HIP(hipStreamWaitEvent(p->stream, lane_done[lane], 0));
+            }
+            f0 += nf;
         }
     } else if (stages & FSGM_STAGE_AGGREGATE) {
         if (!p->dL) FSGM_HIP(hipMalloc((void**)&p->dL, (size_t)p->batch * p->N * p->prm.paths));
