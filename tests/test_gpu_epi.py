@@ -95,7 +95,9 @@ def test_aggregate_sum_bit_exact(gpu_lib, oracle, W, H, D, P1, P2, cmax, kernel,
 
 
 @pytest.mark.parametrize("W,H,D", [(70, 40, 128), (200, 53, 64), (33, 100, 128), (130, 35, 32), (50, 20, 256), (257, 19, 16),
-                                   (320, 240, 64), (40, 300, 16), (60, 150, 32), (23, 40, 256)])
+                                   (320, 240, 64), (40, 300, 16), (60, 150, 32), (23, 40, 256),
+                                   # widths around the horizontal pair's 8-column tiles (no / one / partial checkpoint)
+                                   (1, 9, 64), (5, 20, 128), (8, 33, 128), (9, 20, 32), (16, 20, 128), (17, 40, 64), (1242, 17, 128)])
 def test_sweep_blocks_and_strips(gpu_lib, oracle, W, H, D):
     """Fused sweeps across several row blocks and column strips (block / halo / state hand-over paths)."""
     Cv = synth.cost_volume(W, H, D, seed=W + H, cmax=24)
