@@ -125,6 +125,20 @@ static int fsgm_env_wide() {
 }
 
 fsgm_status fsgm::pyd_enqueue(fsgm_pyd_plan* p, int stages, uint32_t* dS) {
+    PydAggArgs g;
+    PydWtaArgs w;
+    g.I1 = p->dI1; g.C = p->dC; g.mv = p->dMv; g.L = p->dL; g.desc = p->dDesc; g.dump = p->dDesc ? p->dDesc + (size_t)p->batch * p->NP * 8 : nullptr;
+    g.W = p->W; g.H = p->H; g.mvW = p->mvW; g.mvH = p->mvH; g.Sx = p->Sx; g.Sy = p->Sy;
+    g.RS = p->RS; g.PS = p->PS;
+    g.P1 = p->P1; g.P2 = p->P2; g.adaptive = p->adaptive;
+    // cmax: 24 for volumes built here (census 5x5 Hamming mean; out-of-image taps add 5), else as uploaded
+    const int cm = (stages & FSGM_STAGE_COST) ? 24 : p->cmax;
+    const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + (p->P1 > p->P2 ? p->P1 : p->P2) <= 255;
+    const bool rows = nowrap && p->dDesc != nullptr;        // row-packed aggregation (pyd_rows.hip)
+    // A single landscape frame is bounded by its longest serial chains, the horizontal lines: those take
+    // the kernel's one-line-per-wave mapping (fewer instructions per step); batches keep the packed one.
+    const bool wide_rows = rows && p->batch <= 2 && p->W > p->H && fsgm_env_wide() != 0;
+    plan_pyd_dirs(g, p->diagonal, p->totalPass, w.weight, rows ? 16 : 4, wide_rows || (rows && fsgm_env_wide() == 2));
     if (stages & FSGM_STAGE_COST) {
         launch_census(p->stream, p->dI1, p->dCen1, p->W, p->H, p->batch);       // :485-486
         launch_census(p->stream, p->dI2, p->dCen2, p->W, p->H, p->batch);
@@ -133,23 +147,12 @@ fsgm_status fsgm::pyd_enqueue(fsgm_pyd_plan* p, int stages, uint32_t* dS) {
         a.W = p->W; a.H = p->H; a.mvW = p->mvW; a.mvH = p->mvH; a.rAgg = p->rAgg; a.rX = p->rX; a.rY = p->rY;
         a.RS = p->RS; a.PS = p->PS;
         launch_pyd_cost(p->stream, a, p->batch);
+        p->cmax = 24;
     }
-    PydAggArgs g;
-    PydWtaArgs w;
-    g.I1 = p->dI1; g.C = p->dC; g.mv = p->dMv; g.L = p->dL; g.desc = p->dDesc; g.dump = p->dDesc ? p->dDesc + (size_t)p->batch * p->NP * 8 : nullptr;
-    g.W = p->W; g.H = p->H; g.mvW = p->mvW; g.mvH = p->mvH; g.Sx = p->Sx; g.Sy = p->Sy;
-    g.RS = p->RS; g.PS = p->PS;
-    g.P1 = p->P1; g.P2 = p->P2; g.adaptive = p->adaptive;
-    // cmax: 24 for volumes built here (census 5x5 Hamming mean; out-of-image taps add 5), else as uploaded
-    const int cm = p->cmax;
-    const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + (p->P1 > p->P2 ? p->P1 : p->P2) <= 255;
-    const bool rows = nowrap && p->dDesc != nullptr;        // row-packed aggregation (pyd_rows.hip)
-    // A single landscape frame is bounded by its longest serial chains, the horizontal lines: those take
-    // the kernel's one-line-per-wave mapping (fewer instructions per step); batches keep the packed one.
-    const bool wide_rows = rows && p->batch <= 2 && p->W > p->H && fsgm_env_wide() != 0;
-    plan_pyd_dirs(g, p->diagonal, p->totalPass, w.weight, rows ? 16 : 4, wide_rows || (rows && fsgm_env_wide() == 2));
     if (stages & FSGM_STAGE_AGGREGATE) {
         if (rows) {
+            // (making the descriptors on a side stream while the cost volume is built was tried: the event
+            // fork/join costs more than the 0.06 ms it hides -- 1.71 vs 1.68 ms per 3-level pyramid)
             launch_pyd_rows_desc(p->stream, g, p->batch);
             launch_pyd_rows_aggregate(p->stream, g, p->batch);
         } else {

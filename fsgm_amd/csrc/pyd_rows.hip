@@ -85,19 +85,41 @@ __global__ __launch_bounds__(256) void pyd_rows_cost_kernel(PydCostArgs a) {
         const int y2 = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)(y + j - a.rY - r), mvy), 0.5));   // :415
         y2tab[j] = (y2 >= 0 && y2 <= H - 1) ? y2 : -1;
     }
-    for (int k = j; k < AW * AW; k += 16) {
-        const int y1 = y + k / AW - r, x1 = x + k % AW - r;
-        const bool in = y1 >= 0 && y1 <= H - 1 && x1 >= 0 && x1 <= W - 1;                            // :405
-        c1s[k] = in ? cen1[(size_t)W * (in ? y1 : 0) + (in ? x1 : 0)] : ROWS_OUTSIDE;
-        outside |= !in;
+    // Fills in two phases -- every address first, then all loads in flight together, then the LDS
+    // writes: as a plain loop each iteration waited for its own gathered load (~1 us), which made
+    // the fill, not the 3025 taps, the longest part of the kernel.
+    {
+        uint32_t v[2];
+#pragma unroll
+        for (int it = 0; it < 2; it++) {                             // (2r+1)^2 <= 25 image-1 taps
+            const int k = j + 16 * it;
+            const int kc = min(k, AW * AW - 1);
+            const int y1 = y + kc / AW - r, x1 = x + kc % AW - r;
+            const bool in = y1 >= 0 && y1 <= H - 1 && x1 >= 0 && x1 <= W - 1;                        // :405
+            v[it] = in ? cen1[(size_t)W * (in ? y1 : 0) + (in ? x1 : 0)] : ROWS_OUTSIDE;
+            outside |= !in && k < AW * AW;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; it++)
+            if (j + 16 * it < AW * AW) c1s[j + 16 * it] = v[it];
     }
     __builtin_amdgcn_wave_barrier();
-    for (int k = j; k < PX * PY; k += 16) {
-        const int ky = k / PX, kx = k - ky * PX;
-        const int y2 = y2tab[ky], x2 = x2tab[kx];
-        const bool in = y2 >= 0 && x2 >= 0;                                                          // :418
-        patch[k] = in ? cen2[(size_t)W * (in ? y2 : 0) + (in ? x2 : 0)] : ROWS_OUTSIDE;
-        outside |= !in;
+    {
+        constexpr int NIT = (COST_PM * COST_PM + 15) / 16;           // 15 rounds cover the largest patch
+        uint32_t v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int k = j + 16 * it;
+            const int kc = min(k, PX * PY - 1);
+            const int ky = kc / PX, kx = kc - ky * PX;
+            const int y2 = y2tab[ky], x2 = x2tab[kx];
+            const bool in = y2 >= 0 && x2 >= 0;                                                      // :418
+            v[it] = in ? cen2[(size_t)W * (in ? y2 : 0) + (in ? x2 : 0)] : ROWS_OUTSIDE;
+            outside |= !in && k < PX * PY;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++)
+            if (j + 16 * it < PX * PY) patch[j + 16 * it] = v[it];
     }
     __builtin_amdgcn_wave_barrier();
     const bool any_outside = __builtin_amdgcn_ballot_w64(outside) != 0;       // wave-uniform
@@ -127,7 +149,11 @@ __global__ __launch_bounds__(256) void pyd_rows_cost_kernel(PydCostArgs a) {
             }
         }
     }
-    const double win = (double)(AW * AW);
+    // (u8)(1.0*sum/win + 0.5) (:431) without the fp64 division: win = (2r+1)^2 is odd, so sum/win + 0.5
+    // is never within 1/(2*win) of an integer and the truncation equals (2*sum + win) / (2*win) in
+    // integers; that quotient by multiply-shift (exact for every sum up to 32*win, checked value by
+    // value in tests/test_capi_cpu.py).
+    const uint32_t win = (uint32_t)(AW * AW), inv = (1u << 20) / (2u * win) + 1u;
     uint32_t out[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) {
@@ -135,8 +161,7 @@ __global__ __launch_bounds__(256) void pyd_rows_cost_kernel(PydCostArgs a) {
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const int oy = 4 * k + b;
-            const double vv = __dadd_rn(__ddiv_rn(__dmul_rn(1.0, (double)sum[oy]), win), 0.5);       // :431
-            const uint32_t c = oy < Sy ? ((uint32_t)f64_to_i32_x86(vv) & 0xFFu) : 0u;
+            const uint32_t c = oy < Sy ? (((2u * sum[oy] + win) * inv) >> 20) : 0u;
             w |= c << (8 * b);
         }
         out[k] = w;

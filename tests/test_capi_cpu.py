@@ -82,3 +82,16 @@ def test_synthetic_inputs_are_deterministic():
     assert a.max() <= 24
     assert synth.splitmix64(1, 3).tolist() == synth.splitmix64(1, 3).tolist()
     assert int(synth.splitmix64(0, 1)[0]) == 0xE220A8397B1DCDAF                 # splitmix64(0) known answer
+
+
+def test_window_mean_rounding_identity_of_the_rows_cost_kernel():
+    """pyd_rows_cost_kernel replaces (u8)(1.0*sum/win + 0.5) (calc_pyd_cost_sgm.cpp:431, fp64) by
+    ((2*sum + win) * inv) >> 20 with inv = 2^20 / (2*win) + 1: equal for every sum a window can produce
+    (win = 1, 9, 25 taps of at most 32 each)."""
+    for win in (1, 9, 25):
+        inv = (1 << 20) // (2 * win) + 1
+        s = np.arange(0, 32 * win + 1, dtype=np.int64)
+        want = (1.0 * s.astype(np.float64) / win + 0.5).astype(np.int64)
+        got = ((2 * s + win) * inv) >> 20
+        np.testing.assert_array_equal(got, want)
+        assert ((2 * s + win) * inv).max() < 2 ** 32
