@@ -58,8 +58,9 @@ fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in
     if (st != FSGM_OK) return st;
     const size_t NP = (size_t)W * H, MV = (size_t)a.mvWidth * a.mvHeight, N = NP * D, B = n;
     DevBufs d;
-    uint8_t *dI1, *dI2; uint32_t *dCen1, *dCen2, *dS, *dMinC; double *dMv, *dFlow; Cand* dC;
+    uint8_t *dI1, *dI2; uint32_t *dCen1, *dCen2, *dS, *dMinC, *dUnsafe; double *dMv, *dFlow; Cand* dC;
     FSGM_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    FSGM_HIP(d.alloc((void**)&dUnsafe, 4));
     FSGM_HIP(d.alloc((void**)&dI1, B * NP));
     FSGM_HIP(d.alloc((void**)&dI2, B * NP));
     FSGM_HIP(d.alloc((void**)&dCen1, B * NP * 4));
@@ -75,14 +76,15 @@ fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in
         FSGM_HIP(hipMemcpyAsync(dMv + i * 2 * MV, in[i].preMv, MV * 16, hipMemcpyHostToDevice, d.stream));
     }
     FSGM_HIP(hipMemsetAsync(dS, 0, B * N * 4, d.stream));                       // :111
+    FSGM_HIP(hipMemsetAsync(dUnsafe, 0, 4, d.stream));
     launch_census(d.stream, dI1, dCen1, W, H, n);                               // :485-486
     launch_census(d.stream, dI2, dCen2, W, H, n);
     NgCostArgs ca;
-    ca.cen1 = dCen1; ca.cen2 = dCen2; ca.mv = dMv; ca.C = dC; ca.W = W; ca.H = H;
+    ca.cen1 = dCen1; ca.cen2 = dCen2; ca.mv = dMv; ca.C = dC; ca.unsafe = dUnsafe; ca.W = W; ca.H = H;
     ca.mvW = a.mvWidth; ca.mvH = a.mvHeight; ca.rAgg = rAgg; ca.rX = r; ca.rY = r;
     launch_ng_cost(d.stream, ca, n);
     NgAggArgs ga;
-    ga.C = dC; ga.S = dS; ga.W = W; ga.H = H; ga.D = (int)D; ga.P1 = a.P1; ga.P2 = a.P2;
+    ga.C = dC; ga.S = dS; ga.unsafe = dUnsafe; ga.W = W; ga.H = H; ga.D = (int)D; ga.P1 = a.P1; ga.P2 = a.P2;
     launch_ng_aggregate(d.stream, ga, n);
     NgWtaArgs wa;
     wa.C = dC; wa.S = dS; wa.minC = dMinC; wa.flow = dFlow; wa.W = W; wa.H = H; wa.D = (int)D;

@@ -16,6 +16,7 @@ struct NgCostArgs {
     const uint32_t* cen2;
     const double* mv;       // [frames][2][mvH*mvW]
     Cand* C;                // [frames][NP][D]
+    uint32_t* unsafe;       // one word (may be null), zeroed by the caller: set when a motion vector has |v| >= 2^30
     int W, H, mvW, mvH;
     int rAgg, rX, rY;
 };
@@ -23,6 +24,7 @@ struct NgCostArgs {
 struct NgAggArgs {
     const Cand* C;          // [frames][NP][D]
     uint32_t* S;            // [frames][NP][D], zeroed before the launch; paths add atomically
+    const uint32_t* unsafe; // the cost kernel's flag (null: take the generic kernel)
     int W, H, D;
     int P1, P2;
     int blk_begin[5];

@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256) void ng_cost_kernel(NgCostArgs a) {
     o.mvx = f64_to_i32_x86(__dadd_rn(mvx, (double)offx));                                           // :433
     o.mvy = f64_to_i32_x86(__dadd_rn(mvy, (double)offy));                                           // :434
     a.C[f * (size_t)NP * D + (size_t)p * D + d] = o;
+    // the fast matcher decides "within 2" with 32-bit differences: tell it when a vector could overflow them
+    if (a.unsafe && !(o.mvx > -(1 << 30) && o.mvx < (1 << 30) && o.mvy > -(1 << 30) && o.mvy < (1 << 30))) atomicOr(a.unsafe, 1u);
 }
 
 // One matcher step shared by both variants (calc_pyd_cost_sgm_ng.cpp:39-78 /
@@ -121,6 +123,116 @@ __global__ __launch_bounds__(256) void ng_agg_kernel(NgAggArgs a) {
         m = t > 0 ? lo : 0u;                                                     // :172 / :77
         __builtin_amdgcn_wave_barrier();
         Cand* tmp = pre; pre = cur; cur = tmp;
+    }
+}
+
+// =============================================================================================
+// The same aggregation for D <= 128 (the reference's D = 81), restructured for latency:
+//   * the previous pixel's entries sit in LDS as four arrays (mvx, mvy, cost & 0xFF, (cost + P1) & 0xFF)
+//     and are read four at a time (ds_read_b128 of one address = broadcast), all reads of a group of
+//     four before their compares: the plain loop above waits for every 12-byte read in turn;
+//   * "within 2" as one unsigned compare per axis, (mv + 2 - mv') <= 4, valid while no difference can
+//     overflow: the cost kernel raises a flag when any |mv| >= 2^30, and then the exact 64-bit form of
+//     ng_match is used for the whole launch;
+//   * the next pixel's candidates are requested one step ahead.
+// Same results as ng_agg_kernel (the order-free u32 sums are atomic adds there and here).
+// =============================================================================================
+struct NgPre { const int32_t* x; const int32_t* y; const uint32_t* c8; const uint32_t* cp; };
+
+__device__ __forceinline__ int ng_match4(const NgPre& q, int D, int mvx, int mvy, int ccost, uint32_t m, uint32_t jump, bool safe) {
+    uint32_t min1 = jump, min2 = jump;
+    if (safe) {
+        const uint32_t ax = (uint32_t)mvx + 2u, ay = (uint32_t)mvy + 2u;
+        int d2 = 0;
+        for (; d2 + 4 <= D; d2 += 4) {
+            const int4 qx = *(const int4*)(q.x + d2), qy = *(const int4*)(q.y + d2);
+            const uint4 c8 = *(const uint4*)(q.c8 + d2), cp = *(const uint4*)(q.cp + d2);
+            const int qxa[4] = {qx.x, qx.y, qx.z, qx.w}, qya[4] = {qy.x, qy.y, qy.z, qy.w};
+            const uint32_t c8a[4] = {c8.x, c8.y, c8.z, c8.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool eq = mvx == qxa[i] && mvy == qya[i];
+                const bool nr = (ax - (uint32_t)qxa[i]) <= 4u && (ay - (uint32_t)qya[i]) <= 4u;
+                min1 = eq ? c8a[i] : min1;                                        // last match wins
+                min2 = (nr && !eq) ? min(min2, cpa[i]) : min2;
+            }
+        }
+        for (; d2 < D; d2++) {
+            const int qx = q.x[d2], qy = q.y[d2];
+            const bool eq = mvx == qx && mvy == qy;
+            const bool nr = (ax - (uint32_t)qx) <= 4u && (ay - (uint32_t)qy) <= 4u;
+            min1 = eq ? q.c8[d2] : min1;
+            min2 = (nr && !eq) ? min(min2, q.cp[d2]) : min2;
+        }
+    } else {
+        for (int d2 = 0; d2 < D; d2++) {
+            const int qx = q.x[d2], qy = q.y[d2];
+            if (mvx == qx && mvy == qy) min1 = q.c8[d2];
+            else if (near2(mvx, qx) && near2(mvy, qy)) min2 = min(min2, q.cp[d2]);
+        }
+    }
+    const uint32_t best = min(jump, min(min1, min2));
+    return (ccost + (int)best) - (int)m;
+}
+
+// One THREAD per (line, candidate): a 256-thread workgroup advances 256/D lines (3 at D = 81, 95 % of the
+// lanes busy; one wave per line leaves 37 % idle and needs two rounds).  The per-line minimum crosses
+// waves through an LDS atomicMin in a three-slot ring (written at step t, read at t+1, reset at t+2),
+// one barrier per step.
+__global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
+    extern __shared__ uint32_t sNg[];                         // [line][2 buffers][4 arrays][Dp], then [line][3] minima
+    int slot = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if ((int)blockIdx.x >= a.blk_begin[i]) slot = i;
+    const int base = slot & 1;                               // 0: along x, 1: along y
+    const bool mirror = slot >= 2;
+    const int W = a.W, H = a.H, D = a.D, Dp = (D + 3) & ~3;
+    const int LPB = 256 / D;                                  // lines per workgroup
+    const int NP = W * H;
+    const int nlines = base == 0 ? H : W;
+    const int len = base == 0 ? W : H;
+    const int g = threadIdx.x;
+    const int ll = min(g / D, LPB - 1), cand = g - (g / D) * D;
+    const bool tact = g < LPB * D;                            // this thread holds a candidate
+    const int line = ((int)blockIdx.x - a.blk_begin[slot]) * LPB + ll;
+    const bool lact = tact && line < nlines;
+    const int linec = min(line, nlines - 1);
+    const size_t f = blockIdx.y;
+    const Cand* __restrict__ Cf = a.C + f * (size_t)NP * D;
+    uint32_t* __restrict__ Sf = a.S + f * (size_t)NP * D;
+    uint32_t* buf0 = sNg + (size_t)ll * 8 * Dp;
+    uint32_t* buf1 = buf0 + 4 * Dp;
+    uint32_t* smin = sNg + (size_t)LPB * 8 * Dp + ll * 3;
+    if (cand < 3 && tact) smin[cand] = 255u;
+    const bool safe = *a.unsafe == 0;                         // no motion vector of this launch near the int range
+    auto pix_of = [&](int t) {
+        int x = base == 0 ? t : linec, y = base == 0 ? linec : t;
+        if (mirror) { x = W - 1 - x; y = H - 1 - y; }
+        return (size_t)y * W + x;
+    };
+    Cand nxt = Cf[pix_of(0) * D + cand];
+    __syncthreads();
+    for (int t = 0; t < len; t++) {
+        const Cand c = nxt;
+        nxt = Cf[pix_of(min(t + 1, len - 1)) * D + cand];      // in flight while this step computes
+        const size_t off = pix_of(t) * D;
+        const NgPre q{(const int32_t*)buf0, (const int32_t*)buf0 + Dp, buf0 + 2 * Dp, buf0 + 3 * Dp};
+        const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
+        const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
+        int o = c.cost;
+        if (t > 0) {
+            o = ng_match4(q, D, c.mvx, c.mvy, c.cost, m, jump, safe);
+            if (tact) atomicMin(&smin[t % 3], (uint32_t)o & 0xFF);                // :74 narrowed
+        }
+        if (tact) {
+            buf1[cand] = (uint32_t)c.mvx; buf1[Dp + cand] = (uint32_t)c.mvy;
+            buf1[2 * Dp + cand] = (uint32_t)o & 0xFF; buf1[3 * Dp + cand] = (uint32_t)(o + a.P1) & 0xFF;
+            if (lact) atomicAdd(&Sf[off + cand], (uint32_t)o);                    // :249
+            if (cand == 0) smin[(t + 1) % 3] = 255u;
+        }
+        __syncthreads();
+        uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
     }
 }
 
@@ -393,6 +505,18 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         acc += (((i & 1) == 0 ? a.H : a.W) + 3) / 4;
     }
     a.blk_begin[4] = acc;
+    if (a.D <= 128 && a.unsafe) {
+        const int lpb = 256 / a.D;
+        acc = 0;
+        for (int i = 0; i < 4; i++) {
+            a.blk_begin[i] = acc;
+            acc += (((i & 1) == 0 ? a.H : a.W) + lpb - 1) / lpb;
+        }
+        a.blk_begin[4] = acc;
+        const size_t lds = ((size_t)lpb * 8 * ((a.D + 3) & ~3) + lpb * 3) * sizeof(uint32_t);
+        hipLaunchKernelGGL(ng_agg_lines_kernel, dim3(acc, frames), dim3(256), lds, st, a);
+        return;
+    }
     hipLaunchKernelGGL(ng_agg_kernel, dim3(acc, frames), dim3(256), 0, st, a);
 }
 

@@ -15,12 +15,30 @@ pytestmark = pytest.mark.gpu
     (33, 21, 40, 25, 1, 2, 1, 90, 120, "general"),     # wrapping penalties
     (21, 15, 21, 15, 2, 3, 0, 6, 32, "even"),          # D = 225
     (12, 1, 12, 1, 1, 2, 0, 6, 32, "general"), (1, 12, 1, 12, 1, 2, 1, 6, 32, "general"),
+    (150, 90, 150, 90, 1, 2, 1, 6, 32, "int"),         # several workgroups per direction
 ])
 def test_calc_pyd_cost_sgm_ng_bit_exact(gpu_lib, oracle, W, H, mvW, mvH, r, agg, sub, P1, P2, kind):
     I1, I2 = synth.image_pair(W, H, 16, seed=W + r)
     mv = synth.hint_map(mvW, mvH, kind, seed=H, amp=6.0)
     mc, fl, _, S = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, r, agg, sub, P1, P2, want_volumes=True)
     gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv, r, agg, sub, P1, P2, return_sum=True)
+    np.testing.assert_array_equal(gS, S)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gfl, fl)
+
+
+def test_calc_pyd_cost_sgm_ng_extreme_hints(gpu_lib, oracle):
+    """Hints near and beyond the int range: candidate motion vectors of +-2^31 magnitude, for which
+    'within 2' must not be decided by a wrapping 32-bit difference (the fast matcher steps aside)."""
+    W, H = 48, 20
+    I1, I2 = synth.image_pair(W, H, 16, seed=7)
+    mv = synth.hint_map(W, H, "int", seed=3, amp=5.0)
+    mv[0, 3:9, 10:20] = 2147483646.0
+    mv[1, 5:12, 22:30] = -2147483647.0
+    mv[0, 10:14, 30:40] = 3.0e9                           # converts to INT_MIN like cvttsd2si
+    mv[1, 0:4, 0:6] = 1073741823.0                        # just inside the fast matcher's range
+    mc, fl, _, S = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 0, 6, 32, want_volumes=True)
+    gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 0, 6, 32, return_sum=True)
     np.testing.assert_array_equal(gS, S)
     np.testing.assert_array_equal(gmc, mc)
     np.testing.assert_array_equal(gfl, fl)
