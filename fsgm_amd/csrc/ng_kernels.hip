@@ -180,7 +180,7 @@ __device__ __forceinline__ int ng_match4(const NgPre& q, int D, int mvx, int mvy
 // waves through an LDS atomicMin in a three-slot ring (written at step t, read at t+1, reset at t+2),
 // one barrier per step.
 __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
-    extern __shared__ uint32_t sNg[];                         // [line][2 buffers][4 arrays][Dp], then [line][3] minima
+    extern __shared__ __attribute__((aligned(16))) uint32_t sNg[];   // [line][2 buffers][4 arrays][Dp], then [line][3] minima
     int slot = 0;
 #pragma unroll
     for (int i = 1; i < 4; i++)
@@ -301,10 +301,10 @@ __global__ __launch_bounds__(256) void ng_subpixel_kernel(NgSubpixArgs a) {
 // over the threads, then wave k runs path k's O(D^2) matcher + top-2 tracking.  Frames of a
 // batch run on different CUs.  A correctness port, not a throughput kernel.
 // =============================================================================================
-__device__ __forceinline__ void otf_step_wave(Cand* Lout, const Cand* pre, const Cand* Cc, int lane,
-                                              int P1, int P2, Cand* top /*[2] in LDS*/) {
-    // calc_cost_sgm_ng.cpp:46-98 for one path, executed by one wave (64 lanes over 108 candidates)
-    const uint32_t m = (uint32_t)pre[OTF_D].cost & 0xFF;                         // :53
+__device__ __forceinline__ void otf_step_wave(Cand* Lout, const NgPre& pre, uint32_t m, const Cand* Cc, int lane,
+                                              int P2, bool safe) {
+    // calc_cost_sgm_ng.cpp:46-98 for one path, executed by one wave (64 lanes over 108 candidates);
+    // pre: the predecessor's entries as four arrays (ng_match4), m: its stored minimum (:53)
     const uint32_t jump = (m + (uint32_t)P2) & 0xFF;
     int cost[2] = {0x7FFFFFFF, 0x7FFFFFFF};
 #pragma unroll
@@ -313,7 +313,7 @@ __device__ __forceinline__ void otf_step_wave(Cand* Lout, const Cand* pre, const
         if (d < OTF_D) {
             const Cand c = Cc[d];
             Cand o = c;
-            o.cost = ng_match(pre, OTF_D, c.mvx, c.mvy, c.cost, m, jump, P1);
+            o.cost = ng_match4(pre, OTF_D, c.mvx, c.mvy, c.cost, m, jump, safe);
             Lout[d] = o;
             cost[i] = o.cost;
         }
@@ -358,13 +358,13 @@ __device__ __forceinline__ void otf_step_wave(Cand* Lout, const Cand* pre, const
         Lout[OTF_D] = t0;
         Lout[OTF_D + 1] = t1;
     }
-    (void)top;
 }
 
 __global__ __launch_bounds__(256) void otf_kernel(OtfArgs a) {
     __shared__ Cand sC[OTF_D];                    // candidates of the current pixel
     __shared__ Cand sL1[2][OTF_E];                // L1 double buffer (:197)
-    __shared__ Cand sPre[4][OTF_E];               // predecessor entries staged per path
+    __shared__ __attribute__((aligned(16))) uint32_t sPre[4][4][OTF_D];        // predecessor entries staged per path: mvx, mvy, cost & 0xFF, (cost + P1) & 0xFF
+    __shared__ int sUnsafe;                       // sticky: a motion vector near the int range was seen (exact matcher from then on)
     __shared__ Cand sOut[4][OTF_E];               // new entries per path
     __shared__ int sHint[4][3][2];                // [buffer][hint][mvx,mvy]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -377,6 +377,7 @@ __global__ __launch_bounds__(256) void otf_kernel(OtfArgs a) {
     const size_t rowE = (size_t)W * OTF_E;
     Cand* Lrow = a.Lrow + f * 6 * rowE;           // [L2,L3,L4][2][W][OTF_E]
     for (int i = tid; i < 2 * OTF_E; i += 256) { Cand z = {0, 0, 0}; sL1[i / OTF_E][i % OTF_E] = z; }   // :204
+    if (tid == 0) sUnsafe = 0;
     __syncthreads();
     int l1cur = 1, rowcur = 1;                    // :248, :250-254
     for (int y = 0; y < H; y++) {
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(256) void otf_kernel(OtfArgs a) {
                 c.cost = f64_to_i32_x86(__dadd_rn(__ddiv_rn(__dmul_rn(1.0, (double)sum), 25.0), 0.5));   // :177
                 c.mvx = mvx + offx; c.mvy = mvy + offy;
                 sC[tid] = c;
+                if (!(c.mvx > -(1 << 30) && c.mvx < (1 << 30) && c.mvy > -(1 << 30) && c.mvy < (1 << 30))) sUnsafe = 1;
             }
             __syncthreads();
             // ---- per path (wave k = path buffer k): start copy or matcher step
@@ -443,11 +445,17 @@ __global__ __launch_bounds__(256) void otf_kernel(OtfArgs a) {
                     else if (wave == 1) { psrc = Lrow + (0 * 2 + rowpre) * rowE + (size_t)(x - 1) * OTF_E; pp = If[p - W - 1]; }
                     else if (wave == 2) { psrc = Lrow + (1 * 2 + rowpre) * rowE + (size_t)x * OTF_E; pp = If[p - W]; }
                     else { psrc = Lrow + (2 * 2 + rowpre) * rowE + (size_t)(x + 1) * OTF_E; pp = If[p - W + 1]; }
-                    Cand* pre = sPre[wave];
-                    for (int d = lane; d < OTF_E; d += 64) pre[d] = psrc[d];
+                    uint32_t (*pre)[OTF_D] = sPre[wave];
+                    for (int d = lane; d < OTF_D; d += 64) {
+                        const Cand e = psrc[d];
+                        pre[0][d] = (uint32_t)e.mvx; pre[1][d] = (uint32_t)e.mvy;
+                        pre[2][d] = (uint32_t)e.cost & 0xFF; pre[3][d] = (uint32_t)(e.cost + a.P1) & 0xFF;
+                    }
+                    const uint32_t m = (uint32_t)psrc[OTF_D].cost & 0xFF;        // :53
                     __builtin_amdgcn_wave_barrier();
                     const int P2 = abs((int)If[p] - pp) > 50 ? a.P2 / 8 : a.P2;  // :101-105 adaptive P2
-                    otf_step_wave(out, pre, sC, lane, a.P1, P2, nullptr);
+                    const NgPre q{(const int32_t*)pre[0], (const int32_t*)pre[1], pre[2], pre[3]};
+                    otf_step_wave(out, q, m, sC, lane, P2, sUnsafe == 0);
                 }
             }
             __syncthreads();
