@@ -113,7 +113,9 @@ void fsgm_oracle_forward_backward_check(double* out, const double* D1, const dou
             double disp;
             fsgm_oracle_vzind2disp(&disp, &vzInd, &O[p], 1, vMax, n);          /* :15 */
             const double p2x = round(Pd0[p] + disp * nd[p]), p2y = round(Pd0[NP + p] + disp * nd[NP + p]);   /* :17-20 */
-            if (p2x < 1 || p2x > W || p2y < 1 || p2y > H) { out[p] = NAN; continue; }   /* :22-25 */
+            /* :22-25; a NaN target (NaN geometry) passes every test of :22 and then indexes D2(NaN,NaN), an
+             * error in MATLAB: treated as outside here and in the kernel */
+            if (!(p2x >= 1 && p2x <= W && p2y >= 1 && p2y <= H)) { out[p] = NAN; continue; }
             const double d2 = D2[(size_t)((int)p2y - 1) * W + ((int)p2x - 1)];
             if (d2 == -1) { out[p] = NAN; continue; }              /* :27-30 */
             if (fabs(out[p] - d2) > thr) out[p] = NAN;             /* :32-34 */

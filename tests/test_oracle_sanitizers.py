@@ -14,7 +14,8 @@ ORACLE = os.path.join(ROOT, "oracle")
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
 def test_oracle_is_asan_ubsan_clean(tmp_path):
     exe = tmp_path / "sanitize_driver"
-    srcs = [os.path.join(ORACLE, f) for f in ("sanitize_driver.cpp", "fsgm_oracle_epi.cpp", "fsgm_oracle_pyd.cpp", "fsgm_oracle_ng.cpp")]
+    srcs = [os.path.join(ORACLE, f) for f in ("sanitize_driver.cpp", "fsgm_oracle_epi.cpp", "fsgm_oracle_pyd.cpp", "fsgm_oracle_ng.cpp",
+                                                "fsgm_oracle_pyramid.cpp", "fsgm_oracle_post.cpp", "fsgm_oracle_geometry.cpp")]
     subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-ffp-contract=off", "-I", ORACLE, "-o", str(exe)] + srcs)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
