@@ -55,6 +55,10 @@ constexpr uint32_t SEL_E = 0x0C020C00u;     // v_perm: bytes 0,2 -> 2 x u16
 constexpr uint32_t SEL_O = 0x0C030C01u;     // v_perm: bytes 1,3 -> 2 x u16
 constexpr uint32_t SEL_PACK = 0x06020400u;  // v_perm(O, E): bytes E.lo, O.lo, E.hi, O.hi
 
+__device__ __forceinline__ uint32_t pk_mad16(uint32_t a, uint32_t b, uint32_t c) {        // v_pk_mad_u16
+    u16x2 r = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c);
+    return __builtin_bit_cast(uint32_t, r);
+}
 __device__ __forceinline__ void unpack16(const uint4 v, uint32_t (&E)[4], uint32_t (&O)[4]) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -257,17 +261,21 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
             }
-            // WTA: first minimum over d (:263-271) via (S << 8 | d) keys
-            uint32_t key = 0xFFFFFFFFu;
+            // WTA: first minimum over d (:263-271).  Inside a lane as packed u16 keys S*16 + (index in the lane)
+            // (S <= 8*255, so the key fits 16 bits and two of them compare per v_pk_min_u16); across the
+            // lanes of a pixel as (S << 8 | d).
             uint32_t* row = sRow + (size_t)(tid / LPP) * (D / 2) + j * 8;
+            uint32_t kmin = 0xFFFFFFFFu;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t v0 = SE[q] & 0xFFFF, v1 = SO[q] & 0xFFFF, v2 = SE[q] >> 16, v3 = SO[q] >> 16;
-                row[2 * q] = v0 | (v1 << 16);
-                row[2 * q + 1] = v2 | (v3 << 16);
-                const uint32_t dd = (uint32_t)j * 16 + 4 * q;
-                key = min(key, min(min((v0 << 8) | dd, (v1 << 8) | (dd + 1)), min((v2 << 8) | (dd + 2), (v3 << 8) | (dd + 3))));
+                row[2 * q] = __builtin_amdgcn_perm(SO[q], SE[q], 0x05040100u);       // (S[4q], S[4q+1])   natural d order for the
+                row[2 * q + 1] = __builtin_amdgcn_perm(SO[q], SE[q], 0x07060302u);   // (S[4q+2], S[4q+3]) parabola taps
+                const uint32_t kE = pk_mad16(SE[q], 0x00100010u, (uint32_t)(4 * q) | ((uint32_t)(4 * q + 2) << 16));
+                const uint32_t kO = pk_mad16(SO[q], 0x00100010u, (uint32_t)(4 * q + 1) | ((uint32_t)(4 * q + 3) << 16));
+                kmin = pk_min(kmin, pk_min(kE, kO));
             }
+            const uint32_t k16 = min(kmin & 0xFFFFu, kmin >> 16);
+            uint32_t key = ((k16 >> 4) << 8) | ((uint32_t)j * 16u + (k16 & 15u));
             key = group_min_u32<LPP>(key);
             __builtin_amdgcn_wave_barrier();                 // sRow rows are private to the wave that wrote them
             if (j == 0 && own_ok) {
@@ -493,13 +501,13 @@ __global__ __launch_bounds__(256) void hpair_sum_kernel(HpairArgs a) {
 #pragma unroll
         for (int c = 0; c < TC; c++) {
             const int x = xb + c;
-            uint32_t CE[4], CO[4], XE[4], XO[4], E2[4], O2[4];
+            uint32_t CE[4], CO[4], XE[4], XO[4];
             unpack16(cT[c], CE, CO);
             step_norm<LPP>(LE, LO, CE, CO, XE, XO, x == 0, P1pk, P2pk, j);
-            unpack16(exR[c], E2, O2);
-#pragma unroll
-            for (int q = 0; q < 4; q++) { XE[q] += E2[q]; XO[q] += O2[q]; }
-            if (x < W) *(uint4*)(Xrow + (size_t)x * D) = pack16(XE, XO);
+            // both excesses are <= P2 per byte and 2*P2 <= 255: the packed bytes add as plain words
+            uint4 xs = pack16(XE, XO);
+            xs.x += exR[c].x; xs.y += exR[c].y; xs.z += exR[c].z; xs.w += exR[c].w;
+            if (x < W) *(uint4*)(Xrow + (size_t)x * D) = xs;
         }
 #pragma unroll
         for (int c = 0; c < TC; c++) cT[c] = cN[c];
