@@ -19,3 +19,20 @@ for paths in (4, 8):
     out[f"bestD{paths}"], out[f"minC{paths}"] = bd, mc
 np.savez_compressed(os.path.join(os.path.dirname(__file__), "oracle_epi_48x36x16.npz"), **out)
 print("wrote oracle_epi_48x36x16.npz")
+
+# ---- the MATLAB layers around the MEX files: pyramidal driver, post-processing chain,
+# ---- epipolar maps.  Same caveat: this repo's oracle, kept as a regression anchor.
+g0, g1 = synth.image_pair(40, 26, 10, seed=21)
+R0 = np.stack([g0, 255 - g0, g0 // 3 + 80])
+R1 = np.stack([g1, 255 - g1, g1 // 3 + 80])
+mv, minC, lv = pyoracle.pyramidal_sgm(R0, R1, 3)
+ext = {"pyr_mv": mv, "pyr_minC": minC, "pyr_lv2": lv[1], "pyr_lv3": lv[2]}
+D1 = synth.vz_index_map(44, 30, 32, seed=22)
+pd0p, ndp, offp = synth.epi_maps(44, 30, "general", seed=23)
+f1, f2, disp = pyoracle.postprocess(D1, pd0p, ndp, offp / 8, 0.3, 33, 32)
+ext.update(post_f1=f1, post_f2=f2, post_disp=disp)
+F, Hm, epi, direction = synth.epi_geometry(36, 24, "contract")
+P, n, o, r = pyoracle.epipolar_maps(F, Hm, epi, direction, 36, 24)
+ext.update(geo_Pd0=P, geo_nd=n, geo_off=o, geo_rflow=r)
+np.savez_compressed(os.path.join(os.path.dirname(__file__), "oracle_layers.npz"), **ext)
+print("wrote oracle_layers.npz")

@@ -60,3 +60,26 @@ def test_pyramidal_sgm_vs_second_restatement(oracle, W, H, ch, numPyd, ver, hor)
     np.testing.assert_array_equal(minC, rminC)
     for a, b in zip(lv, rlv):
         np.testing.assert_array_equal(a, b)
+
+
+def test_layers_regression_fixture(oracle):
+    """Guards the oracle's pyramidal driver, post-processing chain and epipolar maps against accidental
+    edits.  NOT reference-derived: produced by this oracle itself (tests/golden/make_oracle_fixtures.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_layers.npz"))
+    g0, g1 = synth.image_pair(40, 26, 10, seed=21)
+    R0 = np.stack([g0, 255 - g0, g0 // 3 + 80])
+    R1 = np.stack([g1, 255 - g1, g1 // 3 + 80])
+    mv, minC, lv = oracle.pyramidal_sgm(R0, R1, 3)
+    np.testing.assert_array_equal(mv, g["pyr_mv"])
+    np.testing.assert_array_equal(minC, g["pyr_minC"])
+    np.testing.assert_array_equal(lv[1], g["pyr_lv2"])
+    np.testing.assert_array_equal(lv[2], g["pyr_lv3"])
+    D1 = synth.vz_index_map(44, 30, 32, seed=22)
+    pd0, nd, off = synth.epi_maps(44, 30, "general", seed=23)
+    for got, key in zip(oracle.postprocess(D1, pd0, nd, off / 8, 0.3, 33, 32), ("post_f1", "post_f2", "post_disp")):
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(g[key]))
+        np.testing.assert_array_equal(np.nan_to_num(got, nan=-7.0), np.nan_to_num(g[key], nan=-7.0))
+    F, Hm, epi, direction = synth.epi_geometry(36, 24, "contract")
+    for got, key in zip(oracle.epipolar_maps(F, Hm, epi, direction, 36, 24), ("geo_Pd0", "geo_nd", "geo_off", "geo_rflow")):
+        np.testing.assert_array_equal(got, g[key])
