@@ -208,10 +208,10 @@ def main():
                        "frames_per_gpu": B, "P1": P1, "P2": P2, "kernel": plan.kernel_name,
                        "step": "aggregate(8 paths) + sum/WTA/subpixel", "sharding": "frames, no collective"},
             # the aggregation is one stage of four kernel types that run concurrently on three streams
-            # (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane; hpair_ckpt_kernel<8> +
-            # hpair_sum_kernel<8> for the horizontal pair): the roofline is taken over the stage, HIP
+            # (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane; pair_ckpt_kernel<8,0> +
+            # pair_sum_kernel<8,0,false> for the horizontal pair): the roofline is taken over the stage, HIP
             # events fork->join
-            "roofline": {"bound": "hbm", "kernel": "aggregation stage: sweep_kernel<8,0> + sweep_kernel<8,2> + hpair_ckpt_kernel<8> + hpair_sum_kernel<8>",
+            "roofline": {"bound": "hbm", "kernel": "aggregation stage: sweep_kernel<8,0> + sweep_kernel<8,2> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES_PER_VOXEL * B * W * H * D if plan.kernel_name.startswith("sweep") else None,
                          "algorithmic_bytes": alg_bytes_launch, "stage_ms": agg_ms, "finish_ms": wta_ms},

@@ -37,11 +37,11 @@ struct fsgm_epi_plan {
     // fused-sweep aggregation (epi_sweep.hip): horizontal path costs, u16 sums, block-boundary states
     // (see enqueue(): horizontal kernel on stream_h; the frames split into two lanes that sweep
     // down then up on stream / stream_b)
-    uint8_t *dLh = nullptr, *dX = nullptr, *dXup = nullptr, *dState = nullptr, *dCkpt = nullptr;
+    uint8_t *dLh = nullptr, *dX = nullptr, *dXup = nullptr, *dState = nullptr, *dCkpt = nullptr, *dCkptV = nullptr;
     // epipolar driver (fsgm_epipolar_sgm_of_host): rotation flow, composed flow, RGB staging
     double *dRflow = nullptr, *dFlow = nullptr;
     uint8_t* dRgb = nullptr;
-    int lh_planes = 1;                   // 1: horizontal pair as its excess sum X_h (hpair kernels); 2: two path volumes
+    int lh_planes = 1;                   // 1: horizontal pair as its excess sum X_h (pair kernels); 2: two path volumes
     uint4* dRec = nullptr;
     uint16_t* dS0 = nullptr;
     size_t state_stride = 0;
@@ -75,6 +75,9 @@ static void select_kernel(fsgm_epi_plan* p) {
     // 1242x375x128 frame; crossover at 4, measured).
     const bool want = p->agg_mode == 2 || (p->agg_mode == 0 && p->batch >= 4);
     if (nowrap && 3 * p->P2 <= 255 && p->prm.paths == 8 && want) p->kernel_kind = AGG_SWEEP;
+    // the shipped 4-path configuration: both axes as pair kernels, the vertical one final (2*P2 <= 255:
+    // the excess sum of a pair fits a byte)
+    if (nowrap && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
 }
 
 extern "C" {
@@ -109,7 +112,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dState, p->dCkpt, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -246,6 +249,21 @@ fsgm_status fsgm_epi_plan_upload_offset(fsgm_epi_plan* p, int32_t f, const doubl
     return FSGM_OK;
 }
 
+static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
+    if (p->dCkptV) return FSGM_OK;
+    const size_t B = p->batch;
+    p->lh_planes = 1;
+    FSGM_HIP(hipMalloc((void**)&p->dLh, B * p->N));
+    FSGM_HIP(hipMalloc((void**)&p->dCkpt, B * pair_ckpt_bytes(p->W, p->H, p->D, 0)));
+    FSGM_HIP(hipMalloc((void**)&p->dRec, B * p->NP * sizeof(uint4)));
+    FSGM_HIP(hipMalloc((void**)&p->dS0, B * p->NP * sizeof(uint16_t)));
+    FSGM_HIP(hipStreamCreateWithFlags(&p->stream_h, hipStreamNonBlocking));
+    FSGM_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    FSGM_HIP(hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming));
+    FSGM_HIP(hipMalloc((void**)&p->dCkptV, B * pair_ckpt_bytes(p->W, p->H, p->D, 1)));   // last: marks the set complete
+    return FSGM_OK;
+}
+
 static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     if (p->dX) return FSGM_OK;
     const size_t B = p->batch;
@@ -254,7 +272,7 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     // 0 = the two path volumes of the per-direction kernel (A/B switch)
     { const char* e = getenv("FSGM_EPI_HPAIR"); p->lh_planes = (e && *e && atoi(e) == 0) ? 2 : 1; }
     FSGM_HIP(hipMalloc((void**)&p->dLh, B * p->N * p->lh_planes));
-    if (p->lh_planes == 1) FSGM_HIP(hipMalloc((void**)&p->dCkpt, B * hpair_ckpt_bytes(p->W, p->H, p->D)));
+    if (p->lh_planes == 1) FSGM_HIP(hipMalloc((void**)&p->dCkpt, B * pair_ckpt_bytes(p->W, p->H, p->D, 0)));
     FSGM_HIP(hipMalloc((void**)&p->dState, 2 * B * p->state_stride));
     FSGM_HIP(hipMalloc((void**)&p->dRec, B * p->NP * sizeof(uint4)));
     FSGM_HIP(hipMalloc((void**)&p->dS0, B * p->NP * sizeof(uint16_t)));
@@ -273,6 +291,10 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
 static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
     if (p->kernel_kind == AGG_SWEEP && (stages & (FSGM_STAGE_AGGREGATE | FSGM_STAGE_WTA))) {
         fsgm_status st = ensure_sweep_buffers(p);
+        if (st != FSGM_OK) return st;
+    }
+    if (p->kernel_kind == AGG_PAIRS && (stages & (FSGM_STAGE_AGGREGATE | FSGM_STAGE_WTA))) {
+        fsgm_status st = ensure_pairs_buffers(p);
         if (st != FSGM_OK) return st;
     }
     if (stages & FSGM_STAGE_COST) {
@@ -299,11 +321,11 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         FSGM_HIP(hipStreamWaitEvent(p->stream_h, p->ev_fork, 0));
         for (int l = 1; l < NLN; l++) FSGM_HIP(hipStreamWaitEvent(lane_stream[l], p->ev_fork, 0));
         if (p->lh_planes == 1) {                     // the two horizontal paths as one excess sum X_h
-            HpairArgs h;
-            h.C = p->dC; h.c_frame_stride = p->N; h.Xh = p->dLh; h.xh_frame_stride = p->N;
-            h.ckpt = p->dCkpt; h.ckpt_frame_stride = hpair_ckpt_bytes(p->W, p->H, p->D);
+            PairArgs h{};
+            h.C = p->dC; h.c_frame_stride = p->N; h.X = p->dLh; h.x_frame_stride = p->N;
+            h.ckpt = p->dCkpt; h.ckpt_frame_stride = pair_ckpt_bytes(p->W, p->H, p->D, 0);
             h.W = p->W; h.H = p->H; h.D = p->D; h.P1 = p->P1; h.P2 = p->P2;
-            launch_hpair(p->stream_h, h, p->batch);
+            launch_pair(p->stream_h, h, p->batch, 0, false);
         } else {                                     // per-direction kernel, 2 slots
             AggArgs a;
             a.C = p->dC; a.L = p->dLh;
@@ -333,6 +355,24 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
             }
             f0 += nf;
         }
+    } else if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_PAIRS) {
+        // 4 paths: the horizontal pair -> X_h on stream_h while the vertical pair's checkpoint pass runs
+        // here; then the vertical sum pass adds X_h + 4*C and does the WTA (7.5 B per voxel, S never in HBM)
+        FSGM_HIP(hipEventRecord(p->ev_fork, p->stream));
+        FSGM_HIP(hipStreamWaitEvent(p->stream_h, p->ev_fork, 0));
+        PairArgs h{};
+        h.C = p->dC; h.c_frame_stride = p->N; h.X = p->dLh; h.x_frame_stride = p->N;
+        h.ckpt = p->dCkpt; h.ckpt_frame_stride = pair_ckpt_bytes(p->W, p->H, p->D, 0);
+        h.W = p->W; h.H = p->H; h.D = p->D; h.P1 = p->P1; h.P2 = p->P2;
+        launch_pair(p->stream_h, h, p->batch, 0, false);
+        FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
+        PairArgs v = h;
+        v.X = nullptr; v.x_frame_stride = 0;
+        v.ckpt = p->dCkptV; v.ckpt_frame_stride = pair_ckpt_bytes(p->W, p->H, p->D, 1);
+        v.Xother = p->dLh; v.xo_frame_stride = p->N; v.rec = p->dRec; v.s0 = p->dS0; v.nC = 4;
+        launch_pair(p->stream, v, p->batch, 1, true, 1);
+        FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_h, 0));
+        launch_pair(p->stream, v, p->batch, 1, true, 2);
     } else if (stages & FSGM_STAGE_AGGREGATE) {
         if (!p->dL) FSGM_HIP(hipMalloc((void**)&p->dL, (size_t)p->batch * p->N * p->prm.paths));
         AggArgs a;
@@ -341,8 +381,8 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
         launch_aggregate(p->stream, a, p->prm.paths, p->batch, p->kernel_kind);
     }
-    if ((stages & FSGM_STAGE_WTA) && p->kernel_kind == AGG_SWEEP) {
-        WtaArgs a;                                   // the argmin happened inside the final sweep; finish the records
+    if ((stages & FSGM_STAGE_WTA) && (p->kernel_kind == AGG_SWEEP || p->kernel_kind == AGG_PAIRS)) {
+        WtaArgs a;                                   // the argmin happened inside the final sweep / pair pass; finish the records
         a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
         a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
         a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
@@ -481,7 +521,35 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         SweepSumArgs q;
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX + (size_t)f * p->N; q.Xup = p->dXup; q.v_frame_stride = p->N;
         q.Lh = p->dLh + (size_t)f * p->N * p->lh_planes; q.lh_frame_stride = p->N * p->lh_planes; q.lh_dir_stride = p->N;
-        q.lh_planes = p->lh_planes; q.Sdbg = p->dS;
+        q.lh_planes = p->lh_planes; q.nC = p->lh_planes == 2 ? 6 : 8; q.Sdbg = p->dS;
+        launch_wta_sweep(p->stream, a, q, 1);
+        FSGM_HIP(hipGetLastError());
+        FSGM_HIP(hipStreamSynchronize(p->stream));
+        FSGM_HIP(hipMemcpy(S, p->dS, p->N * 4, hipMemcpyDeviceToHost));
+        return FSGM_OK;
+    }
+    if (p->kernel_kind == AGG_PAIRS) {
+        // Debug tap of the 4-path pair pipeline: materialise the vertical pair's X_v of that frame with a
+        // non-final sum pass, then wta_sweep_kernel rebuilds S = X_v + X_h + 4C.
+        FSGM_HIP(hipStreamSynchronize(p->stream));
+        fsgm_status es = ensure_pairs_buffers(p);
+        if (es != FSGM_OK) return es;
+        if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
+        if (!p->dX) FSGM_HIP(hipMalloc((void**)&p->dX, p->N));
+        PairArgs v{};
+        v.C = p->dC + (size_t)f * p->N; v.c_frame_stride = p->N; v.X = p->dX; v.x_frame_stride = p->N;
+        v.ckpt = p->dCkptV; v.ckpt_frame_stride = pair_ckpt_bytes(p->W, p->H, p->D, 1);
+        v.W = p->W; v.H = p->H; v.D = p->D; v.P1 = p->P1; v.P2 = p->P2;
+        launch_pair(p->stream, v, 1, 1, false);
+        WtaArgs a;
+        a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
+        a.off = p->dOff + f * p->NP; a.bestD = p->dBestD + f * p->NP; a.minC = p->dMinC + f * p->NP; a.vMax = p->vMax;
+        a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
+        a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
+        SweepSumArgs q;
+        q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX; q.Xup = nullptr; q.v_frame_stride = p->N;
+        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_dir_stride = p->N;
+        q.lh_planes = 1; q.nC = 4; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));
@@ -526,6 +594,7 @@ const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* p) {
         case AGG_PACKED_NOWRAP: return "packed16/nowrap";
         case AGG_PACKED_WRAP: return "packed16/wrap";
         case AGG_SWEEP: return "sweep16/nowrap";
+        case AGG_PAIRS: return "pairs16/nowrap";
         default: return "generic";
     }
 }

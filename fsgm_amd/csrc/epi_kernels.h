@@ -51,7 +51,7 @@ struct SweepArgs {
     uint8_t* X;               // [frames] u8 excess sums: written by modes 0/1, read (the down sweep's) by mode 2
     size_t x_frame_stride;
     const uint8_t* Lh;        // mode 2: horizontal pair, lh_planes = 2: [frames][2] path costs (from the left, from the
-    size_t lh_frame_stride, lh_dir_stride;    // right); lh_planes = 1: [frames] their excess sum X_h (hpair kernels)
+    size_t lh_frame_stride, lh_dir_stride;    // right); lh_planes = 1: [frames] their excess sum X_h (pair kernels)
     int lh_planes;
     uint4* rec;               // mode 2: [frames][NP] {best, minC, S[best-1], S[best+1]}
     uint16_t* s0;             // mode 2: [frames][NP] S[0] of every pixel
@@ -71,16 +71,22 @@ struct SweepSumArgs {          // what wta_sweep_kernel adds up (all u8 volumes,
     const uint8_t* Lh;        // [frames][2] horizontal path costs (from the left, from the right), or [frames] X_h
     size_t lh_frame_stride, lh_dir_stride;
     int lh_planes;            // 2 or 1, as in SweepArgs
+    int nC;                   // S = nC*C + Xdn + Xup + (Lh planes); Xup may be null
     uint32_t* Sdbg;           // optional natural-order u32 dump of S [frames][NP][D]
 };
 
-struct HpairArgs {             // horizontal pair as one excess sum (epi_sweep.hip, hpair kernels)
+struct PairArgs {              // an opposite pair of paths as one excess sum (epi_sweep.hip, pair kernels)
     const uint8_t* C;         // [frames] cost volumes
     size_t c_frame_stride;
-    uint8_t* Xh;              // [frames] u8: (L_left - C) + (L_right - C)
-    size_t xh_frame_stride;
-    uint8_t* ckpt;            // [frames][H][ntiles-1][D] normalised from-the-right states at the tile boundaries
+    uint8_t* X;               // [frames] u8 out: (L_fwd - C) + (L_bwd - C)              (not in the final pass)
+    size_t x_frame_stride;
+    uint8_t* ckpt;            // [frames][lines][ntiles-1][D] normalised backward states at the tile boundaries
     size_t ckpt_frame_stride;
+    const uint8_t* Xother;    // final pass: [frames] the other axis' excess sum
+    size_t xo_frame_stride;
+    uint4* rec;               // final pass: [frames][NP] {best, minC, S[best-1], S[best+1]}
+    uint16_t* s0;             // final pass: [frames][NP] S[0] of every pixel
+    int nC;                   // final pass: S = X + Xother + nC * C
     int W, H, D;
     int P1, P2;
 };
@@ -97,7 +103,7 @@ struct FbArgs {                // forward-backward check (calc_cost_sgm.cpp:429-
     int W, H, n, thr;
 };
 
-enum { AGG_PACKED_NOWRAP = 0, AGG_PACKED_WRAP = 1, AGG_GENERIC = 2, AGG_SWEEP = 3 };
+enum { AGG_PACKED_NOWRAP = 0, AGG_PACKED_WRAP = 1, AGG_GENERIC = 2, AGG_SWEEP = 3, AGG_PAIRS = 4 };
 
 int  agg_packed_lpp(int D);   // lanes per pixel of the packed kernels, 0 if D is not 16<<k, k<=4
 void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int H, int frames);
@@ -107,8 +113,8 @@ void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
 int    sweep_rows_per_launch(int D);
 size_t sweep_state_bytes(int W, int D);   // one state buffer of one frame
 void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode);   // 0 down, 1 up, 2 up + fused WTA
-size_t hpair_ckpt_bytes(int W, int H, int D);               // per frame
-void launch_hpair(hipStream_t st, const HpairArgs& a, int frames);
+size_t pair_ckpt_bytes(int W, int H, int D, int axis);      // per frame; axis 0 horizontal, 1 vertical
+void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase = 0);
 void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames);
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);
 void launch_fb_check(hipStream_t st, const FbArgs& a, int frames);

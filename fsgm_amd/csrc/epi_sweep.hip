@@ -6,8 +6,8 @@
 // (+1,+1) and from above-right (-1,+1), calc_cost_sgm.cpp:193-226 -- are computed TOGETHER for the
 // same pixel, so C is read once per sweep and only their sum leaves the chip:
 //
-//   hpair kernels           C -> X_h  = (L_left - C) + (L_right - C), the two horizontal paths      (u8)
-//                           (checkpoint-and-recompute, see the hpair section below)
+//   pair kernels (AXIS 0)   C -> X_h  = (L_left - C) + (L_right - C), the two horizontal paths      (u8)
+//                           (checkpoint-and-recompute, see the pair section below)
 //   down sweep   (MODE 0)   C -> X_dn = sum over the three pass-0 paths from above of (L_r - C)  (u8)
 //   final sweep  (MODE 2)   on the point-mirrored frame (pass 1): its own three paths, then in
 //                           registers S = X_up + X_dn + X_h + 8*C and the WTA;
@@ -19,7 +19,7 @@
 // 1 B per voxel each, and neither X_up nor S (u32 in the reference) ever reaches HBM.  8.25 B per
 // voxel by design (9.65 measured) instead of 24.  One sweep launch alone -- strips x frames
 // workgroups -- is too small to fill 256 CUs, so the host forks the work over three streams: the
-// hpair kernels, and two lanes of frames that each sweep down and then up (capi_epi.hip).
+// pair kernels, and two lanes of frames that each sweep down and then up (capi_epi.hip).
 // (lh_planes = 2 keeps the earlier form: both horizontal path volumes from agg_packed_kernel,
 // S = ... + 6*C + L_left + L_right; FSGM_EPI_HPAIR=0, for A/B runs.)
 // MODE 1 (plain up sweep writing X_up) and wta_sweep_kernel exist for the debug tap that
@@ -107,6 +107,39 @@ __device__ __forceinline__ void step_norm(uint32_t (&LE)[4], uint32_t (&LO)[4], 
     const uint32_t mpk = mx | (mx << 16);
 #pragma unroll
     for (int k = 0; k < 4; k++) { LE[k] = pk_sub(NE[k], mpk); LO[k] = pk_sub(NO[k], mpk); }
+}
+
+// Per-pixel WTA of the final passes: S (packed u16, E/O split) of the LPP lanes of a pixel -> one record
+// {best, minC, S[best-1], S[best+1]} + S[0] (calc_cost_sgm.cpp:263-271; the parabola runs in
+// sweep_finish_kernel).  First minimum over d: inside a lane as packed u16 keys S*16 + (index in the
+// lane) (S <= 8*255, so a key fits 16 bits and two of them compare per v_pk_min_u16); across the lanes
+// of a pixel as (S << 8 | d).  sRow: 8 u32 per lane, rows private to the wave that writes them.
+template <int LPP>
+__device__ __forceinline__ void wta_row_record(const uint32_t (&SE)[4], const uint32_t (&SO)[4], uint32_t* sRow, int tid, int j,
+                                               bool ok, uint4* rec, uint16_t* s0, size_t idx) {
+    constexpr int D = LPP * 16;
+    uint32_t* row = sRow + (size_t)(tid / LPP) * (D / 2) + j * 8;
+    uint32_t kmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        row[2 * q] = __builtin_amdgcn_perm(SO[q], SE[q], 0x05040100u);       // (S[4q], S[4q+1])   natural d order for the
+        row[2 * q + 1] = __builtin_amdgcn_perm(SO[q], SE[q], 0x07060302u);   // (S[4q+2], S[4q+3]) parabola taps
+        const uint32_t kE = pk_mad16(SE[q], 0x00100010u, (uint32_t)(4 * q) | ((uint32_t)(4 * q + 2) << 16));
+        const uint32_t kO = pk_mad16(SO[q], 0x00100010u, (uint32_t)(4 * q + 1) | ((uint32_t)(4 * q + 3) << 16));
+        kmin = pk_min(kmin, pk_min(kE, kO));
+    }
+    const uint32_t k16 = min(kmin & 0xFFFFu, kmin >> 16);
+    uint32_t key = ((k16 >> 4) << 8) | ((uint32_t)j * 16u + (k16 & 15u));
+    key = group_min_u32<LPP>(key);
+    __builtin_amdgcn_wave_barrier();
+    if (j == 0 && ok) {
+        const uint32_t best = key & 0xFF, minc = key >> 8;
+        const uint16_t* srow = (const uint16_t*)(sRow + (size_t)(tid / LPP) * (D / 2));
+        const uint32_t c_1 = best > 0 ? srow[best - 1] : 0u;
+        const uint32_t c1 = best + 1 < (uint32_t)D ? srow[best + 1] : 0u;   // best == D-1: the finish kernel takes the next pixel's S[0]
+        rec[idx] = make_uint4(best, minc, c_1, c1);
+        s0[idx] = (uint16_t)srow[0];
+    }
 }
 
 }  // namespace
@@ -261,32 +294,7 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
             }
-            // WTA: first minimum over d (:263-271).  Inside a lane as packed u16 keys S*16 + (index in the lane)
-            // (S <= 8*255, so the key fits 16 bits and two of them compare per v_pk_min_u16); across the
-            // lanes of a pixel as (S << 8 | d).
-            uint32_t* row = sRow + (size_t)(tid / LPP) * (D / 2) + j * 8;
-            uint32_t kmin = 0xFFFFFFFFu;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                row[2 * q] = __builtin_amdgcn_perm(SO[q], SE[q], 0x05040100u);       // (S[4q], S[4q+1])   natural d order for the
-                row[2 * q + 1] = __builtin_amdgcn_perm(SO[q], SE[q], 0x07060302u);   // (S[4q+2], S[4q+3]) parabola taps
-                const uint32_t kE = pk_mad16(SE[q], 0x00100010u, (uint32_t)(4 * q) | ((uint32_t)(4 * q + 2) << 16));
-                const uint32_t kO = pk_mad16(SO[q], 0x00100010u, (uint32_t)(4 * q + 1) | ((uint32_t)(4 * q + 3) << 16));
-                kmin = pk_min(kmin, pk_min(kE, kO));
-            }
-            const uint32_t k16 = min(kmin & 0xFFFFu, kmin >> 16);
-            uint32_t key = ((k16 >> 4) << 8) | ((uint32_t)j * 16u + (k16 & 15u));
-            key = group_min_u32<LPP>(key);
-            __builtin_amdgcn_wave_barrier();                 // sRow rows are private to the wave that wrote them
-            if (j == 0 && own_ok) {
-                const uint32_t best = key & 0xFF, minc = key >> 8;
-                const uint16_t* srow = (const uint16_t*)(sRow + (size_t)(tid / LPP) * (D / 2));
-                const uint32_t c_1 = best > 0 ? srow[best - 1] : 0u;
-                const uint32_t c1 = best + 1 < (uint32_t)D ? srow[best + 1] : 0u;   // best == D-1: fsgm finish kernel takes the next pixel's S[0]
-                const int ap = pix_of(gx, y);
-                a.rec[f * (size_t)NP + ap] = make_uint4(best, minc, c_1, c1);
-                a.s0[f * (size_t)NP + ap] = (uint16_t)srow[0];
-            }
+            wta_row_record<LPP>(SE, SO, sRow, tid, j, own_ok, a.rec, a.s0, f * (size_t)NP + pix_of(gx, y));
         }
         __syncthreads();                                         // diagonal states of row y visible to row y+1
     };
@@ -351,15 +359,17 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
     const uint8_t* Lh = q.Lh + f * q.lh_frame_stride;
     uint32_t E[4], O[4], E2[4], O2[4];
     unpack16(*(const uint4*)(q.C + f * q.v_frame_stride + bo), E, O);
-    const uint32_t nC = q.lh_planes == 2 ? 6u : 8u;
+    const uint32_t nC = (uint32_t)q.nC;
 #pragma unroll
     for (int k = 0; k < 4; k++) { E[k] *= nC; O[k] *= nC; }
     unpack16(*(const uint4*)(q.Xdn + f * q.v_frame_stride + bo), E2, O2);
 #pragma unroll
     for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
-    unpack16(*(const uint4*)(q.Xup + f * q.v_frame_stride + bo), E2, O2);
+    if (q.Xup) {
+        unpack16(*(const uint4*)(q.Xup + f * q.v_frame_stride + bo), E2, O2);
 #pragma unroll
-    for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
+        for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
+    }
     unpack16(*(const uint4*)(Lh + bo), E2, O2);
 #pragma unroll
     for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
             if (best + 1 < (uint32_t)D) c1 = srow[best + 1];
             else if (p + 1 < NP) {                                           // next pixel's d=0 (:296)
                 const size_t nb = f * q.v_frame_stride + (size_t)(p + 1) * D;
-                c1 = nC * q.C[nb] + q.Xdn[nb] + q.Xup[nb] + Lh[(size_t)(p + 1) * D] +
+                c1 = nC * q.C[nb] + q.Xdn[nb] + (q.Xup ? (uint32_t)q.Xup[nb] : 0u) + Lh[(size_t)(p + 1) * D] +
                      (q.lh_planes == 2 ? (uint32_t)Lh[q.lh_dir_stride + (size_t)(p + 1) * D] : 0u);
             }
         }
@@ -403,111 +413,139 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
 }
 
 // =============================================================================================
-// Horizontal pair as ONE excess sum  X_h = (L_left - C) + (L_right - C)  (<= 2*P2, one byte).
-// The two horizontal paths (calc_cost_sgm.cpp:183-192 and its pass-1 mirror) run in opposite
-// directions along a row, so their values for a pixel exist at different times; writing both path
-// volumes and reading them back in the final sweep costs 6 B per voxel (C twice, 2 writes, 2 reads).
+// An opposite pair of paths as ONE excess sum  X = (L_fwd - C) + (L_bwd - C)  (<= 2*P2, one byte).
+// The two paths of an axis (calc_cost_sgm.cpp:183-202 and their pass-1 mirrors) run in opposite
+// directions along a line, so their values for a pixel exist at different times; writing both path
+// volumes and reading them back costs 6 B per voxel (C twice, 2 writes, 2 reads).
 // Checkpoint-and-recompute brings that to ~4.25 B:
-//   pass A (hpair_ckpt_kernel)  right -> left, keeps nothing but the normalised from-the-right state at
-//          every HP_TC-th column (1/HP_TC B per voxel);
-//   pass B (hpair_sum_kernel)   left -> right in tiles of HP_TC columns: the tile's from-the-right
-//          excesses are recomputed from the checkpoint on its right edge into registers, then the
-//          from-the-left path crosses the tile, adds them and stores X_h.  The tile's C stays in
-//          registers between the two.
-// The final sweep then adds X_h + 8*C instead of L_left + L_right + 6*C.  Same lane layout as
-// agg_packed_kernel: LPP lanes x 16 d per pixel, 64/LPP rows per wave.
+//   pass A (pair_ckpt_kernel)  end -> start of the line, keeps nothing but the normalised backward
+//          state at every HP_TC-th position (1/HP_TC B per voxel);
+//   pass B (pair_sum_kernel)   start -> end in tiles of HP_TC positions: the tile's backward excesses
+//          are recomputed from the checkpoint on its far edge into registers, then the forward path
+//          crosses the tile, adds them and stores X.  The tile's C stays in registers between the two.
+// AXIS 0: lines = image rows (the horizontal pair; 64/LPP rows per wave, consecutive positions 16*LPP
+//         bytes apart); AXIS 1: lines = image columns (the vertical pair; 64/LPP adjacent columns per
+//         wave -- one contiguous run per step -- consecutive positions a row apart).
+// FINAL:  instead of storing X, pass B adds the other axis' X and nC*C and does the WTA on the spot --
+//         the 4-path pipeline (the reference's shipped configuration): horizontal pair -> X_h, vertical
+//         pair final: S = X_v + X_h + 4*C, 7.5 B per voxel for 4 voxel-paths, S never in HBM.
+// Same lane layout as agg_packed_kernel: LPP lanes x 16 d per pixel.
 // =============================================================================================
 #ifndef FSGM_HP_TC
-#define FSGM_HP_TC 8            // tile width = checkpoint spacing in columns (A/B knob)
+#define FSGM_HP_TC 8            // tile width = checkpoint spacing in positions (A/B knob)
 #endif
 constexpr int HP_TC = FSGM_HP_TC;
 
-template <int LPP>
-__global__ __launch_bounds__(256) void hpair_ckpt_kernel(HpairArgs a) {
+template <int LPP, int AXIS>
+__global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
     constexpr int PXW = 64 / LPP, D = LPP * 16, PF = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / LPP, j = lane % LPP;
-    const int W = a.W, H = a.H;
+    const int nl = AXIS ? a.W : a.H, len = AXIS ? a.H : a.W;
     const int lg = (int)blockIdx.x * 4 + wave;
-    if (lg * PXW >= H) return;                                  // wave-uniform
-    const int l = min(lg * PXW + g, H - 1);                     // rows past the last redo the last (same bytes, same addresses)
-    const int NT = (W + HP_TC - 1) / HP_TC;
+    if (lg * PXW >= nl) return;                                 // wave-uniform
+    const int l = min(lg * PXW + g, nl - 1);                    // lines past the last redo the last (same bytes, same addresses)
+    const int NT = (len + HP_TC - 1) / HP_TC;
     if (NT < 2) return;                                         // a single tile starts at the border: no checkpoint
     const size_t f = blockIdx.y;
-    const uint8_t* __restrict__ Crow = a.C + f * a.c_frame_stride + ((size_t)l * W) * D + (size_t)j * 16;
-    uint8_t* __restrict__ Krow = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * (NT - 1)) * D + (size_t)j * 16;
+    const size_t lstride = AXIS ? (size_t)D : (size_t)a.W * D, tstride = AXIS ? (size_t)a.W * D : (size_t)D;
+    const uint8_t* __restrict__ Cl = a.C + f * a.c_frame_stride + (size_t)l * lstride + (size_t)j * 16;
+    uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * (NT - 1)) * D + (size_t)j * 16;
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
     uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};
-    auto load_c = [&](int x) -> uint4 { return *(const uint4*)(Crow + (size_t)max(x, 0) * D); };
+    auto load_c = [&](int t) -> uint4 { return *(const uint4*)(Cl + (size_t)max(t, 0) * tstride); };
     uint4 ring[PF];
 #pragma unroll
-    for (int i = 0; i < PF; i++) ring[i] = load_c(W - 1 - i);
-    const int last = HP_TC;                                     // the leftmost checkpoint column
-    for (int x0 = W - 1; x0 >= last; x0 -= PF) {
+    for (int i = 0; i < PF; i++) ring[i] = load_c(len - 1 - i);
+    const int last = HP_TC;                                     // the nearest checkpoint to the line start
+    for (int t0 = len - 1; t0 >= last; t0 -= PF) {
 #pragma unroll
         for (int i = 0; i < PF; i++) {
-            const int x = x0 - i;
+            const int t = t0 - i;
             const uint4 cw = ring[i];
-            ring[i] = load_c(x - PF);
+            ring[i] = load_c(t - PF);
             uint32_t CE[4], CO[4], XE[4], XO[4];
             unpack16(cw, CE, CO);
-            step_norm<LPP>(LE, LO, CE, CO, XE, XO, x == W - 1, P1pk, P2pk, j);
-            // columns below `last` in the final group are computed but not needed; x >= 0 always holds there
-            if (x >= last && (x % HP_TC) == 0) *(uint4*)(Krow + (size_t)(x / HP_TC - 1) * D) = pack16(LE, LO);
+            step_norm<LPP>(LE, LO, CE, CO, XE, XO, t == len - 1, P1pk, P2pk, j);
+            // positions below `last` in the final group are computed but not needed; t >= 0 always holds there
+            if (t >= last && (t % HP_TC) == 0) *(uint4*)(Kl + (size_t)(t / HP_TC - 1) * D) = pack16(LE, LO);
         }
     }
 }
 
-template <int LPP>
-__global__ __launch_bounds__(256) void hpair_sum_kernel(HpairArgs a) {
+template <int LPP, int AXIS, bool FINAL>
+__global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs a) {
     constexpr int PXW = 64 / LPP, D = LPP * 16, TC = HP_TC;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t sRow[FINAL ? 4 * 64 * 8 : 1];            // FINAL: S of the wave's pixels in natural d order (u16)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPP, j = lane % LPP;
-    const int W = a.W, H = a.H;
+    const int W = a.W, NP = a.W * a.H;
+    const int nl = AXIS ? a.W : a.H, len = AXIS ? a.H : a.W;
     const int lg = (int)blockIdx.x * 4 + wave;
-    if (lg * PXW >= H) return;
-    const int l = min(lg * PXW + g, H - 1);
-    const int NT = (W + TC - 1) / TC;
+    if (lg * PXW >= nl) return;
+    const bool own_ok = lg * PXW + g < nl;
+    const int l = min(lg * PXW + g, nl - 1);
+    const int NT = (len + TC - 1) / TC;
     const size_t f = blockIdx.y;
-    const uint8_t* __restrict__ Crow = a.C + f * a.c_frame_stride + ((size_t)l * W) * D + (size_t)j * 16;
-    uint8_t* __restrict__ Xrow = a.Xh + f * a.xh_frame_stride + ((size_t)l * W) * D + (size_t)j * 16;
-    const uint8_t* __restrict__ Krow = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * max(NT - 1, 1)) * D + (size_t)j * 16;
+    const size_t lstride = AXIS ? (size_t)D : (size_t)W * D, tstride = AXIS ? (size_t)W * D : (size_t)D;
+    const size_t lbase = (size_t)l * lstride + (size_t)j * 16;
+    const uint8_t* __restrict__ Cl = a.C + f * a.c_frame_stride + lbase;
+    uint8_t* __restrict__ Xl = a.X + f * a.x_frame_stride + lbase;                       // !FINAL: this pair's excess sum, out
+    const uint8_t* __restrict__ Ol = FINAL ? a.Xother + f * a.xo_frame_stride + lbase : nullptr;   // FINAL: the other pair's, in
+    const uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * max(NT - 1, 1)) * D + (size_t)j * 16;
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
-    uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};          // from-the-left state, carried across tiles
-    auto load_c = [&](int x) -> uint4 { return *(const uint4*)(Crow + (size_t)min(x, W - 1) * D); };
-    auto load_k = [&](int t) -> uint4 { return *(const uint4*)(Krow + (size_t)min(t, max(NT - 2, 0)) * D); };
+    uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};          // forward state, carried across tiles
+    auto load_c = [&](int t) -> uint4 { return *(const uint4*)(Cl + (size_t)min(t, len - 1) * tstride); };
+    auto load_k = [&](int t) -> uint4 { return *(const uint4*)(Kl + (size_t)min(t, max(NT - 2, 0)) * D); };
     uint4 cT[TC], cN[TC], kT = load_k(0), kN;
 #pragma unroll
     for (int c = 0; c < TC; c++) cT[c] = load_c(c);
     for (int t = 0; t < NT; t++) {
-        const int xb = t * TC;
+        const int tb = t * TC;
 #pragma unroll
-        for (int c = 0; c < TC; c++) cN[c] = load_c(xb + TC + c);      // next tile, in flight while this one computes
+        for (int c = 0; c < TC; c++) cN[c] = load_c(tb + TC + c);      // next tile, in flight while this one computes
         kN = load_k(t + 1);
-        // from the right, through the tile: columns past the image come first and are wiped by the path
-        // start at x = W-1 (:152-180); a tile inside the image starts from its checkpoint
+        // backward path through the tile: positions past the line end come first and are wiped by the path
+        // start at the last position (:152-180); a tile inside the line starts from its checkpoint
         uint32_t RE[4], RO[4];
         unpack16(kT, RE, RO);
         uint4 exR[TC];
 #pragma unroll
         for (int c = TC - 1; c >= 0; c--) {
-            const int x = xb + c;
+            const int x = tb + c;
             uint32_t CE[4], CO[4], XE[4], XO[4];
             unpack16(cT[c], CE, CO);
-            step_norm<LPP>(RE, RO, CE, CO, XE, XO, x >= W - 1, P1pk, P2pk, j);
+            step_norm<LPP>(RE, RO, CE, CO, XE, XO, x >= len - 1, P1pk, P2pk, j);
             exR[c] = pack16(XE, XO);
         }
-        // from the left, adding the two excesses
+        uint4 xo[TC];
+        if (FINAL) {
+#pragma unroll
+            for (int c = 0; c < TC; c++) xo[c] = *(const uint4*)(Ol + (size_t)min(tb + c, len - 1) * tstride);
+        }
+        // forward path, adding the two excesses
 #pragma unroll
         for (int c = 0; c < TC; c++) {
-            const int x = xb + c;
+            const int x = tb + c;
             uint32_t CE[4], CO[4], XE[4], XO[4];
             unpack16(cT[c], CE, CO);
             step_norm<LPP>(LE, LO, CE, CO, XE, XO, x == 0, P1pk, P2pk, j);
             // both excesses are <= P2 per byte and 2*P2 <= 255: the packed bytes add as plain words
             uint4 xs = pack16(XE, XO);
             xs.x += exR[c].x; xs.y += exR[c].y; xs.z += exR[c].z; xs.w += exR[c].w;
-            if (x < W) *(uint4*)(Xrow + (size_t)x * D) = xs;
+            if (!FINAL) {
+                if (x < len) *(uint4*)(Xl + (size_t)x * tstride) = xs;
+            } else {
+                // S = this pair + the other pair + nC*C (calc_cost_sgm.cpp:227-232), WTA on the spot
+                uint32_t SE[4], SO[4], E2[4], O2[4];
+                unpack16(xs, SE, SO);
+                unpack16(xo[c], E2, O2);
+                const uint32_t nC = (uint32_t)a.nC;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { SE[q] += E2[q] + nC * CE[q]; SO[q] += O2[q] + nC * CO[q]; }
+                const int ap = AXIS ? x * W + l : l * W + x;     // pixel index (wave-uniform validity: x < len)
+                wta_row_record<LPP>(SE, SO, sRow, tid, j, own_ok && x < len, a.rec, a.s0, f * (size_t)NP + (size_t)min(ap, NP - 1));
+            }
         }
 #pragma unroll
         for (int c = 0; c < TC; c++) cT[c] = cN[c];
@@ -515,26 +553,39 @@ __global__ __launch_bounds__(256) void hpair_sum_kernel(HpairArgs a) {
     }
 }
 
-size_t hpair_ckpt_bytes(int W, int H, int D) {
-    const int NT = (W + HP_TC - 1) / HP_TC;
-    return (size_t)H * (size_t)(NT > 1 ? NT - 1 : 1) * D;
+size_t pair_ckpt_bytes(int W, int H, int D, int axis) {
+    const int len = axis ? H : W, nl = axis ? W : H;
+    const int NT = (len + HP_TC - 1) / HP_TC;
+    return (size_t)nl * (size_t)(NT > 1 ? NT - 1 : 1) * D;
 }
 
 template <int LPP>
-static void launch_hpair_t(hipStream_t st, const HpairArgs& a, int frames) {
+static void launch_pair_t(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase) {
     constexpr int PXW = 64 / LPP;
-    dim3 grid((a.H + 4 * PXW - 1) / (4 * PXW), frames);
-    hipLaunchKernelGGL(hpair_ckpt_kernel<LPP>, grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(hpair_sum_kernel<LPP>, grid, dim3(256), 0, st, a);
+    const int nl = axis ? a.W : a.H;
+    dim3 grid((nl + 4 * PXW - 1) / (4 * PXW), frames);
+    if (phase != 2) {
+        if (axis == 0) hipLaunchKernelGGL((pair_ckpt_kernel<LPP, 0>), grid, dim3(256), 0, st, a);
+        else           hipLaunchKernelGGL((pair_ckpt_kernel<LPP, 1>), grid, dim3(256), 0, st, a);
+    }
+    if (phase != 1) {
+        if (axis == 0 && !final_pass)      hipLaunchKernelGGL((pair_sum_kernel<LPP, 0, false>), grid, dim3(256), 0, st, a);
+        else if (axis == 0)                hipLaunchKernelGGL((pair_sum_kernel<LPP, 0, true>), grid, dim3(256), 0, st, a);
+        else if (!final_pass)              hipLaunchKernelGGL((pair_sum_kernel<LPP, 1, false>), grid, dim3(256), 0, st, a);
+        else                               hipLaunchKernelGGL((pair_sum_kernel<LPP, 1, true>), grid, dim3(256), 0, st, a);
+    }
 }
 
-void launch_hpair(hipStream_t st, const HpairArgs& a, int frames) {
+// One axis (0 horizontal, 1 vertical).  phase 0: checkpoint pass + sum pass; 1: checkpoint pass only;
+// 2: sum pass only (so that the caller can put an event between them).  final_pass: the sum pass adds
+// a.Xother and nC*C and writes WTA records instead of X.
+void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase) {
     switch (agg_packed_lpp(a.D)) {
-        case 1: launch_hpair_t<1>(st, a, frames); break;
-        case 2: launch_hpair_t<2>(st, a, frames); break;
-        case 4: launch_hpair_t<4>(st, a, frames); break;
-        case 8: launch_hpair_t<8>(st, a, frames); break;
-        case 16: launch_hpair_t<16>(st, a, frames); break;
+        case 1: launch_pair_t<1>(st, a, frames, axis, final_pass, phase); break;
+        case 2: launch_pair_t<2>(st, a, frames, axis, final_pass, phase); break;
+        case 4: launch_pair_t<4>(st, a, frames, axis, final_pass, phase); break;
+        case 8: launch_pair_t<8>(st, a, frames, axis, final_pass, phase); break;
+        case 16: launch_pair_t<16>(st, a, frames, axis, final_pass, phase); break;
         default: break;
     }
 }

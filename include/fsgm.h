@@ -110,9 +110,10 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** plan, int32_t width, int32_t he
                                  int32_t dMax, int32_t batch, const fsgm_epi_params* prm);
 void        fsgm_epi_plan_destroy(fsgm_epi_plan* plan);
 fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t P2, double vMax);
-/* Aggregation strategy: 0 = auto (fused sweeps when eligible -- 8 paths, D = 16<<k, no-wrap
- * penalties with 3*P2 <= 255 -- and the plan holds >= 4 frames; else the per-direction line
- * kernels), 1 = line kernels, 2 = fused sweeps whenever eligible.  Results are identical. */
+/* Aggregation strategy: 0 = auto (a fused pipeline when eligible and the plan holds >= 4 frames: the
+ * sweeps for 8 paths -- D = 16<<k, no-wrap penalties with 3*P2 <= 255 -- the pair kernels for the
+ * shipped 4 paths -- 2*P2 <= 255; else the per-direction line kernels), 1 = line kernels, 2 = the
+ * fused pipeline whenever eligible.  Results are identical. */
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* plan, int32_t mode);
 /* host -> HBM (async on the plan's stream) */
 fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* plan, int32_t frame, const uint8_t* I1,
@@ -135,7 +136,7 @@ fsgm_status fsgm_epi_plan_time(fsgm_epi_plan* plan, int32_t stages, int32_t warm
                                int32_t iters, float* ms_avg);
 /* the hipStream_t the plan launches on */
 void*       fsgm_epi_plan_stream(fsgm_epi_plan* plan);
-/* which aggregation kernel the plan selected: "sweep16/nowrap", "packed16/nowrap", "packed16/wrap", "generic" */
+/* which aggregation kernel the plan selected: "sweep16/nowrap", "pairs16/nowrap", "packed16/nowrap", "packed16/wrap", "generic" */
 const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* plan);
 /* device-to-device copy bandwidth probe (GB/s, read+write bytes counted) used by bench.py */
 fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps);

@@ -80,10 +80,12 @@ def test_aggregate_sum_bit_exact(gpu_lib, oracle, W, H, D, P1, P2, cmax, kernel,
     with EpiPlan(W, H, D, 1, paths=paths) as plan:
         plan.set_penalties(P1, P2, 0.3)
         plan.upload_cost(0, Cv)
-        # mode 2: the fused sweeps take the 8-path no-wrap case, the line kernels everything else
+        # mode 2: the fused sweeps take the 8-path no-wrap case, the pair kernels the 4-path one (the shipped
+        # configuration), the line kernels everything else
         assert plan.kernel_name == kernel                   # auto mode, 1 frame: line kernels
         plan.set_agg_mode(2)
-        assert plan.kernel_name == ("sweep16/nowrap" if (paths == 8 and kernel == "packed16/nowrap") else kernel)
+        fused = {8: "sweep16/nowrap", 4: "pairs16/nowrap"}[paths]
+        assert plan.kernel_name == (fused if kernel == "packed16/nowrap" else kernel)
         plan.run(STAGE_AGGREGATE)
         got = plan.download_sum(0)
         np.testing.assert_array_equal(got, want)
@@ -92,6 +94,35 @@ def test_aggregate_sum_bit_exact(gpu_lib, oracle, W, H, D, P1, P2, cmax, kernel,
         plan.run(STAGE_AGGREGATE)
         got = plan.download_sum(0)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("W,H,D,B", [(70, 40, 128, 2), (200, 53, 64, 1), (33, 100, 128, 3), (50, 20, 256, 1), (257, 19, 16, 2), (40, 300, 32, 1),
+                                     # sizes around the 8-position tiles of either axis (no / one / partial checkpoint)
+                                     (1, 9, 64, 1), (9, 1, 64, 1), (5, 20, 128, 2), (8, 8, 128, 1), (9, 17, 32, 1), (16, 7, 128, 1),
+                                     (17, 16, 64, 2), (1242, 9, 128, 1), (12, 375, 128, 1)])
+def test_pairs_pipeline_4_paths(gpu_lib, oracle, W, H, D, B):
+    """The 4-path pair pipeline (horizontal pair -> X_h, vertical pair final with the WTA): S through the
+    debug tap, bestD / minC through the records, against the oracle and the line kernels."""
+    vols = [synth.cost_volume(W, H, D, seed=W + H + f, cmax=24) for f in range(B)]
+    for v in vols:
+        v[:, ::5, :] = 0
+    _, _, off = synth.epi_maps(W, H, "general", seed=3)
+    with EpiPlan(W, H, D, B, paths=4) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        for f in range(B):
+            plan.upload_cost(f, vols[f])
+            plan.upload_offset(f, off)
+        plan.set_agg_mode(2)
+        assert plan.kernel_name == "pairs16/nowrap"
+        for _ in range(2):                                   # twice: scratch buffers are reused
+            plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        for f in range(B):
+            S = oracle.epi_aggregate(vols[f], 6, 64, 4)
+            bd, mc = oracle.epi_wta(S, W, H, D, 1)
+            gbd, gmc = plan.download(f)
+            np.testing.assert_array_equal(gmc, mc)
+            np.testing.assert_array_equal(gbd, oracle.epi_vz_to_disp(bd, off, 0.3, D + 1))
+            np.testing.assert_array_equal(plan.download_sum(f), S[:-1].reshape(H, W, D))
 
 
 @pytest.mark.parametrize("W,H,D", [(70, 40, 128), (200, 53, 64), (33, 100, 128), (130, 35, 32), (50, 20, 256), (257, 19, 16),
