@@ -70,10 +70,12 @@ static void select_kernel(fsgm_epi_plan* p) {
     p->kernel_kind = nowrap ? AGG_PACKED_NOWRAP : AGG_PACKED_WRAP;
     // the fused sweeps cover the 8-path no-wrap case; everything else stays on the line kernels
     // (3*P2 <= 255: the excess sum of three paths fits a byte)
-    // Auto mode takes them from 4 frames up: a sweep launch is only strips x frames workgroups, so
-    // for 1-3 frames (one MEX call) the line kernels finish sooner (0.43 vs 1.27 ms at one
-    // 1242x375x128 frame; crossover at 4, measured).
-    const bool want = p->agg_mode == 2 || (p->agg_mode == 0 && p->batch >= 4);
+    // Auto mode takes the fused pipelines only for batches: their fixed latency (row blocks of the sweeps,
+    // three passes along 1242-pixel rows for a pair) is ~1.1-1.6 ms whatever the frame count, while the
+    // line kernels scale with it.  Measured crossovers at 1242x375x128 (ms per batch, line vs fused):
+    // 8 paths 4 frames 1.53 / 1.77, 6 frames 2.22 / 1.81; 4 paths 8 frames 1.26 / 1.41, 16 frames 2.47 / 1.85.
+    const int min_batch = p->prm.paths == 8 ? 5 : 10;
+    const bool want = p->agg_mode == 2 || (p->agg_mode == 0 && p->batch >= min_batch);
     if (nowrap && 3 * p->P2 <= 255 && p->prm.paths == 8 && want) p->kernel_kind = AGG_SWEEP;
     // the shipped 4-path configuration: both axes as pair kernels, the vertical one final (2*P2 <= 255:
     // the excess sum of a pair fits a byte)

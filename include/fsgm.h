@@ -110,7 +110,8 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** plan, int32_t width, int32_t he
                                  int32_t dMax, int32_t batch, const fsgm_epi_params* prm);
 void        fsgm_epi_plan_destroy(fsgm_epi_plan* plan);
 fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t P2, double vMax);
-/* Aggregation strategy: 0 = auto (a fused pipeline when eligible and the plan holds >= 4 frames: the
+/* Aggregation strategy: 0 = auto (a fused pipeline when eligible and the plan holds a batch -- 5 frames or
+ * more for 8 paths, 10 or more for 4 paths, the measured crossovers: the
  * sweeps for 8 paths -- D = 16<<k, no-wrap penalties with 3*P2 <= 255 -- the pair kernels for the
  * shipped 4 paths -- 2*P2 <= 255; else the per-direction line kernels), 1 = line kernels, 2 = the
  * fused pipeline whenever eligible.  Results are identical. */

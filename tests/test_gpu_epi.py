@@ -227,16 +227,17 @@ def test_calc_cost_sgm_kitti_shape_8_paths(gpu_lib, oracle):
         np.testing.assert_array_equal(plan.download_sum(0), S)
 
 
-def test_batch_matches_single_frames(gpu_lib, oracle):
+@pytest.mark.parametrize("paths,n", [(8, 5), (4, 10)])          # auto mode: fused sweeps from 5 frames, pair kernels from 10
+def test_batch_matches_single_frames(gpu_lib, oracle, paths, n):
     W, H, D = 96, 64, 64
     frames = []
-    for s in range(5):                                       # >= 4 frames: auto mode picks the fused sweeps
+    for s in range(n):
         I1, I2 = synth.image_pair(W, H, D, seed=20 + s)
         pd0, nd, off = synth.epi_maps(W, H, "general", seed=30 + s)
         frames.append((I1, I2, pd0, nd, off))
-    res = calc_cost_sgm_batch(frames, D, 0.3, 6, 64, paths=8)
+    res = calc_cost_sgm_batch(frames, D, 0.3, 6, 64, paths=paths)
     for (I1, I2, pd0, nd, off), (gbd, gmc) in zip(frames, res):
-        bd, mc = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, 8)
+        bd, mc = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, paths)
         np.testing.assert_array_equal(gmc, mc)
         np.testing.assert_array_equal(gbd, bd)
 
