@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_BYTES_PER_VOXEL = 9.65
 
 
-def cpu_baseline(sample_rows=48):
+def cpu_baseline(sample_rows=48, PATHS=PATHS):
     """The CPU oracle (a port: oracle/fsgm_oracle_epi.cpp, 1 thread like the reference) timed on a
     bounded sample of the same workload: 8-path aggregation of a 1242 x sample_rows x 128 strip."""
     import numpy as np
@@ -45,7 +45,7 @@ def cpu_baseline(sample_rows=48):
             break
     vp = reps * W * sample_rows * D * PATHS
     return {"value": vp / dt, "unit": "voxel-paths/s", "cores": 1, "kind": "port",
-            "sample": f"oracle fsgm_oracle_epi_aggregate, {reps} x (1242x{sample_rows}x128, 8 paths), {dt:.1f} s"}
+            "sample": f"oracle fsgm_oracle_epi_aggregate, {reps} x (1242x{sample_rows}x128, {PATHS} paths), {dt:.1f} s"}
 
 
 def pyramid3(args):
@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo to rehearse on one GPU)")
+    ap.add_argument("--paths", type=int, default=8, choices=[4, 8],
+                    help="8 = the headline metric (default); 4 = the reference's shipped configuration (no diagonal "
+                         "paths, calc_cost_sgm.cpp:104) through the pair kernels -- secondary, not the judged line")
     ap.add_argument("--workload", default="epi8", choices=["epi8", "pyramid3", "postprocess"],
                     help="epi8 = the headline metric (default); pyramid3 = BASELINE config 4, one pyramidal_sgm at 1242x375 "
                          "(3 levels); postprocess = the test.m:45-50 chain on a 1242x375 map (both secondary, 1 GPU, "
@@ -138,6 +141,7 @@ def main():
     if args.workload == "postprocess":
         return postprocess(args)
 
+    PATHS = args.paths
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -200,20 +204,21 @@ def main():
         alg_bytes_launch = B * W * H * D * PATHS            # 1 byte of C per voxel-path
         achieved = alg_bytes_launch / (agg_ms * 1e-3) / 1e9
         out = {
-            "metric": "aggregated cost-volume voxel-paths/s (HxWxDx8 paths), KITTI 1242x375 D=128",
+            "metric": f"aggregated cost-volume voxel-paths/s (HxWxDx{PATHS} paths), KITTI 1242x375 D=128",
             "value": value, "unit": "voxel-paths/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "KITTI 1242x375 D=128, 8 paths, aggregation stage (C resident in HBM -> bestD/minC)",
+            "config": {"workload": f"KITTI 1242x375 D=128, {PATHS} paths, aggregation stage (C resident in HBM -> bestD/minC)",
                        "frames_per_gpu": B, "P1": P1, "P2": P2, "kernel": plan.kernel_name,
-                       "step": "aggregate(8 paths) + sum/WTA/subpixel", "sharding": "frames, no collective"},
+                       "step": f"aggregate({PATHS} paths) + sum/WTA/subpixel", "sharding": "frames, no collective"},
             # the aggregation is one stage of four kernel types that run concurrently on three streams
             # (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane; pair_ckpt_kernel<8,0> +
             # pair_sum_kernel<8,0,false> for the horizontal pair): the roofline is taken over the stage, HIP
             # events fork->join
-            "roofline": {"bound": "hbm", "kernel": "aggregation stage: sweep_kernel<8,0> + sweep_kernel<8,2> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>",
+            "roofline": {"bound": "hbm", "kernel": ("aggregation stage: sweep_kernel<8,0> + sweep_kernel<8,2> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>"
+                                                     if PATHS == 8 else "aggregation stage: pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + pair_ckpt_kernel<8,1> + pair_sum_kernel<8,1,true>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES_PER_VOXEL * B * W * H * D if plan.kernel_name.startswith("sweep") else None,
+                         "traffic": TRAFFIC_BYTES_PER_VOXEL * B * W * H * D if plan.kernel_name.startswith("sweep") else None,   # measured for the 8-path pipeline only
                          "algorithmic_bytes": alg_bytes_launch, "stage_ms": agg_ms, "finish_ms": wta_ms},
         }
         try:
@@ -233,9 +238,9 @@ def main():
                 plan.upload(f, I1, I2, pd0, nd, offg)
             all_ms = plan.time(STAGE_COST | STAGE_AGGREGATE | STAGE_WTA, warmup=1, iters=3)
             out["whole_mex"] = {"ms_per_frame": all_ms / B, "frames_per_s": B / (all_ms * 1e-3),
-                                "stages": "census x2, cost fill, box, aggregate(8 paths), WTA", "inputs": "resident in HBM"}
+                                "stages": f"census x2, cost fill, box, aggregate({PATHS} paths), WTA", "inputs": "resident in HBM"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(PATHS=PATHS)
         print(json.dumps(out), flush=True)
     plan.close()
     if world > 1:

@@ -242,23 +242,30 @@ def test_batch_matches_single_frames(gpu_lib, oracle, paths, n):
         np.testing.assert_array_equal(gbd, bd)
 
 
-def test_full_size_property_mirror_symmetry(gpu_lib):
-    """Size-independent property at full KITTI size: point-mirroring the cost volume in (x,y)
-    mirrors S (pass 1 of the reference is the point mirror of pass 0, calc_cost_sgm.cpp:115-123),
-    and S >= paths * min_d C elementwise lower bound holds."""
+@pytest.mark.parametrize("paths,kernel", [(8, "sweep16/nowrap"), (4, "pairs16/nowrap")])
+def test_full_size_property_mirror_symmetry(gpu_lib, paths, kernel):
+    """Size-independent properties at full KITTI size, for both fused pipelines: point-mirroring the cost
+    volume in (x,y) mirrors S (pass 1 of the reference is the point mirror of pass 0,
+    calc_cost_sgm.cpp:115-123); paths*C <= S <= paths*(C + P2) elementwise when nothing wraps; and the
+    fused pipeline agrees with the per-direction line kernels voxel for voxel."""
     W, H, D = 1242, 375, 128
     Cv = synth.cost_volume(W, H, D, seed=99, cmax=24)
-    with EpiPlan(W, H, D, 2, paths=8) as plan:
+    with EpiPlan(W, H, D, 2, paths=paths) as plan:
         plan.set_penalties(6, 64, 0.3)
         plan.set_agg_mode(2)
+        assert plan.kernel_name == kernel
         plan.upload_cost(0, Cv)
         plan.upload_cost(1, np.ascontiguousarray(Cv[::-1, ::-1, :]))
         plan.run(STAGE_AGGREGATE)
         S0 = plan.download_sum(0)
         S1 = plan.download_sum(1)
+        plan.set_agg_mode(1)
+        plan.run(STAGE_AGGREGATE)
+        L0 = plan.download_sum(0)
     np.testing.assert_array_equal(S1[::-1, ::-1, :], S0)
-    assert (S0 >= 8 * Cv.astype(np.uint32)).all()           # every L_r(p,d) >= C(p,d) when nothing wraps
-    assert (S0 <= 8 * (Cv.astype(np.uint32) + 64)).all()    # and <= C + P2
+    np.testing.assert_array_equal(L0, S0)
+    assert (S0 >= paths * Cv.astype(np.uint32)).all()           # every L_r(p,d) >= C(p,d) when nothing wraps
+    assert (S0 <= paths * (Cv.astype(np.uint32) + 64)).all()    # and <= C + P2
 
 
 def test_run_sharded_with_the_hip_compute(gpu_lib, oracle):
