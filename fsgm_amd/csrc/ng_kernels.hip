@@ -211,11 +211,20 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
         if (mirror) { x = W - 1 - x; y = H - 1 - y; }
         return (size_t)y * W + x;
     };
-    Cand nxt = Cf[pix_of(0) * D + cand];
+    // the candidates of step t+PF are requested while step t computes (a gathered 12-byte load takes
+    // longer than one step); the ring rotates by unrolling, not by copying (a copy would wait for the load)
+    constexpr int PF = 4;
+    Cand ring[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) ring[k] = Cf[pix_of(min(k, len - 1)) * D + cand];
     __syncthreads();
-    for (int t = 0; t < len; t++) {
-        const Cand c = nxt;
-        nxt = Cf[pix_of(min(t + 1, len - 1)) * D + cand];      // in flight while this step computes
+    for (int t0 = 0; t0 < len; t0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int t = t0 + u;
+        if (t >= len) break;                                  // block-uniform
+        const Cand c = ring[u];
+        ring[u] = Cf[pix_of(min(t + PF, len - 1)) * D + cand];
         const size_t off = pix_of(t) * D;
         const NgPre q{(const int32_t*)buf0, (const int32_t*)buf0 + Dp, buf0 + 2 * Dp, buf0 + 3 * Dp};
         const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
         }
         __syncthreads();
         uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
+      }
     }
 }
 
