@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs a) {
     const size_t lstride = AXIS ? (size_t)D : (size_t)W * D, tstride = AXIS ? (size_t)W * D : (size_t)D;
     const size_t lbase = (size_t)l * lstride + (size_t)j * 16;
     const uint8_t* __restrict__ Cl = a.C + f * a.c_frame_stride + lbase;
-    uint8_t* __restrict__ Xl = a.X + f * a.x_frame_stride + lbase;                       // !FINAL: this pair's excess sum, out
+    uint8_t* __restrict__ Xl = FINAL ? nullptr : a.X + f * a.x_frame_stride + lbase;     // !FINAL: this pair's excess sum, out
     const uint8_t* __restrict__ Ol = FINAL ? a.Xother + f * a.xo_frame_stride + lbase : nullptr;   // FINAL: the other pair's, in
     const uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * max(NT - 1, 1)) * D + (size_t)j * 16;
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
