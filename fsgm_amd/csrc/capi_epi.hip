@@ -30,6 +30,7 @@ struct fsgm_epi_plan {
     uint8_t *dI1 = nullptr, *dI2 = nullptr;
     uint32_t *dCen1 = nullptr, *dCen2 = nullptr;
     double *dPd0 = nullptr, *dNd = nullptr, *dOff = nullptr, *dVz = nullptr;
+    double vzmax = 0.0;         // max |vzInd(d)| of the table in dVz (inf when not finite)
     uint8_t *dCraw = nullptr, *dC = nullptr, *dL = nullptr;
     uint32_t *dBestD = nullptr, *dMinC = nullptr, *dS = nullptr;
     uint32_t *dD2enc = nullptr, *dD2 = nullptr;          // forward-backward check (prm.fb_check)
@@ -202,13 +203,16 @@ static fsgm_status ensure_vz(fsgm_epi_plan* p) {
     if (p->vz_valid) return FSGM_OK;
     // calc_cost_sgm.cpp:339,360-361 -- depends on d only; same fp64 expressions, host side
     std::vector<double> vz(p->D);
+    double vzmax = 0.0;
     const double n = p->D + 1;
     for (int d = 0; d < p->D; d++) {
         const double vzRatio = 1.0 * d / n * p->vMax;
         vz[d] = vzRatio / (1 - vzRatio);
+        vzmax = std::isfinite(vz[d]) ? std::max(vzmax, std::fabs(vz[d])) : INFINITY;
     }
     FSGM_HIP(hipMemcpyAsync(p->dVz, vz.data(), (size_t)p->D * 8, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));   // vz is a stack-lifetime host buffer
+    p->vzmax = vzmax;
     p->vz_valid = true;
     return FSGM_OK;
 }
@@ -306,7 +310,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         launch_census(p->stream, p->dI2, p->dCen2, p->W, p->H, p->batch);
         EpiCostArgs a;
         a.cen1 = p->dCen1; a.cen2 = p->dCen2; a.pd0 = p->dPd0; a.nd = p->dNd; a.off = p->dOff;
-        a.vz = p->dVz; a.Craw = p->dCraw; a.W = p->W; a.H = p->H; a.D = p->D;
+        a.vz = p->dVz; a.vzmax = p->vzmax; a.Craw = p->dCraw; a.W = p->W; a.H = p->H; a.D = p->D;
         launch_epi_cost(p->stream, a, p->dC, p->batch);
         bool changed = false;
         for (int& c : p->cmax) { if (c != 24) changed = true; c = 24; }

@@ -15,6 +15,7 @@ struct EpiCostArgs {
     const double* nd;       // [frames][2][NP]
     const double* off;      // [frames][NP]
     const double* vz;       // [D]  vzInd(d), tabulated on the host with the reference's expression
+    double vzmax;           // max |vz[d]| (inf if any is not finite): bounds the sample positions per pixel
     uint8_t* Craw;          // [frames][NP][D]
     int W, H, D;
 };

@@ -84,6 +84,77 @@ __global__ __launch_bounds__(256) void epi_rawcost_kernel(EpiCostArgs a) {
     }
 }
 
+// Same for D % 8 == 0, one thread = one pixel, all d.  Neighbouring lanes are neighbouring pixels at the
+// same d, so the gather of the second image's census word touches two or three cache lines per wave
+// whatever the direction of the epipolar lines (with d across lanes every lane lands in its own line and
+// the kernel is bound by the L1 tag rate); vzInd(d) is wave-uniform and comes from scalar loads; the
+// per-pixel maps are read once, coalesced.  The 8 costs of a chunk are packed and parked in a per-wave
+// LDS tile [64 px][128 B + 8 pad] and written out as full 128-B lines.  ~30 VALU instructions per voxel,
+// most of them the reference's own fp64 sequence (3 mul, 2 add, 2 x round-half-away + truncate).
+// SMALL: every sample position of the wave is below 2^30 in magnitude (checked per pixel from the maps and
+// max |vzInd|), so the rounding needs no range test.
+constexpr int RC_SEG = 128, RC_PAD = RC_SEG + 8;
+template <bool SMALL>
+__device__ __forceinline__ void epi_rawcost_px_body(const EpiCostArgs& a, uint8_t* tilew, const uint32_t pw, const uint32_t p,
+                                                    const double bx, const double by, const double ux, const double uy, const double off) {
+    const int W = a.W, H = a.H, D = a.D;
+    const uint32_t NP = (uint32_t)W * (uint32_t)H;
+    const int lane = threadIdx.x & 63;
+    const size_t f = blockIdx.y;
+    const char* __restrict__ cen2 = (const char*)(a.cen2 + f * (size_t)NP);
+    const uint32_t c1 = a.cen1[f * (size_t)NP + p];
+    const double* __restrict__ vzt = a.vz;
+    const int xhi = W - 1, yhi = H - 1;
+    const uint32_t W4 = 4u * (uint32_t)W;
+    uint8_t* const myrow = tilew + lane * RC_PAD;
+    uint8_t* const outw = a.Craw + f * (size_t)NP * D + (size_t)pw * D;
+    for (int d0 = 0; d0 < D; d0 += RC_SEG) {
+        const int sb = min(RC_SEG, D - d0);
+        for (int c = 0; c < sb; c += 8) {
+            uint32_t packed[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const double s = __dmul_rn(off, vzt[d0 + c + k]);                             // offset * vzInd
+                const double ox = __dmul_rn(s, ux), oy = __dmul_rn(s, uy);                    // :365-366
+                const double vx = __dadd_rn(bx, ox), vy = __dadd_rn(by, oy);
+                const int x2 = SMALL ? round_clamp_small(vx, xhi) : clamp0(round_to_i32_x86(vx), xhi);   // :371, :374
+                const int y2 = SMALL ? round_clamp_small(vy, yhi) : clamp0(round_to_i32_x86(vy), yhi);   // :372, :375
+                const uint32_t boff = __umul24((uint32_t)y2, W4) + ((uint32_t)x2 << 2);       // 4W, H < 2^24 (launcher)
+                const uint32_t cost = __popc(c1 ^ *(const uint32_t*)(cen2 + boff));           // :377-378
+                asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(packed[k >> 2]) : "v"(cost), "n"(8 * (k & 3)));
+            }
+            *(uint2*)(myrow + c) = make_uint2(packed[0], packed[1]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t e = lane * 8u; e < 64u * (uint32_t)sb; e += 512u) {                     // tile -> HBM, whole lines
+            const uint32_t px = e / (uint32_t)sb, o = e - px * (uint32_t)sb;
+            if (pw + px < NP) *(uint2*)(outw + (size_t)px * D + d0 + o) = *(const uint2*)(tilew + px * RC_PAD + o);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void epi_rawcost_px_kernel(EpiCostArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[4][64 * RC_PAD];
+    const uint32_t NP = (uint32_t)a.W * (uint32_t)a.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t pw = (blockIdx.x * 4u + wave) * 64u;          // first pixel of this wave
+    if (pw >= NP) return;                                        // wave-uniform
+    const uint32_t p = min(pw + lane, NP - 1);                   // lanes past the end redo the last pixel, never stored
+    const size_t f = blockIdx.y;
+    const double* __restrict__ p0 = a.pd0 + f * 2 * (size_t)NP;
+    const double* __restrict__ nd = a.nd + f * 2 * (size_t)NP;
+    const double bx = __dsub_rn(p0[p], 1.0), by = __dsub_rn(p0[NP + p], 1.0);          // :348-349
+    const double ux = nd[p], uy = nd[NP + p];
+    const double off = a.off[f * (size_t)NP + p];
+    // |off * vz * u| <= reach * (1 + 3 ulp); NaN or inf anywhere fails the compares
+    const double reach = __dmul_rn(__dmul_rn(fabs(off), a.vzmax), fmax(fabs(ux), fabs(uy)));
+    const bool small = fabs(bx) < 536870912.0 && fabs(by) < 536870912.0 && reach < 536870912.0 &&
+                       fabs(ux) <= 1.7e308 && fabs(uy) <= 1.7e308;
+    if (__builtin_amdgcn_ballot_w64(!small) == 0) epi_rawcost_px_body<true>(a, tile[wave], pw, p, bx, by, ux, uy, off);
+    else                                          epi_rawcost_px_body<false>(a, tile[wave], pw, p, bx, by, ux, uy, off);
+}
+
 // =============================================================================================
 // 5x5 box mean, replicate border  (calc_cost_sgm.cpp:387-407).
 // (u8)(1.0*sum/25 + 0.5) == (2*sum + 25) / 50 in integers: the exact value has denominator 50,
@@ -637,8 +708,10 @@ void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int
 void launch_epi_cost(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frames) {
     const long long n = (long long)a.W * a.H * ((a.D + 3) / 4);
     dim3 grid((unsigned)((n + 255) / 256), frames);
-    if ((a.D & 3) == 0) hipLaunchKernelGGL(epi_rawcost_kernel<true>, grid, dim3(256), 0, st, a);
-    else                hipLaunchKernelGGL(epi_rawcost_kernel<false>, grid, dim3(256), 0, st, a);
+    if ((a.D & 7) == 0 && a.W < (1 << 22) && a.H < (1 << 24)) {
+        hipLaunchKernelGGL(epi_rawcost_px_kernel, dim3((unsigned)(((long long)a.W * a.H + 255) / 256), frames), dim3(256), 0, st, a);
+    } else if ((a.D & 3) == 0) hipLaunchKernelGGL(epi_rawcost_kernel<true>, grid, dim3(256), 0, st, a);
+    else                       hipLaunchKernelGGL(epi_rawcost_kernel<false>, grid, dim3(256), 0, st, a);
     if ((a.D & 3) == 0 && a.D <= 1024) {
         const int cols = 256 / (a.D >> 2);
         dim3 g2((a.W + cols - 1) / cols, (a.H + BOX_ROWS - 1) / BOX_ROWS, frames);

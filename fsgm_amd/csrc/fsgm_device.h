@@ -20,17 +20,36 @@ __device__ __forceinline__ uint32_t f64_to_u32_x86(double v) { return (uint32_t)
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, max(lo, v)); }
 
 // (int)round(v) exactly as x86-64 computes it -- C round() is half away from zero, the cast is
-// cvttsd2si -- with 4 fp64-rate instructions instead of ocml round + two fp64 range compares:
-//   t = trunc(v), f = v - t (exact), result = (int)t +- 1 when |f| >= 0.5.
-// |v| >= 2^31, inf and NaN are recognised from the exponent field and give INT_MIN; a rounded
-// value of exactly 2^31 comes out of the wrapping integer add as INT_MIN as well.
+// cvttsd2si (INT_MIN for NaN and anything outside int) -- in 8 instructions:
+//   t = trunc(v), f = v - t (exact, |f| < 1); the increment is trunc(2f) = -1, 0 or +1, i.e. |f| >= 0.5
+//   with v's sign; v_cvt_i32_f64 of v itself is t as an integer.  A rounded value of exactly 2^31
+//   comes out of the wrapping integer add as INT_MIN as well; |v| >= 2^31, inf and NaN fail the
+//   one range compare (the conversions' results are not used then).
 __device__ __forceinline__ int32_t round_to_i32_x86(double v) {
-    const uint32_t hi = (uint32_t)__double2hiint(v);
     const double t = trunc(v);
     const double f = __dsub_rn(v, t);
-    const uint32_t n = (uint32_t)(int32_t)t;
-    const uint32_t inc = fabs(f) >= 0.5 ? ((hi >> 31) ? 0xFFFFFFFFu : 1u) : 0u;
-    return ((hi >> 20) & 0x7FFu) >= 1023u + 31u ? INT32_MIN : (int32_t)(n + inc);
+    const uint32_t n = (uint32_t)__double2int_rz(v);
+    const uint32_t inc = (uint32_t)__double2int_rz(__dadd_rn(f, f));
+    return fabs(v) < 2147483648.0 ? (int32_t)(n + inc) : INT32_MIN;
+}
+
+// clamp((int)round(v), 0, hi) for a finite |v| < 2^31 - 1 (the caller has proved it), six full-rate
+// instructions: every negative v rounds to something <= 0 and clamps to 0, so v is clamped at 0.0 first;
+// for v >= 0 round-half-away is floor(v) + [fract(v) >= 0.5], v_cvt_i32_f64 is the floor and v_fract_f64
+// is exact.  The half test is a signed compare of fract's high word (fract(-0.0) = -0.0 must fail it).
+__device__ __forceinline__ int round_clamp_small(double v, int hi) {
+    const double vp = fmax(v, 0.0);
+    const int n = __double2int_rz(vp);
+    const double fr = __builtin_amdgcn_fract(vp);
+    const int r = n + (__double2hiint(fr) >= 0x3FE00000 ? 1 : 0);
+    return min(r, hi);
+}
+
+// clamp to [0, hi] in one instruction (hi >= 0)
+__device__ __forceinline__ int clamp0(int v, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi));
+    return r;
 }
 
 // parabola vertex offset as the pyramidal variant writes it (calc_pyd_cost_sgm.cpp:341-344)
