@@ -228,6 +228,20 @@ def test_calc_cost_sgm_kitti_shape_8_paths(gpu_lib, oracle):
         np.testing.assert_array_equal(plan.download_sum(0), S)
 
 
+def test_cost_volume_kitti_shape_general_field(gpu_lib, oracle):
+    """Full-size cost volume on the general direction field (fractional positions, exact .5 ties, a random
+    direction per pixel): the pixel-per-thread cost fill against the oracle, all 59.6 M voxels."""
+    W, H, D = 1242, 375, 128
+    I1, I2 = synth.image_pair(W, H, D, seed=2)
+    pd0, nd, off = synth.epi_maps(W, H, "general", seed=4)
+    want = oracle.epi_cost(I1, I2, D, 0.3, pd0, nd, off)
+    with EpiPlan(W, H, D, 1, paths=8) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        plan.upload(0, I1, I2, pd0, nd, off)
+        plan.run(STAGE_COST)
+        np.testing.assert_array_equal(plan.download_cost(0), want)
+
+
 @pytest.mark.parametrize("paths,n", [(8, 5), (4, 10)])          # auto mode: fused sweeps from 5 frames, pair kernels from 10
 def test_batch_matches_single_frames(gpu_lib, oracle, paths, n):
     W, H, D = 96, 64, 64
