@@ -151,6 +151,8 @@ fsgm_status fsgm_calc_cost_sgm_ng_batch_host(int32_t n, const fsgm_otf_in* in, c
     OtfArgs oa;
     oa.I1 = dI1; oa.cen1 = dCen1; oa.cen2 = dCen2; oa.rnd = dRnd; oa.Lrow = dLrow; oa.minC = dMinC; oa.flow = dFlow;
     oa.W = W; oa.H = H; oa.P1 = in[0].P1; oa.P2 = in[0].P2;
+    const char* ex = getenv("FSGM_OTF_EXACT");
+    oa.exact = (ex && atoi(ex) != 0) ? 1 : 0;
     launch_otf(d.stream, oa, n);
     FSGM_HIP(hipGetLastError());
     FSGM_HIP(hipStreamSynchronize(d.stream));

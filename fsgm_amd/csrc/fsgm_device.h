@@ -116,4 +116,13 @@ __device__ __forceinline__ uint32_t group_min_u32(uint32_t x) {
     return x;
 }
 
+// minimum over the 64 lanes of a wave, uniform result: DPP within the rows of 16, then the four row results
+// through scalar registers (all lanes must be active)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+    x = group_min_u32<16>(x);
+    const uint32_t r0 = __builtin_amdgcn_readlane(x, 0), r1 = __builtin_amdgcn_readlane(x, 16);
+    const uint32_t r2 = __builtin_amdgcn_readlane(x, 32), r3 = __builtin_amdgcn_readlane(x, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
 }  // namespace fsgm

@@ -57,6 +57,7 @@ struct OtfArgs {
     uint32_t* minC;         // [frames][NP]
     double* flow;           // [frames][2][NP]
     int W, H, P1, P2;
+    int exact;              // 1: start in the exact matcher (FSGM_OTF_EXACT=1; otherwise entered when a motion vector leaves the packed range)
 };
 
 void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames);

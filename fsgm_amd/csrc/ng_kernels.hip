@@ -175,6 +175,34 @@ __device__ __forceinline__ int ng_match4(const NgPre& q, int D, int mvx, int mvy
     return (ccost + (int)best) - (int)m;
 }
 
+// Two candidates of one lane against the same predecessor (D % 4 == 0, motion vectors in the safe range):
+// one pass over the entries, every 16-byte LDS read shared, the loop unrolled so the reads run ahead.
+__device__ __forceinline__ void ng_match4_pair(const NgPre& q, int D, int mvxa, int mvya, int mvxb, int mvyb, uint32_t jump,
+                                               uint32_t& besta, uint32_t& bestb) {
+    uint32_t min1a = jump, min2a = jump, min1b = jump, min2b = jump;
+    const uint32_t axa = (uint32_t)mvxa + 2u, aya = (uint32_t)mvya + 2u, axb = (uint32_t)mvxb + 2u, ayb = (uint32_t)mvyb + 2u;
+#pragma unroll 9
+    for (int d2 = 0; d2 < D; d2 += 4) {
+        const int4 qx = *(const int4*)(q.x + d2), qy = *(const int4*)(q.y + d2);
+        const uint4 c8 = *(const uint4*)(q.c8 + d2), cp = *(const uint4*)(q.cp + d2);
+        const int qxa[4] = {qx.x, qx.y, qx.z, qx.w}, qya[4] = {qy.x, qy.y, qy.z, qy.w};
+        const uint32_t c8a[4] = {c8.x, c8.y, c8.z, c8.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool eqa = mvxa == qxa[i] && mvya == qya[i];
+            const bool nra = (axa - (uint32_t)qxa[i]) <= 4u && (aya - (uint32_t)qya[i]) <= 4u;
+            min1a = eqa ? c8a[i] : min1a;                                     // last match wins
+            min2a = (nra && !eqa) ? min(min2a, cpa[i]) : min2a;
+            const bool eqb = mvxb == qxa[i] && mvyb == qya[i];
+            const bool nrb = (axb - (uint32_t)qxa[i]) <= 4u && (ayb - (uint32_t)qya[i]) <= 4u;
+            min1b = eqb ? c8a[i] : min1b;
+            min2b = (nrb && !eqb) ? min(min2b, cpa[i]) : min2b;
+        }
+    }
+    besta = min(jump, min(min1a, min2a));
+    bestb = min(jump, min(min1b, min2b));
+}
+
 // One THREAD per (line, candidate): a 256-thread workgroup advances 256/D lines (3 at D = 81, 95 % of the
 // lanes busy; one wave per line leaves 37 % idle and needs two rounds).  The per-line minimum crosses
 // waves through an LDS atomicMin in a three-slot ring (written at step t, read at t+1, reset at t+2),
@@ -307,60 +335,30 @@ __global__ __launch_bounds__(256) void ng_subpixel_kernel(NgSubpixArgs a) {
 // candidates of pixel (x,y) are the two best motion vectors left in the path buffers that are
 // about to be overwritten -- L1's from two pixels earlier in raster order, L2/L3/L4's from two
 // rows earlier (:276-277) -- plus one libc-rand() hint per buffer (:148-149), each expanded 3x3.
-// One 256-thread workgroup walks one frame pixel by pixel: the 108 candidate costs are spread
-// over the threads, then wave k runs path k's O(D^2) matcher + top-2 tracking.  Frames of a
-// batch run on different CUs.  A correctness port, not a throughput kernel.
+// One workgroup walks one frame pixel by pixel; frames of a batch run on different CUs.
+// otf_kernel (W < 4, and the plain statement of the step): 256 threads, the 108 candidate costs spread
+// over the threads, then wave k runs path k's O(D^2) matcher + top-2 tracking, four barriers per pixel.
+// otf_pipe_kernel (below) is the form that runs on real images.
 // =============================================================================================
-__device__ __forceinline__ void otf_step_wave(Cand* Lout, const NgPre& pre, uint32_t m, const Cand* Cc, int lane,
-                                              int P2, bool safe) {
-    // calc_cost_sgm_ng.cpp:46-98 for one path, executed by one wave (64 lanes over 108 candidates);
-    // pre: the predecessor's entries as four arrays (ng_match4), m: its stored minimum (:53)
-    const uint32_t jump = (m + (uint32_t)P2) & 0xFF;
-    int cost[2] = {0x7FFFFFFF, 0x7FFFFFFF};
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int d = lane + 64 * i;
-        if (d < OTF_D) {
-            const Cand c = Cc[d];
-            Cand o = c;
-            o.cost = ng_match4(pre, OTF_D, c.mvx, c.mvy, c.cost, m, jump, safe);
-            Lout[d] = o;
-            cost[i] = o.cost;
-        }
-    }
-    // top-2 by insertion in ascending d with strict '<' (:84-96): entry j precedes entry k when
-    // cost_j < cost_k, or cost_j == cost_k and j < k.  Slots start at cost 255 (:54-55) and an
-    // entry that is not < 255 never enters; the motion vectors of untouched slots stay as they are.
-    // key = (cost biased to unsigned) << 8 | d  gives exactly that order.
-    auto key_of = [](int c, int d) -> unsigned long long {
-        return ((unsigned long long)(uint32_t)(c ^ 0x80000000) << 8) | (unsigned)d;
-    };
-    const unsigned long long KMAX = ~0ull;
-    unsigned long long k0 = cost[0] != 0x7FFFFFFF ? key_of(cost[0], lane) : KMAX;
-    unsigned long long k1 = cost[1] != 0x7FFFFFFF ? key_of(cost[1], lane + 64) : KMAX;
-    unsigned long long best = k0 < k1 ? k0 : k1;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const unsigned long long o = __shfl_xor(best, s);
-        best = o < best ? o : best;
-    }
-    // second best: smallest key different from best
-    unsigned long long c0 = k0 == best ? KMAX : k0, c1 = k1 == best ? KMAX : k1;
-    unsigned long long second = c0 < c1 ? c0 : c1;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const unsigned long long o = __shfl_xor(second, s);
-        second = o < second ? o : second;
-    }
+// the two best entries and the top-N slots, by the wave that holds all 108 new costs.
+// Top-2 by insertion in ascending d with strict '<' (:84-96): entry j precedes entry k when cost_j < cost_k,
+// or cost_j == cost_k and j < k.  Slots start at cost 255 (:54-55) and an entry that is not < 255 never
+// enters; the motion vectors of untouched slots stay as they are; the first insertion shifts old slot 0
+// (cost 255, old mv) down into slot 1 (:92-95).  key = (cost + 2^16) << 8 | d gives exactly that order: a cost
+// is (candidate cost <= 25) + (best <= 255) - (m <= 255).
+__device__ __forceinline__ void otf_keep_best(Cand* Lout, int costa, int costb, bool has1, int lane) {
+    const uint32_t KMAX = 0xFFFFFFFFu;
+    const uint32_t k0 = ((uint32_t)(costa + 65536) << 8) | (uint32_t)lane;
+    const uint32_t k1 = has1 ? ((uint32_t)(costb + 65536) << 8) | (uint32_t)(lane + 64) : KMAX;
+    const uint32_t best = wave_min_u32(min(k0, k1));
+    const uint32_t second = wave_min_u32(min(k0 == best ? KMAX : k0, k1 == best ? KMAX : k1));
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        // Slot costs reset to 255, slot motion vectors keep whatever the buffer held (:54-55).  The
-        // first insertion shifts old slot 0 (cost 255, old mv) down into slot 1 (:92-95).
         Cand t0 = Lout[OTF_D], t1 = Lout[OTF_D + 1];
         t0.cost = 255; t1.cost = 255;
-        const int bc = (int)((uint32_t)(best >> 8) ^ 0x80000000), bd = (int)(best & 0xFF);
-        const int sc = (int)((uint32_t)(second >> 8) ^ 0x80000000), sd = (int)(second & 0xFF);
-        if (best != KMAX && bc < 255) {
+        const int bc = (int)(best >> 8) - 65536, bd = (int)(best & 0xFF);
+        const int sc = (int)(second >> 8) - 65536, sd = (int)(second & 0xFF);
+        if (bc < 255) {
             t1 = t0;
             t0 = Lout[bd];
             if (second != KMAX && sc < 255) t1 = Lout[sd];
@@ -368,6 +366,30 @@ __device__ __forceinline__ void otf_step_wave(Cand* Lout, const NgPre& pre, uint
         Lout[OTF_D] = t0;
         Lout[OTF_D + 1] = t1;
     }
+}
+
+__device__ __forceinline__ void otf_step_wave(Cand* Lout, const NgPre& pre, uint32_t m, const Cand* Cc, int lane,
+                                              int P2, bool safe) {
+    // calc_cost_sgm_ng.cpp:46-98 for one path, executed by one wave (64 lanes over 108 candidates, two per lane);
+    // pre: the predecessor's entries as four arrays, m: its stored minimum (:53)
+    const uint32_t jump = (m + (uint32_t)P2) & 0xFF;
+    const bool has1 = lane + 64 < OTF_D;
+    const Cand ca = Cc[lane], cb = Cc[has1 ? lane + 64 : lane];
+    int costa, costb;
+    if (safe) {
+        uint32_t ba, bb;
+        ng_match4_pair(pre, OTF_D, ca.mvx, ca.mvy, cb.mvx, cb.mvy, jump, ba, bb);
+        costa = (ca.cost + (int)ba) - (int)m;
+        costb = (cb.cost + (int)bb) - (int)m;
+    } else {
+        costa = ng_match4(pre, OTF_D, ca.mvx, ca.mvy, ca.cost, m, jump, false);
+        costb = ng_match4(pre, OTF_D, cb.mvx, cb.mvy, cb.cost, m, jump, false);
+    }
+    Cand oa = ca, ob = cb;
+    oa.cost = costa; ob.cost = costb;
+    Lout[lane] = oa;
+    if (has1) Lout[lane + 64] = ob;
+    otf_keep_best(Lout, costa, costb, has1, lane);
 }
 
 __global__ __launch_bounds__(256) void otf_kernel(OtfArgs a) {
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(256) void otf_kernel(OtfArgs a) {
     const size_t rowE = (size_t)W * OTF_E;
     Cand* Lrow = a.Lrow + f * 6 * rowE;           // [L2,L3,L4][2][W][OTF_E]
     for (int i = tid; i < 2 * OTF_E; i += 256) { Cand z = {0, 0, 0}; sL1[i / OTF_E][i % OTF_E] = z; }   // :204
-    if (tid == 0) sUnsafe = 0;
+    if (tid == 0) sUnsafe = a.exact;
     __syncthreads();
     int l1cur = 1, rowcur = 1;                    // :248, :250-254
     for (int y = 0; y < H; y++) {
@@ -507,6 +529,265 @@ __global__ __launch_bounds__(256) void otf_kernel(OtfArgs a) {
 }
 
 // =============================================================================================
+// The same recursion, software-pipelined over raster order (W >= 4), 14 waves per frame.
+// Everything pixel n+1 needs from global memory was written at least two pixels earlier -- the hints come
+// from buffers last written at pixel n-1 (L1, in LDS) or two rows back, the predecessors of the three
+// downward paths from the row above -- so no global round trip is left on the critical path:
+//   waves 0..11: path p = wave / 3, part e = wave % 3.  The O(D^2) matcher of pixel n is cut three ways
+//     over the predecessor's entries (36 each, fetched into registers during pixel n-1, staged into LDS by
+//     the wave that scans them); every lane carries two candidates through its part and leaves
+//     (last exact match, minimum over the near entries); after one barrier part 0 folds the three partial
+//     results in entry order, finishes the costs, keeps the two best and writes the path's buffer back.
+//   waves 12..13: the 108 candidate costs of pixel n+1 (hints fetched during pixel n-1 as well), then the
+//     minimum over the four paths for pixel n-1.
+// Motion vectors within +-0x3FF0 (anything a real image produces) are matched as packed 2 x u16 keys:
+// t = (c + (2,2)) - q per half; equal means t == (2,2), near means both halves <= 4 -- 8 VALU per
+// entry and candidate, no scalar mask arithmetic.  A vector outside that range switches the frame to
+// the exact form for good (sUnsafe).
+// =============================================================================================
+constexpr uint32_t OTF_NOMATCH = 0xFFFFFFFFu, OTF_BIG = 0xFFFFu;
+constexpr int OTF_PART = 36;                      // entries per part: 9 blocks of 4
+
+__device__ __forceinline__ void otf_match_part(const uint32_t* __restrict__ key, const uint32_t* __restrict__ c8,
+                                               const uint32_t* __restrict__ cp, uint32_t cka, uint32_t ckb,
+                                               uint32_t& m1a, uint32_t& m2a, uint32_t& m1b, uint32_t& m2b) {
+    const uint32_t ka2 = cka + 0x00020002u, kb2 = ckb + 0x00020002u;
+#pragma unroll
+    for (int d2 = 0; d2 < OTF_PART; d2 += 4) {
+        const uint4 k4 = *(const uint4*)(key + d2), v8 = *(const uint4*)(c8 + d2), vp = *(const uint4*)(cp + d2);
+        const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w}, c8a[4] = {v8.x, v8.y, v8.z, v8.w}, cpa[4] = {vp.x, vp.y, vp.z, vp.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t ta = pk_sub(ka2, ka[i]), tb = pk_sub(kb2, ka[i]);
+            const bool nra = pk_min(ta, 0x00040004u) == ta, eqa = ta == 0x00020002u;
+            const bool nrb = pk_min(tb, 0x00040004u) == tb, eqb = tb == 0x00020002u;
+            m1a = eqa ? c8a[i] : m1a;                                         // last match wins
+            uint32_t sa = nra ? cpa[i] : OTF_BIG;
+            sa = eqa ? OTF_BIG : sa;
+            m2a = min(m2a, sa);
+            m1b = eqb ? c8a[i] : m1b;
+            uint32_t sb = nrb ? cpa[i] : OTF_BIG;
+            sb = eqb ? OTF_BIG : sb;
+            m2b = min(m2b, sb);
+        }
+    }
+}
+
+__device__ __forceinline__ void otf_match_part_exact(const int32_t* qx, const int32_t* qy, const uint32_t* c8, const uint32_t* cp,
+                                                     int mvx, int mvy, uint32_t& m1, uint32_t& m2) {
+    for (int d2 = 0; d2 < OTF_PART; d2++) {
+        if (mvx == qx[d2] && mvy == qy[d2]) m1 = c8[d2];
+        else if (near2(mvx, qx[d2]) && near2(mvy, qy[d2])) m2 = min(m2, cp[d2]);
+    }
+}
+
+__global__ __launch_bounds__(896) void otf_pipe_kernel(OtfArgs a) {
+    __shared__ Cand sC[3][OTF_D];                 // candidates of pixels n-1, n, n+1 (slot = pixel % 3)
+    __shared__ Cand sL1[2][OTF_E];                // L1 double buffer (:197)
+    __shared__ __attribute__((aligned(16))) uint32_t sKey[4][OTF_D], sC8[4][OTF_D], sCp[4][OTF_D];   // staged predecessor entries per path
+    __shared__ int32_t sX[4][OTF_D], sY[4][OTF_D];                                                   // the same, unpacked (exact form)
+    __shared__ uint32_t sPart[4][2][128][2];      // [path][part - 1][candidate][last match, near minimum]
+    __shared__ int sUnsafe;
+    __shared__ Cand sOut[2][4][OTF_E];            // new entries per path of pixels n-1, n (slot = pixel & 1)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int path = wave / 3, part = wave - 3 * path;           // waves 0..11
+    const bool is_path = wave < 12;
+    const int W = a.W, H = a.H, NP = W * H;
+    const size_t f = blockIdx.x;
+    const uint8_t* __restrict__ If = a.I1 + f * (size_t)NP;
+    const uint32_t* __restrict__ cen1 = a.cen1 + f * (size_t)NP;
+    const uint32_t* __restrict__ cen2 = a.cen2 + f * (size_t)NP;
+    const int32_t* __restrict__ rnd = a.rnd + f * (size_t)NP * 8;
+    const size_t rowE = (size_t)W * OTF_E;
+    Cand* Lrow = a.Lrow + f * 6 * rowE;           // [L2,L3,L4][2][W][OTF_E]
+    for (int i = tid; i < 2 * OTF_E; i += 896) { Cand z = {0, 0, 0}; sL1[i / OTF_E][i % OTF_E] = z; }   // :204
+    if (tid == 0) sUnsafe = a.exact;
+    __syncthreads();
+
+    // ---- path waves: operands of pixel t fetched one step ahead
+    const int dxw = path == 1 ? -1 : (path == 3 ? 1 : 0);
+    auto starts = [&](int x, int y) -> bool {
+        return path == 0 ? x == 0 : (path == 1 ? (x == 0 || y == 0) : (path == 2 ? y == 0 : (y == 0 || x == W - 1)));
+    };
+    Cand ent = {0, 0, 0}, top = {0, 0, 0};
+    int pm = 0, ppre = 0, pcur = 0;
+    auto fetch_path = [&](int t, Cand& E, Cand& T, int& M, int& PP, int& PC) {
+        const int ty = t / W, tx = t - ty * W;
+        PC = If[t];
+        if (path == 0) {
+            if (tx > 0) PP = If[t - 1];
+            return;
+        }
+        const int rc = 1 ^ (ty & 1);
+        const Cand* cur = Lrow + ((path - 1) * 2 + rc) * rowE + (size_t)tx * OTF_E;
+        if (part == 0 && lane < 2) T = cur[OTF_D + lane];
+        if (!starts(tx, ty)) {
+            const Cand* psrc = Lrow + ((path - 1) * 2 + (rc ^ 1)) * rowE + (size_t)(tx + dxw) * OTF_E;
+            if (lane < OTF_PART) E = psrc[OTF_PART * part + lane];
+            M = psrc[OTF_D].cost;
+            PP = If[t - W + dxw];
+        }
+    };
+    // ---- cost lanes: candidate d of every pixel; its hint (:276-277, :148-149) fetched one step ahead
+    const int cd = tid - 768;                                     // 0..127, candidates 0..107
+    const int chi = cd / 9, ck = cd % 9, cl = chi / 3, ci = chi % 3;
+    const int coffy = ck / 3 - 1, coffx = ck % 3 - 1;             // :153-154 offy outer
+    const bool is_cost_lane = !is_path && cd < OTF_D;
+    const bool hint_in_lds = cl == 0 && ci < 2;                   // L1's top entries live in LDS
+    int hx = 0, hy = 0;
+    auto fetch_hint = [&](int t, int& HX, int& HY) {
+        if (hint_in_lds) return;
+        if (ci < 2) {
+            const int ty = t / W, tx = t - ty * W;
+            const Cand* src = Lrow + ((cl - 1) * 2 + (1 ^ (ty & 1))) * rowE + (size_t)tx * OTF_E + OTF_D + ci;
+            HX = src->mvx; HY = src->mvy;
+        } else {
+            HX = rnd[(size_t)t * 8 + 2 * cl] % 256 - 128;         // :148
+            HY = rnd[(size_t)t * 8 + 2 * cl + 1] % 128 - 64;      // :149
+        }
+    };
+    auto candidate = [&](int t, int mvx, int mvy) {               // (:122-186) clamp-border 5x5 mean of Hamming costs
+        const int y = t / W, x = t - y * W;
+        if (hint_in_lds) { const Cand h = sL1[1 ^ (t & 1)][OTF_D + ci]; mvx = h.mvx; mvy = h.mvy; }
+        // all 50 census words requested before the first is used (left alone the compiler waits after every pair)
+        uint32_t w1[25], w2[25];
+#pragma unroll
+        for (int ay = -2; ay <= 2; ay++) {
+            const int y1 = clampi(y + ay, 0, H - 1);
+            const int y2 = clampi((coffy + y1) + mvy, 0, H - 1);
+#pragma unroll
+            for (int ax = -2; ax <= 2; ax++) {
+                const int x1 = clampi(x + ax, 0, W - 1);
+                const int x2 = clampi((coffx + x1) + mvx, 0, W - 1);
+                w1[5 * (ay + 2) + ax + 2] = cen1[(uint32_t)(W * y1 + x1)];
+                w2[5 * (ay + 2) + ax + 2] = cen2[(uint32_t)(W * y2 + x2)];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < 25; i++) sum += __popc(w1[i] ^ w2[i]);
+        Cand c;
+        c.cost = f64_to_i32_x86(__dadd_rn(__ddiv_rn(__dmul_rn(1.0, (double)sum), 25.0), 0.5));   // :177
+        c.mvx = mvx + coffx; c.mvy = mvy + coffy;
+        sC[t % 3][cd] = c;
+        if (!(c.mvx > -0x3FF0 && c.mvx < 0x3FF0 && c.mvy > -0x3FF0 && c.mvy < 0x3FF0)) sUnsafe = 1;
+    };
+    auto pack = [](int mvx, int mvy) -> uint32_t { return ((uint32_t)(mvx + 0x4000) << 16) | ((uint32_t)(mvy + 0x4000) & 0xFFFFu); };
+
+    // prologue: candidates of pixel 0, operands of pixel 0, hints of pixel 1
+    if (is_path) {
+        fetch_path(0, ent, top, pm, ppre, pcur);
+    } else if (is_cost_lane) {
+        fetch_hint(0, hx, hy);
+        candidate(0, hx, hy);
+        if (NP > 1) fetch_hint(1, hx, hy);
+    }
+    __syncthreads();
+
+    for (int n = 0; n <= NP; n++) {
+        const bool live = is_path && n < NP;
+        const int y = n / W, x = n - y * W;
+        const int l1cur = 1 ^ (n & 1), l1pre = l1cur ^ 1, rowcur = 1 ^ (y & 1);
+        const bool start = live && starts(x, y);
+        const bool has1 = lane + 64 < OTF_D;
+        Cand nent = ent, ntop = top;
+        int nm = pm, npp = ppre, npc = pcur;
+        Cand ca = {0, 0, 0}, cb = {0, 0, 0};
+        uint32_t m1a = OTF_NOMATCH, m2a = OTF_BIG, m1b = OTF_NOMATCH, m2b = OTF_BIG;
+        Cand* out = sOut[n & 1][path & 3];
+        // ================= phase 1: partial matchers | candidate costs of pixel n+1
+        if (live) {
+            if (n + 1 < NP) fetch_path(n + 1, nent, ntop, nm, npp, npc);         // consumed after the matcher
+            const Cand* Cc = sC[n % 3];
+            // current content of the slot being overwritten: its top-N mvs survive a start copy
+            if (part == 0 && lane < 2) out[OTF_D + lane] = path == 0 ? sL1[l1cur][OTF_D + lane] : top;
+            if (start) {
+                if (part == 0) {
+                    __builtin_amdgcn_wave_barrier();
+                    for (int d = lane; d < OTF_D; d += 64) out[d] = Cc[d];       // :280,284,290,294,297,304
+                    if (lane == 0) out[OTF_D].cost = 0;
+                }
+            } else {
+                const int d0 = OTF_PART * part;
+                if (lane < OTF_PART) {
+                    const Cand e = path == 0 ? sL1[l1pre][d0 + lane] : ent;
+                    sX[path][d0 + lane] = e.mvx; sY[path][d0 + lane] = e.mvy;
+                    sKey[path][d0 + lane] = pack(e.mvx, e.mvy);
+                    sC8[path][d0 + lane] = (uint32_t)e.cost & 0xFF;
+                    sCp[path][d0 + lane] = (uint32_t)(e.cost + a.P1) & 0xFF;
+                }
+                ca = Cc[lane]; cb = Cc[has1 ? lane + 64 : lane];
+                __builtin_amdgcn_wave_barrier();
+                if (sUnsafe == 0) {
+                    otf_match_part(sKey[path] + d0, sC8[path] + d0, sCp[path] + d0, pack(ca.mvx, ca.mvy), pack(cb.mvx, cb.mvy),
+                                   m1a, m2a, m1b, m2b);
+                } else {
+                    otf_match_part_exact(sX[path] + d0, sY[path] + d0, sC8[path] + d0, sCp[path] + d0, ca.mvx, ca.mvy, m1a, m2a);
+                    otf_match_part_exact(sX[path] + d0, sY[path] + d0, sC8[path] + d0, sCp[path] + d0, cb.mvx, cb.mvy, m1b, m2b);
+                }
+                if (part > 0) {
+                    sPart[path][part - 1][lane][0] = m1a; sPart[path][part - 1][lane][1] = m2a;
+                    sPart[path][part - 1][lane + 64][0] = m1b; sPart[path][part - 1][lane + 64][1] = m2b;
+                }
+            }
+        } else if (!is_path) {
+            int nhx = hx, nhy = hy;
+            if (is_cost_lane && n + 2 < NP) fetch_hint(n + 2, nhx, nhy);
+            if (is_cost_lane && n + 1 < NP) candidate(n + 1, hx, hy);
+            hx = nhx; hy = nhy;
+        }
+        __syncthreads();
+        // ================= phase 2: fold the parts, finish the path step | WTA of pixel n-1
+        if (live && part == 0) {
+            if (!start) {
+                const uint32_t m = (uint32_t)(path == 0 ? sL1[l1pre][OTF_D].cost : pm) & 0xFF;      // :53
+                const int P2 = abs(pcur - ppre) > 50 ? a.P2 / 8 : a.P2;                             // :101-105 adaptive P2
+                const uint32_t jump = (m + (uint32_t)P2) & 0xFF;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {                                                       // later parts override an earlier match
+                    const uint32_t pa = sPart[path][e][lane][0], pb = sPart[path][e][lane + 64][0];
+                    m1a = pa != OTF_NOMATCH ? pa : m1a;
+                    m1b = pb != OTF_NOMATCH ? pb : m1b;
+                    m2a = min(m2a, sPart[path][e][lane][1]);
+                    m2b = min(m2b, sPart[path][e][lane + 64][1]);
+                }
+                const uint32_t besta = min(jump, min(m1a == OTF_NOMATCH ? jump : m1a, m2a));
+                const uint32_t bestb = min(jump, min(m1b == OTF_NOMATCH ? jump : m1b, m2b));
+                Cand oa = ca, ob = cb;
+                oa.cost = (ca.cost + (int)besta) - (int)m;
+                ob.cost = (cb.cost + (int)bestb) - (int)m;
+                out[lane] = oa;
+                if (has1) out[lane + 64] = ob;
+                otf_keep_best(out, oa.cost, ob.cost, has1, lane);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // write the new entries back into the path's buffer
+            Cand* dst = path == 0 ? sL1[l1cur] : Lrow + ((path - 1) * 2 + rowcur) * rowE + (size_t)x * OTF_E;
+            for (int d = lane; d < OTF_E; d += 64) dst[d] = out[d];
+        } else if (wave == 13 && n >= 1) {
+            // S = L1+L3+L2+L4 (:357-362) and WTA (:389-407) of pixel n-1
+            const int t = n - 1;
+            const Cand (*o)[OTF_E] = sOut[t & 1];
+            // first minimum of the u32 sums in d order (a negative sum wraps and sorts last, as in the reference)
+            const bool has1w = lane + 64 < OTF_D;
+            const uint32_t s0 = (uint32_t)(o[0][lane].cost + o[2][lane].cost) + (uint32_t)(o[1][lane].cost + o[3][lane].cost);
+            const int d1 = has1w ? lane + 64 : lane;
+            const uint32_t s1 = (uint32_t)(o[0][d1].cost + o[2][d1].cost) + (uint32_t)(o[1][d1].cost + o[3][d1].cost);
+            const uint32_t smin = wave_min_u32(min(s0, s1));
+            const uint32_t idx = wave_min_u32(s0 == smin ? (uint32_t)lane : (s1 == smin ? (uint32_t)d1 : 0xFFFFFFFFu));
+            if (lane == 0) {
+                a.minC[f * NP + t] = smin;
+                a.flow[f * 2 * (size_t)NP + t] = (double)sC[t % 3][idx].mvx;
+                a.flow[f * 2 * (size_t)NP + NP + t] = (double)sC[t % 3][idx].mvy;
+            }
+        }
+        ent = nent; top = ntop; pm = nm; ppre = npp; pcur = npc;
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames) {
@@ -547,7 +828,9 @@ void launch_ng_subpixel(hipStream_t st, const NgSubpixArgs& a, int frames) {
 }
 
 void launch_otf(hipStream_t st, const OtfArgs& a, int frames) {
-    hipLaunchKernelGGL(otf_kernel, dim3(frames), dim3(256), 0, st, a);
+    // the pipelined form fetches a pixel's operands one step ahead: they must have been written two steps back
+    if (a.W >= 4) hipLaunchKernelGGL(otf_pipe_kernel, dim3(frames), dim3(896), 0, st, a);
+    else          hipLaunchKernelGGL(otf_kernel, dim3(frames), dim3(256), 0, st, a);
 }
 
 }  // namespace fsgm

@@ -45,7 +45,7 @@ def test_calc_pyd_cost_sgm_ng_extreme_hints(gpu_lib, oracle):
 
 
 @pytest.mark.parametrize("W,H,P1,P2", [(40, 30, 6, 32), (33, 17, 6, 32), (24, 20, 100, 200), (7, 3, 6, 32), (2, 2, 6, 32),
-                                        (1, 5, 6, 32), (5, 1, 6, 32)])
+                                        (1, 5, 6, 32), (5, 1, 6, 32), (4, 6, 6, 32), (3, 4, 6, 32), (4, 1, 6, 32), (160, 120, 6, 32)])
 def test_calc_cost_sgm_ng_bit_exact(gpu_lib, oracle, W, H, P1, P2):
     I1, I2 = synth.image_pair(W, H, 16, seed=W * H)
     I1 = (I1.astype(np.int32) * 5 % 256).astype(np.uint8)        # strong gradients: adaptive P2 both ways
@@ -68,3 +68,16 @@ def test_calc_cost_sgm_ng_draws_libc_rand_like_the_reference(gpu_lib, oracle):
     got = calc_cost_sgm_ng(I1, I2, None, 1, 2, 0, 6, 32)
     np.testing.assert_array_equal(got[0], want[0])
     np.testing.assert_array_equal(got[1], want[1])
+
+
+def test_calc_cost_sgm_ng_exact_matcher_form(gpu_lib, oracle, monkeypatch):
+    """The pipelined kernel matches motion vectors as packed 16-bit pairs and switches to the exact
+    comparison when one leaves that range -- unreachable on small images, so the exact form is forced here."""
+    W, H = 37, 21
+    I1, I2 = synth.image_pair(W, H, 16, seed=11)
+    rs = oracle.glibc_rand_stream(oracle.sgm_ng_rand_draws(W, H))
+    mc, fl = oracle.calc_cost_sgm_ng(I1, I2, 6, 32, rs)
+    monkeypatch.setenv("FSGM_OTF_EXACT", "1")
+    gmc, gfl = calc_cost_sgm_ng(I1, I2, None, 1, 2, 0, 6, 32, rand_stream=rs)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gfl, fl)
