@@ -56,7 +56,7 @@ def cpu_baseline_all_cores(sample_rows=48, PATHS=PATHS, seconds=8.0):
     import threading
     from fsgm_amd import synth
     from oracle import pyoracle
-    T = max(1, min(len(os.sched_getaffinity(0)), 64))
+    T = max(1, min(len(os.sched_getaffinity(0)), 16))                  # the box's CPU share for one GPU
     vols = [synth.cost_volume(W, sample_rows, D, seed=5 + t, cmax=24) for t in range(T)]
     reps = [0] * T
     t0 = time.perf_counter()
