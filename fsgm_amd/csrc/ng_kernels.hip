@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void ng_cost_kernel(NgCostArgs a) {
     o.mvx = f64_to_i32_x86(__dadd_rn(mvx, (double)offx));                                           // :433
     o.mvy = f64_to_i32_x86(__dadd_rn(mvy, (double)offy));                                           // :434
     a.C[f * (size_t)NP * D + (size_t)p * D + d] = o;
-    // the fast matcher decides "within 2" with 32-bit differences: tell it when a vector could overflow them
-    if (a.unsafe && !(o.mvx > -(1 << 30) && o.mvx < (1 << 30) && o.mvy > -(1 << 30) && o.mvy < (1 << 30))) atomicOr(a.unsafe, 1u);
+    // the fast matcher compares motion vectors as packed 16-bit pairs (ng_pack_mv): tell it when one does not fit
+    if (a.unsafe && !(o.mvx > -0x3FF0 && o.mvx < 0x3FF0 && o.mvy > -0x3FF0 && o.mvy < 0x3FF0)) atomicOr(a.unsafe, 1u);
 }
 
 // One matcher step shared by both variants (calc_pyd_cost_sgm_ng.cpp:39-78 /
@@ -139,31 +139,42 @@ __global__ __launch_bounds__(256) void ng_agg_kernel(NgAggArgs a) {
 // =============================================================================================
 struct NgPre { const int32_t* x; const int32_t* y; const uint32_t* c8; const uint32_t* cp; };
 
+// motion vector as 2 x u16 (valid for |mv| < 0x3FF0: the launch's unsafe flag is raised otherwise)
+__device__ __forceinline__ uint32_t ng_pack_mv(int mvx, int mvy) {
+    return ((uint32_t)(mvx + 0x4000) << 16) | ((uint32_t)(mvy + 0x4000) & 0xFFFFu);
+}
+
 __device__ __forceinline__ int ng_match4(const NgPre& q, int D, int mvx, int mvy, int ccost, uint32_t m, uint32_t jump, bool safe) {
     uint32_t min1 = jump, min2 = jump;
     if (safe) {
-        const uint32_t ax = (uint32_t)mvx + 2u, ay = (uint32_t)mvy + 2u;
+        // q.x holds packed keys (ng_pack_mv): t = c + (2,2) - q per 16-bit half; equal is t == (2,2), within 2 on
+        // both axes is both halves <= 4.  8 VALU per entry, no scalar mask arithmetic.
+        const uint32_t ck2 = ng_pack_mv(mvx, mvy) + 0x00020002u;
+        const uint32_t* qk = (const uint32_t*)q.x;
+        uint32_t near2min = 0xFFFFu;
         int d2 = 0;
         for (; d2 + 4 <= D; d2 += 4) {
-            const int4 qx = *(const int4*)(q.x + d2), qy = *(const int4*)(q.y + d2);
+            const uint4 k4 = *(const uint4*)(qk + d2);
             const uint4 c8 = *(const uint4*)(q.c8 + d2), cp = *(const uint4*)(q.cp + d2);
-            const int qxa[4] = {qx.x, qx.y, qx.z, qx.w}, qya[4] = {qy.x, qy.y, qy.z, qy.w};
+            const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w};
             const uint32_t c8a[4] = {c8.x, c8.y, c8.z, c8.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const bool eq = mvx == qxa[i] && mvy == qya[i];
-                const bool nr = (ax - (uint32_t)qxa[i]) <= 4u && (ay - (uint32_t)qya[i]) <= 4u;
+                const uint32_t t = pk_sub(ck2, ka[i]);
+                const bool nr = pk_min(t, 0x00040004u) == t, eq = t == 0x00020002u;
                 min1 = eq ? c8a[i] : min1;                                        // last match wins
-                min2 = (nr && !eq) ? min(min2, cpa[i]) : min2;
+                uint32_t sel = nr ? cpa[i] : 0xFFFFu;
+                sel = eq ? 0xFFFFu : sel;
+                near2min = min(near2min, sel);
             }
         }
         for (; d2 < D; d2++) {
-            const int qx = q.x[d2], qy = q.y[d2];
-            const bool eq = mvx == qx && mvy == qy;
-            const bool nr = (ax - (uint32_t)qx) <= 4u && (ay - (uint32_t)qy) <= 4u;
+            const uint32_t t = pk_sub(ck2, qk[d2]);
+            const bool nr = pk_min(t, 0x00040004u) == t, eq = t == 0x00020002u;
             min1 = eq ? q.c8[d2] : min1;
-            min2 = (nr && !eq) ? min(min2, q.cp[d2]) : min2;
+            if (nr && !eq) near2min = min(near2min, q.cp[d2]);
         }
+        min2 = min(min2, near2min);
     } else {
         for (int d2 = 0; d2 < D; d2++) {
             const int qx = q.x[d2], qy = q.y[d2];
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
             if (tact) atomicMin(&smin[t % 3], (uint32_t)o & 0xFF);                // :74 narrowed
         }
         if (tact) {
-            buf1[cand] = (uint32_t)c.mvx; buf1[Dp + cand] = (uint32_t)c.mvy;
+            buf1[cand] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + cand] = (uint32_t)c.mvy;
             buf1[2 * Dp + cand] = (uint32_t)o & 0xFF; buf1[3 * Dp + cand] = (uint32_t)(o + a.P1) & 0xFF;
             if (lact) atomicAdd(&Sf[off + cand], (uint32_t)o);                    // :249
             if (cand == 0) smin[(t + 1) % 3] = 255u;
