@@ -114,6 +114,34 @@ def pyramid3(args):
                       "voxel_paths_per_s": vp / (total * 1e-3), "host_call_ms": host_ms, "levels": levels}), flush=True)
 
 
+def pyramid3_ng(args):
+    """BASELINE config 4 read literally ("calc_pyd_cost_sgm_ng ... 3-level pyramid"): the pyramidal level loop with the
+    neighbour-guided MEX swapped in (fsgm_amd.pyramidal_sgm_ng / NgPyramidPlan; 81 candidates per pixel, 4 paths,
+    2 passes, P1=6, P2=32 as ng_sgm.m:7-8,20).  value = milliseconds of one whole loop on the device (image pyramid,
+    rgb2gray, three levels of census + candidate costs + aggregation + WTA, hint upsampling; HIP events on the
+    plan's stream); the one-shot host call (plan creation and PCIe included) is reported beside it."""
+    import numpy as np
+    from fsgm_amd import synth, pyramidal_sgm_ng, NgPyramidPlan
+    iters = max(3, args.steps // 4)
+    g0, g1 = synth.image_pair(W, H, 16, seed=2)
+    I0 = np.stack([g0, 255 - g0, g0 // 2 + 40])
+    I1 = np.stack([g1, 255 - g1, g1 // 2 + 40])
+    with NgPyramidPlan(W, H, 3, 3) as plan:
+        plan.upload(I0, I1)
+        total = plan.time(1, iters)
+        sizes = [plan.level_size(l) for l in (3, 2, 1)]
+    pyramidal_sgm_ng(I0, I1, 3)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        pyramidal_sgm_ng(I0, I1, 3)
+    host_ms = (time.perf_counter() - t0) / iters * 1e3
+    vp = sum(w * h for (w, h) in sizes) * 81 * 4
+    print(json.dumps({"metric": "pyramidal level loop with calc_pyd_cost_sgm_ng (3 levels), device time per image pair",
+                      "value": total, "unit": "ms", "higher_is_better": False, "n_gpus": 1, "dtype": "u8", "data": "synthetic",
+                      "config": {"workload": "pyramid 1242x375 / 621x188 / 311x94 RGB, 81 candidates per pixel, 4 paths, 2 passes"},
+                      "voxel_paths_per_s": vp / (total * 1e-3), "host_call_ms": host_ms}), flush=True)
+
+
 def postprocess(args):
     """the post-processing chain of test.m:45-50 (speckle filter x2, calc_disp_from_first,
     forward-backward check, scan-line infill, vzInd2Disp) on a 1242x375 vz-index map, dMax = 64 (test.m:4).
@@ -159,13 +187,15 @@ def main():
     ap.add_argument("--paths", type=int, default=8, choices=[4, 8],
                     help="8 = the headline metric (default); 4 = the reference's shipped configuration (no diagonal "
                          "paths, calc_cost_sgm.cpp:104) through the pair kernels -- secondary, not the judged line")
-    ap.add_argument("--workload", default="epi8", choices=["epi8", "pyramid3", "postprocess"],
+    ap.add_argument("--workload", default="epi8", choices=["epi8", "pyramid3", "pyramid3_ng", "postprocess"],
                     help="epi8 = the headline metric (default); pyramid3 = BASELINE config 4, one pyramidal_sgm at 1242x375 "
                          "(3 levels); postprocess = the test.m:45-50 chain on a 1242x375 map (both secondary, 1 GPU, "
                          "not the judged line)")
     args = ap.parse_args()
     if args.workload == "pyramid3":
         return pyramid3(args)
+    if args.workload == "pyramid3_ng":
+        return pyramid3_ng(args)
     if args.workload == "postprocess":
         return postprocess(args)
 

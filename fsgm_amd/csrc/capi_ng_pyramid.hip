@@ -1,0 +1,207 @@
+// capi_ng_pyramid.hip -- C ABI for the pyramidal level loop around calc_pyd_cost_sgm_ng (include/fsgm.h).
+// pyramidal_sgm.m:24-76 with the neighbour-guided MEX in place of calc_pyd_cost_sgm: level images, hint
+// maps, candidate lists and flows stay in HBM; one host call uploads the image pair, one downloads a flow.
+// The candidate volume (12 B per entry) and the sum volume are shared by the levels -- they run in order on
+// one stream -- and sized for the finest.
+#include "capi_common.h"
+#include "epi_kernels.h"
+#include "ng_kernels.h"
+#include "pyramid_kernels.h"
+#include <vector>
+
+using namespace fsgm;
+
+struct fsgm_ng_pyramid_plan {
+    int W = 0, H = 0, channels = 1, device = 0, D = 0;
+    fsgm_ng_pyramid_params prm{};
+    std::vector<int> Ws, Hs;                         // level l (0-based) size
+    std::vector<uint8_t*> dP0, dP1;                  // colour pyramids [3][h][w] (channels == 3 only)
+    std::vector<uint8_t*> dG0, dG1;                  // gray pair per level
+    std::vector<double*> dMv;                        // hint map per level: [2][mvH][mvW]
+    std::vector<int> mvW, mvH;
+    std::vector<double*> dFlow;                      // [2][h][w]
+    std::vector<uint32_t*> dMinC;                    // [h][w]
+    uint32_t *dCen1 = nullptr, *dCen2 = nullptr, *dS = nullptr, *dUnsafe = nullptr;
+    Cand* dC = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+fsgm_ng_pyramid_params fsgm_ng_pyramid_params_default(void) {
+    fsgm_ng_pyramid_params p;
+    p.numPyd = 3;                      // test_psgm.m:33
+    p.P1 = 6; p.P2 = 32;               // ng_sgm.m:7-8
+    p.halfSearchWinSize = 1;           // ng_sgm.m:20
+    p.aggSize = 2;
+    p.subPixelRefine = 0;
+    p.device = 0;
+    return p;
+}
+
+void fsgm_ng_pyramid_plan_destroy(fsgm_ng_pyramid_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    auto drop = [](auto& v) { for (auto* b : v) if (b) (void)hipFree(b); };
+    drop(p->dP0); drop(p->dP1); drop(p->dG0); drop(p->dG1); drop(p->dMv); drop(p->dFlow); drop(p->dMinC);
+    void* one[] = {p->dCen1, p->dCen2, p->dS, p->dUnsafe, p->dC};
+    for (void* b : one) if (b) (void)hipFree(b);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+fsgm_status fsgm_ng_pyramid_plan_create(fsgm_ng_pyramid_plan** out, int32_t W, int32_t H, int32_t channels,
+                                        const fsgm_ng_pyramid_params* prm) {
+    FSGM_REQUIRE(out, "fsgm_ng_pyramid_plan_create: null plan pointer");
+    *out = nullptr;
+    FSGM_REQUIRE(prm, "fsgm_ng_pyramid_plan_create: null parameters");
+    FSGM_REQUIRE(W >= 1 && H >= 1, "width/height must be >= 1 (got %d x %d)", W, H);
+    FSGM_REQUIRE(channels == 1 || channels == 3, "channels must be 1 (gray) or 3 (RGB planes), got %d", channels);
+    FSGM_REQUIRE(prm->numPyd >= 1 && prm->numPyd <= 16, "numPyd must be in 1..16 (got %d)", prm->numPyd);
+    FSGM_REQUIRE(prm->halfSearchWinSize >= 0 && prm->aggSize >= 0, "halfSearchWinSize and aggSize must be >= 0");
+    const long long D = 9LL * (2 * prm->halfSearchWinSize + 1) * (2 * prm->halfSearchWinSize + 1);
+    if (D > FSGM_NG_MAX_D) return fail(FSGM_ERR_UNSUPPORTED, "%lld candidates per pixel exceed %d", D, FSGM_NG_MAX_D);
+    if ((double)W * H * D >= 2147483648.0) return fail(FSGM_ERR_UNSUPPORTED, "candidate volume exceeds 2^31 entries");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FSGM_ERR_HIP, "no HIP device available (libfsgm_hip has no CPU fallback)");
+    FSGM_REQUIRE(prm->device >= 0 && prm->device < ndev, "device %d out of range (have %d)", prm->device, ndev);
+    FSGM_HIP(hipSetDevice(prm->device));
+    fsgm_ng_pyramid_plan* p = new fsgm_ng_pyramid_plan;
+    p->W = W; p->H = H; p->channels = channels; p->device = prm->device; p->prm = *prm; p->D = (int)D;
+    const int n = prm->numPyd;
+    p->Ws.resize(n); p->Hs.resize(n); p->mvW.resize(n); p->mvH.resize(n);
+    p->Ws[0] = W; p->Hs[0] = H;
+    for (int l = 1; l < n; l++) { p->Ws[l] = (p->Ws[l - 1] + 1) / 2; p->Hs[l] = (p->Hs[l - 1] + 1) / 2; }   // impyramid: ceil(size/2)
+    p->dP0.assign(n, nullptr); p->dP1.assign(n, nullptr); p->dG0.assign(n, nullptr); p->dG1.assign(n, nullptr);
+    p->dMv.assign(n, nullptr); p->dFlow.assign(n, nullptr); p->dMinC.assign(n, nullptr);
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&p->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+    for (int l = 0; l < n && e == hipSuccess; l++) {
+        // the coarsest level starts from a zero map of its own size (pyramidal_sgm.m:34); every other level gets
+        // 2*imresize(flow, 2, 'nearest') of the level above, twice that level's size (:72)
+        p->mvW[l] = l == n - 1 ? p->Ws[l] : 2 * p->Ws[l + 1];
+        p->mvH[l] = l == n - 1 ? p->Hs[l] : 2 * p->Hs[l + 1];
+        const size_t np = (size_t)p->Ws[l] * p->Hs[l], mv = (size_t)p->mvW[l] * p->mvH[l];
+        if (channels == 3) {
+            e = hipMalloc((void**)&p->dP0[l], 3 * np);
+            if (e == hipSuccess) e = hipMalloc((void**)&p->dP1[l], 3 * np);
+        }
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dG0[l], np);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dG1[l], np);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dMv[l], 2 * mv * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dFlow[l], 2 * np * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dMinC[l], np * 4);
+    }
+    const size_t NP = (size_t)W * H, N = NP * (size_t)D;
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dCen1, NP * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dCen2, NP * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dC, N * sizeof(Cand));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dS, N * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dUnsafe, 4);
+    if (e == hipSuccess) e = hipMemset(p->dMv[n - 1], 0, 2 * (size_t)p->mvW[n - 1] * p->mvH[n - 1] * sizeof(double));   // :34
+    if (e != hipSuccess) {
+        fsgm_ng_pyramid_plan_destroy(p);
+        return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP, "fsgm_ng_pyramid_plan_create: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_ng_pyramid_plan_level_size(fsgm_ng_pyramid_plan* p, int32_t level, int32_t* w, int32_t* h) {
+    FSGM_REQUIRE(p && w && h, "fsgm_ng_pyramid_plan_level_size: null argument");
+    FSGM_REQUIRE(level >= 1 && level <= p->prm.numPyd, "level %d out of range 1..%d", level, p->prm.numPyd);
+    *w = p->Ws[level - 1]; *h = p->Hs[level - 1];
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_ng_pyramid_plan_upload(fsgm_ng_pyramid_plan* p, const uint8_t* I0, const uint8_t* I1) {
+    FSGM_REQUIRE(p && I0 && I1, "fsgm_ng_pyramid_plan_upload: null argument");
+    FSGM_HIP(hipSetDevice(p->device));
+    const size_t n = (size_t)p->channels * p->W * p->H;
+    FSGM_HIP(hipMemcpyAsync(p->channels == 3 ? p->dP0[0] : p->dG0[0], I0, n, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipMemcpyAsync(p->channels == 3 ? p->dP1[0] : p->dG1[0], I1, n, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    return FSGM_OK;
+}
+
+static fsgm_status ng_pyramid_enqueue(fsgm_ng_pyramid_plan* p) {
+    const int n = p->prm.numPyd, ch = p->channels, D = p->D;
+    hipStream_t s = p->stream;
+    for (int l = 1; l < n; l++) {                                                // pyramidal_sgm.m:28-31
+        launch_pyr_reduce(s, ch == 3 ? p->dP0[l - 1] : p->dG0[l - 1], ch == 3 ? p->dP0[l] : p->dG0[l], p->Ws[l - 1], p->Hs[l - 1], ch);
+        launch_pyr_reduce(s, ch == 3 ? p->dP1[l - 1] : p->dG1[l - 1], ch == 3 ? p->dP1[l] : p->dG1[l], p->Ws[l - 1], p->Hs[l - 1], ch);
+    }
+    if (ch == 3)
+        for (int l = 0; l < n; l++) {                                            // :44-45
+            launch_pyr_gray(s, p->dP0[l], p->dG0[l], p->Ws[l], p->Hs[l]);
+            launch_pyr_gray(s, p->dP1[l], p->dG1[l], p->Ws[l], p->Hs[l]);
+        }
+    for (int l = n - 1; l >= 0; l--) {                                           // :37
+        const int w = p->Ws[l], h = p->Hs[l];
+        const size_t N = (size_t)w * h * D;
+        FSGM_HIP(hipMemsetAsync(p->dS, 0, N * 4, s));                            // calc_pyd_cost_sgm_ng.cpp:111
+        FSGM_HIP(hipMemsetAsync(p->dUnsafe, 0, 4, s));
+        launch_census(s, p->dG0[l], p->dCen1, w, h, 1);                          // :485-486
+        launch_census(s, p->dG1[l], p->dCen2, w, h, 1);
+        NgCostArgs ca;
+        ca.cen1 = p->dCen1; ca.cen2 = p->dCen2; ca.mv = p->dMv[l]; ca.C = p->dC; ca.unsafe = p->dUnsafe; ca.W = w; ca.H = h;
+        ca.mvW = p->mvW[l]; ca.mvH = p->mvH[l]; ca.rAgg = p->prm.aggSize / 2; ca.rX = p->prm.halfSearchWinSize; ca.rY = p->prm.halfSearchWinSize;
+        launch_ng_cost(s, ca, 1);
+        NgAggArgs ga;
+        ga.C = p->dC; ga.S = p->dS; ga.unsafe = p->dUnsafe; ga.W = w; ga.H = h; ga.D = D; ga.P1 = p->prm.P1; ga.P2 = p->prm.P2;
+        launch_ng_aggregate(s, ga, 1);
+        NgWtaArgs wa;
+        wa.C = p->dC; wa.S = p->dS; wa.minC = p->dMinC[l]; wa.flow = p->dFlow[l]; wa.W = w; wa.H = h; wa.D = D;
+        launch_ng_wta(s, wa, 1);
+        if (p->prm.subPixelRefine) {                                             // :516-517
+            NgSubpixArgs sa;
+            sa.cen1 = p->dCen1; sa.cen2 = p->dCen2; sa.flow = p->dFlow[l]; sa.W = w; sa.H = h;
+            launch_ng_subpixel(s, sa, 1);
+        }
+        if (l > 0) launch_pyr_upsample2(s, p->dFlow[l], p->dMv[l - 1], w, h);    // pyramidal_sgm.m:72
+    }
+    FSGM_HIP(hipGetLastError());
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_ng_pyramid_plan_run(fsgm_ng_pyramid_plan* p) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_HIP(hipSetDevice(p->device));
+    return ng_pyramid_enqueue(p);
+}
+
+fsgm_status fsgm_ng_pyramid_plan_download(fsgm_ng_pyramid_plan* p, int32_t level, double* flow, uint32_t* minC) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_REQUIRE(level >= 1 && level <= p->prm.numPyd, "level %d out of range 1..%d", level, p->prm.numPyd);
+    FSGM_HIP(hipSetDevice(p->device));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    const int l = level - 1;
+    const size_t np = (size_t)p->Ws[l] * p->Hs[l];
+    if (flow) FSGM_HIP(hipMemcpy(flow, p->dFlow[l], 2 * np * sizeof(double), hipMemcpyDeviceToHost));
+    if (minC) FSGM_HIP(hipMemcpy(minC, p->dMinC[l], np * 4, hipMemcpyDeviceToHost));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_ng_pyramid_plan_time(fsgm_ng_pyramid_plan* p, int32_t warmup, int32_t iters, float* ms_avg) {
+    FSGM_REQUIRE(p && ms_avg && iters >= 1 && warmup >= 0, "fsgm_ng_pyramid_plan_time: bad argument");
+    FSGM_HIP(hipSetDevice(p->device));
+    fsgm_status st;
+    for (int i = 0; i < warmup; i++)
+        if ((st = ng_pyramid_enqueue(p)) != FSGM_OK) return st;
+    FSGM_HIP(hipEventRecord(p->ev0, p->stream));
+    for (int i = 0; i < iters; i++)
+        if ((st = ng_pyramid_enqueue(p)) != FSGM_OK) return st;
+    FSGM_HIP(hipEventRecord(p->ev1, p->stream));
+    FSGM_HIP(hipEventSynchronize(p->ev1));
+    float ms = 0;
+    FSGM_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    *ms_avg = ms / iters;
+    return FSGM_OK;
+}
+
+}  // extern "C"

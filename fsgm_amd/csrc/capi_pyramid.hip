@@ -125,7 +125,7 @@ fsgm_status fsgm_pyramid_plan_upload(fsgm_pyramid_plan* p, const uint8_t* I0, co
     return FSGM_OK;
 }
 
-static fsgm_status pyramid_enqueue(fsgm_pyramid_plan* p) {
+static void pyramid_enqueue_images(fsgm_pyramid_plan* p) {
     const int n = p->prm.numPyd, ch = p->channels;
     for (int l = 1; l < n; l++) {                                                // :28-31
         const uint8_t* s0 = ch == 3 ? p->dP0[l - 1] : p->lv[l - 1]->dI1;
@@ -138,6 +138,11 @@ static fsgm_status pyramid_enqueue(fsgm_pyramid_plan* p) {
             launch_pyr_gray(p->stream, p->dP0[l], p->lv[l]->dI1, p->Ws[l], p->Hs[l]);
             launch_pyr_gray(p->stream, p->dP1[l], p->lv[l]->dI2, p->Ws[l], p->Hs[l]);
         }
+}
+
+static fsgm_status pyramid_enqueue(fsgm_pyramid_plan* p) {
+    const int n = p->prm.numPyd;
+    pyramid_enqueue_images(p);
     for (int l = n - 1; l >= 0; l--) {                                           // :37
         fsgm_pyd_plan* q = p->lv[l];
         fsgm_status st = pyd_enqueue(q, FSGM_STAGE_ALL, nullptr);                // :50
@@ -157,6 +162,14 @@ fsgm_status fsgm_pyramid_plan_run(fsgm_pyramid_plan* p) {
     FSGM_REQUIRE(p, "null plan");
     FSGM_HIP(hipSetDevice(p->device));
     return pyramid_enqueue(p);
+}
+
+fsgm_status fsgm_pyramid_plan_run_images(fsgm_pyramid_plan* p) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_HIP(hipSetDevice(p->device));
+    pyramid_enqueue_images(p);
+    FSGM_HIP(hipGetLastError());
+    return FSGM_OK;
 }
 
 fsgm_status fsgm_pyramid_plan_download(fsgm_pyramid_plan* p, int32_t level, double* mv, uint32_t* minC) {

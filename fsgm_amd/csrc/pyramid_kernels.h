@@ -20,5 +20,7 @@ struct PyrFlowArgs {
 void launch_pyr_reduce(hipStream_t st, const uint8_t* in, uint8_t* out, int W, int H, int planes);
 void launch_pyr_gray(hipStream_t st, const uint8_t* rgb, uint8_t* out, int W, int H);   // rgb [3][H][W]
 void launch_pyr_flow(hipStream_t st, const PyrFlowArgs& a);
+// next[2][2H][2W] = 2 * flow[2][H][W] at (y/2, x/2): 2*imresize(mv, 2, 'nearest') (pyramidal_sgm.m:72)
+void launch_pyr_upsample2(hipStream_t st, const double* flow, double* next, int W, int H);
 
 }  // namespace fsgm

@@ -28,6 +28,7 @@ def _bind(lib):
     lib.fsgm_pyramid_plan_level_size.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.fsgm_pyramid_plan_upload.argtypes = [vp, vp, vp]
     lib.fsgm_pyramid_plan_run.argtypes = [vp]
+    lib.fsgm_pyramid_plan_run_images.argtypes = [vp]
     lib.fsgm_pyramid_plan_download.argtypes = [vp, i32, vp, vp]
     lib.fsgm_pyramid_plan_download_gray.argtypes = [vp, i32, vp, vp]
     lib.fsgm_pyramid_plan_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
@@ -115,6 +116,10 @@ class PyramidPlan:
     def run(self):
         check(self.lib.fsgm_pyramid_plan_run(self._h))
 
+    def run_images(self):
+        """Only impyramid / rgb2gray (the level images), no matching."""
+        check(self.lib.fsgm_pyramid_plan_run_images(self._h))
+
     def download(self, level=1):
         w, h = self.level_size(level)
         mv = np.empty((2, h, w), np.float64)
@@ -133,3 +138,104 @@ class PyramidPlan:
         ms = C.c_float()
         check(self.lib.fsgm_pyramid_plan_time(self._h, int(warmup), int(iters), C.byref(ms)))
         return float(ms.value)
+
+
+class NgPyramidParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("numPyd", "P1", "P2", "halfSearchWinSize", "aggSize", "subPixelRefine", "device")]
+
+
+def _bind_ng(lib):
+    if getattr(lib, "_ng_pyramid_bound", False):
+        return
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.fsgm_ng_pyramid_params_default.restype = NgPyramidParams
+    lib.fsgm_ng_pyramid_plan_create.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(NgPyramidParams)]
+    lib.fsgm_ng_pyramid_plan_destroy.argtypes = [vp]
+    lib.fsgm_ng_pyramid_plan_destroy.restype = None
+    lib.fsgm_ng_pyramid_plan_level_size.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.fsgm_ng_pyramid_plan_upload.argtypes = [vp, vp, vp]
+    lib.fsgm_ng_pyramid_plan_run.argtypes = [vp]
+    lib.fsgm_ng_pyramid_plan_download.argtypes = [vp, i32, vp, vp]
+    lib.fsgm_ng_pyramid_plan_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+    lib._ng_pyramid_bound = True
+
+
+class NgPyramidPlan:
+    """Device-resident level loop around calc_pyd_cost_sgm_ng for one image shape (see pyramidal_sgm_ng)."""
+
+    def __init__(self, width, height, channels=1, numPyd=3, *, device=0, **overrides):
+        self.lib = _lib.load()
+        _bind_ng(self.lib)
+        prm = self.lib.fsgm_ng_pyramid_params_default()
+        prm.numPyd, prm.device = int(numPyd), int(device)
+        for k, v in overrides.items():
+            if not hasattr(prm, k):
+                raise TypeError(f"unknown pyramidal_sgm_ng parameter {k!r}")
+            setattr(prm, k, int(v))
+        self.prm = prm
+        self.W, self.H, self.channels = int(width), int(height), int(channels)
+        self._h = C.c_void_p()
+        check(self.lib.fsgm_ng_pyramid_plan_create(C.byref(self._h), self.W, self.H, self.channels, C.byref(prm)))
+
+    def close(self):
+        if self._h:
+            self.lib.fsgm_ng_pyramid_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        check(self.lib.fsgm_ng_pyramid_plan_level_size(self._h, int(level), C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def upload(self, I0, I1):
+        I0, I1, ch = _check_images(I0, I1)
+        if ch != self.channels or I0.shape[-2:] != (self.H, self.W):
+            raise ValueError("shape mismatch with the plan")
+        check(self.lib.fsgm_ng_pyramid_plan_upload(self._h, ptr(I0), ptr(I1)))
+
+    def run(self):
+        check(self.lib.fsgm_ng_pyramid_plan_run(self._h))
+
+    def download(self, level=1):
+        w, h = self.level_size(level)
+        flow = np.empty((2, h, w), np.float64)
+        minC = np.empty((h, w), np.uint32)
+        check(self.lib.fsgm_ng_pyramid_plan_download(self._h, int(level), ptr(flow), ptr(minC)))
+        return flow, minC
+
+    def time(self, warmup=1, iters=5):
+        ms = C.c_float()
+        check(self.lib.fsgm_ng_pyramid_plan_time(self._h, int(warmup), int(iters), C.byref(ms)))
+        return float(ms.value)
+
+
+def pyramidal_sgm_ng(I0, I1, numPyd=3, *, device=0, **overrides):
+    """The level loop of pyramidal_sgm.m (:24-76) with calc_pyd_cost_sgm_ng swapped in for calc_pyd_cost_sgm
+    (BASELINE config 4): the neighbour-guided MEX takes the previous level's flow as its hint map and returns
+    the flow itself (calc_pyd_cost_sgm_ng.cpp:458-480).  Defaults are the argument values of ng_sgm.m:20
+    (halfSearchWinSize=1, aggSize=2, subPixelRefine=0, P1=6, P2=32); keyword overrides name them.  Level images
+    by impyramid 'reduce' / rgb2gray, hints of a finer level = 2*imresize(flow, 2, 'nearest') (pyramidal_sgm.m:72);
+    everything stays on the device between levels.
+
+    Returns (flow of level 1, [flow per level, coarsest first], minC of level 1)."""
+    I0, I1, ch = _check_images(I0, I1)
+    H, W = I0.shape[-2:]
+    with NgPyramidPlan(W, H, ch, numPyd, device=device, **overrides) as plan:
+        plan.upload(I0, I1)
+        plan.run()
+        flows = [plan.download(l)[0] for l in range(numPyd, 1, -1)]
+        flow, minC = plan.download(1)
+    flows.append(flow)
+    return flow, flows, minC

@@ -264,12 +264,42 @@ void        fsgm_pyramid_plan_destroy(fsgm_pyramid_plan* plan);
 fsgm_status fsgm_pyramid_plan_level_size(fsgm_pyramid_plan* plan, int32_t level, int32_t* width, int32_t* height);
 fsgm_status fsgm_pyramid_plan_upload(fsgm_pyramid_plan* plan, const uint8_t* I0, const uint8_t* I1);
 fsgm_status fsgm_pyramid_plan_run(fsgm_pyramid_plan* plan);              /* asynchronous */
+/* only the image half of the loop (impyramid, rgb2gray: pyramidal_sgm.m:28-31, 44-45), for callers that run
+ * another matcher per level (fsgm_amd.pyramidal_sgm_ng swaps calc_pyd_cost_sgm_ng in); asynchronous */
+fsgm_status fsgm_pyramid_plan_run_images(fsgm_pyramid_plan* plan);
 /* HBM -> host (synchronous): flow and/or minC of one level; either pointer may be NULL */
 fsgm_status fsgm_pyramid_plan_download(fsgm_pyramid_plan* plan, int32_t level, double* mv, uint32_t* minC);
 /* debug tap: the gray images calc_pyd_cost_sgm saw at one level (after impyramid and rgb2gray), u8 [H_l][W_l] */
 fsgm_status fsgm_pyramid_plan_download_gray(fsgm_pyramid_plan* plan, int32_t level, uint8_t* gray0, uint8_t* gray1);
 /* average milliseconds of one whole pyramid run (HIP events on the plan's stream) */
 fsgm_status fsgm_pyramid_plan_time(fsgm_pyramid_plan* plan, int32_t warmup, int32_t iters, float* ms_avg);
+
+/* ---- the pyramidal level loop with the neighbour-guided matcher ----
+ * BASELINE config 4 names calc_pyd_cost_sgm_ng for the pyramidal path.  The reference ships that MEX as a swap-in
+ * (same 8 arguments as ng_sgm.m:20) without a driver; this is pyramidal_sgm.m's loop (:24-76) around it: level
+ * images by impyramid 'reduce' and rgb2gray (:28-31, :44-45), the coarsest level from a zero hint map (:34), every
+ * finer level from 2*imresize(flow, 2, 'nearest') of the level above (:72) -- the MEX returns the flow itself
+ * (calc_pyd_cost_sgm_ng.cpp:296-297), so no index-to-vector step.  Everything stays in HBM between levels. */
+typedef struct {
+    int32_t numPyd;                 /* levels, 1..16 */
+    int32_t P1, P2;                 /* ng_sgm.m:7-8: 6, 32 */
+    int32_t halfSearchWinSize;      /* ng_sgm.m:20: 1  -> 81 candidates per pixel */
+    int32_t aggSize;                /* ng_sgm.m:20: 2 */
+    int32_t subPixelRefine;         /* ng_sgm.m:20: 0 */
+    int32_t device;
+} fsgm_ng_pyramid_params;
+fsgm_ng_pyramid_params fsgm_ng_pyramid_params_default(void);
+typedef struct fsgm_ng_pyramid_plan fsgm_ng_pyramid_plan;
+fsgm_status fsgm_ng_pyramid_plan_create(fsgm_ng_pyramid_plan** plan, int32_t width, int32_t height, int32_t channels,
+                                        const fsgm_ng_pyramid_params* prm);
+void        fsgm_ng_pyramid_plan_destroy(fsgm_ng_pyramid_plan* plan);
+fsgm_status fsgm_ng_pyramid_plan_level_size(fsgm_ng_pyramid_plan* plan, int32_t level, int32_t* width, int32_t* height);
+fsgm_status fsgm_ng_pyramid_plan_upload(fsgm_ng_pyramid_plan* plan, const uint8_t* I0, const uint8_t* I1);
+fsgm_status fsgm_ng_pyramid_plan_run(fsgm_ng_pyramid_plan* plan);        /* asynchronous */
+/* flow [2][h][w] and minC [h][w] of `level` (1 = full resolution); either may be NULL */
+fsgm_status fsgm_ng_pyramid_plan_download(fsgm_ng_pyramid_plan* plan, int32_t level, double* flow, uint32_t* minC);
+fsgm_status fsgm_ng_pyramid_plan_time(fsgm_ng_pyramid_plan* plan, int32_t warmup, int32_t iters, float* ms_avg);
+
 
 /* ------------------------------------------------------------------------------------------
  * Post-processing  (SURVEY 8(f) N3): the MATLAB functions the evaluation script chains after SGM

@@ -91,3 +91,36 @@ def test_pyramidal_sgm_kitti_shape_level_sizes(gpu_lib, oracle):
         np.testing.assert_array_equal(mc3, mc)
         np.testing.assert_array_equal(lv3[0], (bd // 11).astype(np.float64) - 5)
         np.testing.assert_array_equal(lv3[1], (bd % 11).astype(np.float64) - 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,ch,numPyd,sub", [(61, 45, 3, 3, 0), (48, 37, 1, 2, 1)])
+def test_pyramidal_loop_with_the_neighbour_guided_matcher(gpu_lib, oracle, W, H, ch, numPyd, sub):
+    """BASELINE config 4 names calc_pyd_cost_sgm_ng for the pyramidal path: the level loop with the ng MEX swapped
+    in (fsgm_amd.pyramidal_sgm_ng) against the same composition of the oracle's functions, level by level."""
+    from fsgm_amd import pyramidal_sgm_ng
+    g0, g1 = synth.image_pair(W, H, 8, seed=W)
+    if ch == 3:
+        I0 = np.stack([g0, 255 - g0, g0 // 2 + 40]); I1 = np.stack([g1, 255 - g1, g1 // 2 + 40])
+    else:
+        I0, I1 = g0, g1
+    flow, flows, minC = pyramidal_sgm_ng(I0, I1, numPyd, subPixelRefine=sub)
+    # oracle composition
+    lv = [(I0, I1)]
+    for _ in range(1, numPyd):
+        a, b = lv[-1]
+        red = (lambda im: np.stack([oracle.impyramid_reduce(c) for c in im])) if ch == 3 else oracle.impyramid_reduce
+        lv.append((red(a), red(b)))
+    gray = [(oracle.rgb2gray(a), oracle.rgb2gray(b)) if ch == 3 else (a, b) for a, b in lv]
+    hc, wc = gray[-1][0].shape
+    mvPre = np.zeros((2, hc, wc))
+    want = []
+    for l in range(numPyd, 0, -1):
+        mc, fl = oracle.calc_pyd_cost_sgm_ng(gray[l - 1][0], gray[l - 1][1], mvPre, 1, 2, sub, 6, 32)
+        want.append(fl)
+        mvPre = np.ascontiguousarray(2.0 * np.repeat(np.repeat(fl, 2, axis=1), 2, axis=2))
+    assert len(flows) == numPyd
+    for got, w in zip(flows, want):
+        np.testing.assert_array_equal(got, w)
+    np.testing.assert_array_equal(minC, mc)
+    np.testing.assert_array_equal(flow, want[-1])
