@@ -28,6 +28,7 @@ struct NgAggArgs {
     int W, H, D;
     int P1, P2;
     int blk_begin[5];
+    int slot_of[4];         // split kernel: path slot of block range k (long lines are launched first)
 };
 
 struct NgWtaArgs {

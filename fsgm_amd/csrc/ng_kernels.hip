@@ -5,6 +5,7 @@
 //                              (+ a rand() hint), so the frame is inherently raster-serial.
 #include "ng_kernels.h"
 #include "fsgm_device.h"
+#include <stdlib.h>
 
 namespace fsgm {
 
@@ -278,6 +279,145 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
             buf1[2 * Dp + cand] = (uint32_t)o & 0xFF; buf1[3 * Dp + cand] = (uint32_t)(o + a.P1) & 0xFF;
             if (lact) atomicAdd(&Sf[off + cand], (uint32_t)o);                    // :249
             if (cand == 0) smin[(t + 1) % 3] = 255u;
+        }
+        __syncthreads();
+        uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
+      }
+    }
+}
+
+// The matcher of one candidate over the entries [e0, e1) of a staged predecessor (e0 % 4 == 0): the last exact
+// match (NG_NOMATCH if none) and the minimum over the near entries (NG_BIG if none), to be folded in entry order.
+constexpr uint32_t NG_NOMATCH = 0xFFFFFFFFu, NG_BIG = 0xFFFFu;
+__device__ __forceinline__ void ng_match_range(const NgPre& q, int e0, int e1, int mvx, int mvy, bool safe, uint32_t& m1, uint32_t& m2) {
+    if (safe) {
+        const uint32_t ck2 = ng_pack_mv(mvx, mvy) + 0x00020002u;
+        const uint32_t* qk = (const uint32_t*)q.x;
+        int d2 = e0;
+        for (; d2 + 4 <= e1; d2 += 4) {
+            const uint4 k4 = *(const uint4*)(qk + d2);
+            const uint4 c8 = *(const uint4*)(q.c8 + d2), cp = *(const uint4*)(q.cp + d2);
+            const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w};
+            const uint32_t c8a[4] = {c8.x, c8.y, c8.z, c8.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t t = pk_sub(ck2, ka[i]);
+                const bool nr = pk_min(t, 0x00040004u) == t, eq = t == 0x00020002u;
+                m1 = eq ? c8a[i] : m1;                                            // last match wins
+                uint32_t sel = nr ? cpa[i] : NG_BIG;
+                sel = eq ? NG_BIG : sel;
+                m2 = min(m2, sel);
+            }
+        }
+        for (; d2 < e1; d2++) {
+            const uint32_t t = pk_sub(ck2, qk[d2]);
+            const bool nr = pk_min(t, 0x00040004u) == t, eq = t == 0x00020002u;
+            m1 = eq ? q.c8[d2] : m1;
+            if (nr && !eq) m2 = min(m2, q.cp[d2]);
+        }
+    } else {
+        for (int d2 = e0; d2 < e1; d2++) {
+            const int qx = q.x[d2], qy = q.y[d2];
+            if (mvx == qx && mvy == qy) m1 = q.c8[d2];
+            else if (near2(mvx, qx) && near2(mvy, qy)) m2 = min(m2, q.cp[d2]);
+        }
+    }
+}
+
+// ng_agg_lines_kernel with the matcher of every candidate cut PARTS ways over the predecessor's entries:
+// 256 * PARTS threads advance the same 256/D lines, a step is shorter by that factor and costs a second barrier.  For a single
+// frame the long lines (1242 steps against 375) outlive the short ones at about one wave per SIMD, where the
+// step latency is all that counts; with the long lines' blocks launched first (slot_of) the short ones fill in.
+template <int PARTS>
+__global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sNg[];
+    // [line][2 buffers][4 arrays][Dp] | [line][4] minima | [line][Dp] candidate mvx | [line][Dp] mvy | [PARTS - 1][line][Dp][2]
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if ((int)blockIdx.x >= a.blk_begin[i]) k = i;
+    const int slot = a.slot_of[k];
+    const int base = slot & 1;                               // 0: along x, 1: along y
+    const bool mirror = slot >= 2;
+    const int W = a.W, H = a.H, D = a.D, Dp = (D + 3) & ~3;
+    const int LPB = 256 / D;                                  // lines per workgroup
+    const int NP = W * H;
+    const int nlines = base == 0 ? H : W;
+    const int len = base == 0 ? W : H;
+    const int part = threadIdx.x >> 8, g = threadIdx.x & 255;
+    const int ll = min(g / D, LPB - 1), cand = g - (g / D) * D;
+    const bool tact = g < LPB * D;                            // this thread holds a candidate
+    const int line = ((int)blockIdx.x - a.blk_begin[k]) * LPB + ll;
+    const bool lact = tact && line < nlines;
+    const int linec = min(line, nlines - 1);
+    const size_t f = blockIdx.y;
+    const Cand* __restrict__ Cf = a.C + f * (size_t)NP * D;
+    uint32_t* __restrict__ Sf = a.S + f * (size_t)NP * D;
+    uint32_t* buf0 = sNg + (size_t)ll * 8 * Dp;
+    uint32_t* buf1 = buf0 + 4 * Dp;
+    uint32_t* smin = sNg + (size_t)LPB * 8 * Dp + ll * 4;
+    uint32_t* cxs = sNg + (size_t)LPB * (8 * Dp + 4) + (size_t)ll * Dp;
+    uint32_t* cys = cxs + (size_t)LPB * Dp;
+    uint32_t* parts = sNg + (size_t)LPB * (10 * Dp + 4);      // [(part - 1) * LPB + ll][Dp][2]
+    if (part == 0 && cand < 3 && tact) smin[cand] = 255u;
+    const bool safe = *a.unsafe == 0;
+    const int nb = Dp >> 2, pb = (nb + PARTS - 1) / PARTS;
+    const int e0 = min(D, 4 * pb * part), e1 = min(D, 4 * pb * (part + 1));
+    auto pix_of = [&](int t) {
+        int x = base == 0 ? t : linec, y = base == 0 ? linec : t;
+        if (mirror) { x = W - 1 - x; y = H - 1 - y; }
+        return (size_t)y * W + x;
+    };
+    constexpr int PF = 4;
+    Cand ring[PF];                                            // part 0 only: the candidates of steps t .. t+3
+    if (part == 0) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) ring[i] = Cf[pix_of(min(i, len - 1)) * D + cand];
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < len; t0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int t = t0 + u;
+        if (t >= len) break;                                  // block-uniform
+        const NgPre q{(const int32_t*)buf0, (const int32_t*)buf0 + Dp, buf0 + 2 * Dp, buf0 + 3 * Dp};
+        // ---- phase 1: partial matchers
+        uint32_t m1 = NG_NOMATCH, m2 = NG_BIG;
+        if (t > 0) {
+            ng_match_range(q, e0, e1, (int)cxs[cand], (int)cys[cand], safe, m1, m2);
+            if (part > 0) {
+                uint32_t* pr = parts + (((size_t)(part - 1) * LPB + ll) * Dp + cand) * 2;
+                pr[0] = m1; pr[1] = m2;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: fold in entry order, finish the step, stage it for the next one
+        if (part == 0) {
+            const Cand c = ring[u];
+            ring[u] = Cf[pix_of(min(t + PF, len - 1)) * D + cand];
+            const size_t off = pix_of(t) * D;
+            const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
+            const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
+            int o = c.cost;
+            if (t > 0) {
+#pragma unroll
+                for (int e = 0; e < PARTS - 1; e++) {
+                    const uint32_t* pr = parts + (((size_t)e * LPB + ll) * Dp + cand) * 2;
+                    m1 = pr[0] != NG_NOMATCH ? pr[0] : m1;
+                    m2 = min(m2, pr[1]);
+                }
+                const uint32_t best = min(jump, min(m1 == NG_NOMATCH ? jump : m1, m2));
+                o = (c.cost + (int)best) - (int)m;
+                if (tact) atomicMin(&smin[t % 3], (uint32_t)o & 0xFF);            // :74 narrowed
+            }
+            if (tact) {
+                buf1[cand] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + cand] = (uint32_t)c.mvy;
+                buf1[2 * Dp + cand] = (uint32_t)o & 0xFF; buf1[3 * Dp + cand] = (uint32_t)(o + a.P1) & 0xFF;
+                if (lact) atomicAdd(&Sf[off + cand], (uint32_t)o);                // :249
+                if (cand == 0) smin[(t + 1) % 3] = 255u;
+                const Cand cn = ring[(u + 1) % PF];                               // the next step's candidate, for all parts
+                cxs[cand] = (uint32_t)cn.mvx; cys[cand] = (uint32_t)cn.mvy;
+            }
         }
         __syncthreads();
         uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
@@ -816,14 +956,28 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
     }
     a.blk_begin[4] = acc;
     if (a.D <= 128 && a.unsafe) {
-        const int lpb = 256 / a.D;
+        const int lpb = 256 / a.D, Dp = (a.D + 3) & ~3;
+        // long lines first: with few frames their blocks decide when the launch ends
+        const char* env = getenv("FSGM_NG_SPLIT");               // A/B switch: parts per matcher (0/1: one thread per (line, candidate))
+        const int nparts = frames <= 2 ? (env ? atoi(env) : 2) : 1;   // 1242x375, 3-level pyramid: 9.64 / 7.34 / 7.98 / 7.66 ms with 1 / 2 / 3 / 4 parts
+        const bool split = nparts >= 2 && nparts <= 4;
+        const int ord_x[4] = {0, 2, 1, 3}, ord_y[4] = {1, 3, 0, 2};
         acc = 0;
         for (int i = 0; i < 4; i++) {
+            const int sl = split ? (a.W >= a.H ? ord_x[i] : ord_y[i]) : i;
+            a.slot_of[i] = sl;
             a.blk_begin[i] = acc;
-            acc += (((i & 1) == 0 ? a.H : a.W) + lpb - 1) / lpb;
+            acc += (((sl & 1) == 0 ? a.H : a.W) + lpb - 1) / lpb;
         }
         a.blk_begin[4] = acc;
-        const size_t lds = ((size_t)lpb * 8 * ((a.D + 3) & ~3) + lpb * 3) * sizeof(uint32_t);
+        if (split) {
+            const size_t lds = ((size_t)lpb * (10 * Dp + 4) + (size_t)(nparts - 1) * lpb * Dp * 2) * sizeof(uint32_t);
+            if (nparts == 2)      hipLaunchKernelGGL(ng_agg_split_kernel<2>, dim3(acc, frames), dim3(512), lds, st, a);
+            else if (nparts == 3) hipLaunchKernelGGL(ng_agg_split_kernel<3>, dim3(acc, frames), dim3(768), lds, st, a);
+            else                  hipLaunchKernelGGL(ng_agg_split_kernel<4>, dim3(acc, frames), dim3(1024), lds, st, a);
+            return;
+        }
+        const size_t lds = ((size_t)lpb * 8 * Dp + lpb * 3) * sizeof(uint32_t);
         hipLaunchKernelGGL(ng_agg_lines_kernel, dim3(acc, frames), dim3(256), lds, st, a);
         return;
     }

@@ -81,3 +81,18 @@ def test_calc_cost_sgm_ng_exact_matcher_form(gpu_lib, oracle, monkeypatch):
     gmc, gfl = calc_cost_sgm_ng(I1, I2, None, 1, 2, 0, 6, 32, rand_stream=rs)
     np.testing.assert_array_equal(gmc, mc)
     np.testing.assert_array_equal(gfl, fl)
+
+
+@pytest.mark.parametrize("parts", ["0", "2", "3", "4"])
+def test_calc_pyd_cost_sgm_ng_matcher_split(gpu_lib, oracle, monkeypatch, parts):
+    """A single frame cuts every candidate's matcher over the predecessor's entries (2 ways by default;
+    FSGM_NG_SPLIT selects 0/1 = no split, 2, 3, 4): the fold must keep 'last exact match wins'."""
+    W, H = 45, 38
+    I1, I2 = synth.image_pair(W, H, 16, seed=6)
+    mv = synth.hint_map(W, H, "int", seed=9, amp=2.0)
+    mc, fl, _, S = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 1, 6, 32, want_volumes=True)
+    monkeypatch.setenv("FSGM_NG_SPLIT", parts)
+    gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 1, 6, 32, return_sum=True)
+    np.testing.assert_array_equal(gS, S)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gfl, fl)
