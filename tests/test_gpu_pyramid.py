@@ -93,8 +93,7 @@ def test_pyramidal_sgm_kitti_shape_level_sizes(gpu_lib, oracle):
         np.testing.assert_array_equal(lv3[1], (bd % 11).astype(np.float64) - 5)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("W,H,ch,numPyd,sub", [(61, 45, 3, 3, 0), (48, 37, 1, 2, 1)])
+@pytest.mark.parametrize("W,H,ch,numPyd,sub", [(61, 45, 3, 3, 0), (48, 37, 1, 2, 1), (5, 4, 1, 2, 0), (33, 21, 1, 1, 1), (2, 3, 3, 3, 0)])
 def test_pyramidal_loop_with_the_neighbour_guided_matcher(gpu_lib, oracle, W, H, ch, numPyd, sub):
     """BASELINE config 4 names calc_pyd_cost_sgm_ng for the pyramidal path: the level loop with the ng MEX swapped
     in (fsgm_amd.pyramidal_sgm_ng) against the same composition of the oracle's functions, level by level."""
