@@ -658,8 +658,10 @@ static fsgm_status cached_plan(fsgm_epi_plan** out, int W, int H, int D, int bat
 void fsgm_pyd_shutdown_internal(void);
 void fsgm_pyramid_shutdown_internal(void);
 void fsgm_post_shutdown_internal(void);
+void fsgm_ng_shutdown_internal(void);
 
 void fsgm_shutdown(void) {
+    fsgm_ng_shutdown_internal();
     fsgm_post_shutdown_internal();
     fsgm_pyramid_shutdown_internal();
     fsgm_pyd_shutdown_internal();

@@ -1,26 +1,50 @@
 // capi_ng.hip -- C ABI for the two neighbour-guided variants (include/fsgm.h).
-// Buffers are allocated per call: these variants are correctness paths, not the hot loop of the
-// benchmark.
+// (SURVEY 8(a) a-11..a-14).  Device memory comes from a process-lifetime arena (NgPool below).
 #include "capi_common.h"
 #include "epi_kernels.h"
 #include "ng_kernels.h"
+#include <algorithm>
+#include <mutex>
 #include <stdlib.h>
+#include <utility>
 #include <vector>
 
 using namespace fsgm;
 
 namespace {
-struct DevBufs {                       // frees everything on scope exit
-    std::vector<void*> ptrs;
+// Device memory of the two variants comes from one arena that lives as long as the process (like the plans
+// behind the other host entry points: a MATLAB session calls the MEX once per frame, and allocating and
+// freeing 0.6 GB per call costs more than the kernels).  One call at a time, as in a MEX.
+struct NgPool {
+    std::mutex mu;
+    int device = -1;
+    char* base = nullptr;
+    size_t cap = 0;
     hipStream_t stream = nullptr;
-    ~DevBufs() {
-        for (void* p : ptrs) (void)hipFree(p);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-    hipError_t alloc(void** p, size_t bytes) {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 1);
-        if (e == hipSuccess) ptrs.push_back(*p);
-        return e;
+};
+NgPool g_pool;
+
+struct DevBufs {                       // the arena for the duration of one call
+    std::unique_lock<std::mutex> lk{g_pool.mu};
+    std::vector<std::pair<void**, size_t>> req;
+    hipStream_t stream = nullptr;
+    void want(void** p, size_t bytes) { req.emplace_back(p, (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255); }
+    hipError_t commit(int device) {
+        size_t total = 0;
+        for (auto& r : req) total += r.second;
+        hipError_t e = hipSuccess;
+        if (g_pool.device != device || g_pool.cap < total) {
+            if (g_pool.base) { (void)hipSetDevice(g_pool.device); (void)hipFree(g_pool.base); (void)hipSetDevice(device); }
+            if (g_pool.stream && g_pool.device != device) { (void)hipStreamDestroy(g_pool.stream); g_pool.stream = nullptr; }
+            g_pool.base = nullptr; g_pool.cap = 0; g_pool.device = device;
+            if ((e = hipMalloc((void**)&g_pool.base, total)) != hipSuccess) return e;
+            g_pool.cap = total;
+        }
+        if (!g_pool.stream && (e = hipStreamCreateWithFlags(&g_pool.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+        stream = g_pool.stream;
+        size_t used = 0;
+        for (auto& r : req) { *r.first = g_pool.base + used; used += r.second; }
+        return hipSuccess;
     }
 };
 
@@ -35,6 +59,14 @@ fsgm_status pick_device(int device) {
 }  // namespace
 
 extern "C" {
+
+void fsgm_ng_shutdown_internal(void) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (g_pool.device >= 0) (void)hipSetDevice(g_pool.device);
+    if (g_pool.base) (void)hipFree(g_pool.base);
+    if (g_pool.stream) (void)hipStreamDestroy(g_pool.stream);
+    g_pool.base = nullptr; g_pool.cap = 0; g_pool.stream = nullptr; g_pool.device = -1;
+}
 
 fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in, const fsgm_ng_out* out, int32_t device) {
     FSGM_REQUIRE(n >= 1 && in && out, "fsgm_calc_pyd_cost_sgm_ng: null argument");
@@ -59,17 +91,17 @@ fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in
     const size_t NP = (size_t)W * H, MV = (size_t)a.mvWidth * a.mvHeight, N = NP * D, B = n;
     DevBufs d;
     uint8_t *dI1, *dI2; uint32_t *dCen1, *dCen2, *dS, *dMinC, *dUnsafe; double *dMv, *dFlow; Cand* dC;
-    FSGM_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
-    FSGM_HIP(d.alloc((void**)&dUnsafe, 4));
-    FSGM_HIP(d.alloc((void**)&dI1, B * NP));
-    FSGM_HIP(d.alloc((void**)&dI2, B * NP));
-    FSGM_HIP(d.alloc((void**)&dCen1, B * NP * 4));
-    FSGM_HIP(d.alloc((void**)&dCen2, B * NP * 4));
-    FSGM_HIP(d.alloc((void**)&dMv, B * MV * 16));
-    FSGM_HIP(d.alloc((void**)&dC, B * N * sizeof(Cand)));
-    FSGM_HIP(d.alloc((void**)&dS, B * N * 4));
-    FSGM_HIP(d.alloc((void**)&dMinC, B * NP * 4));
-    FSGM_HIP(d.alloc((void**)&dFlow, B * NP * 16));
+    d.want((void**)&dUnsafe, 4);
+    d.want((void**)&dI1, B * NP);
+    d.want((void**)&dI2, B * NP);
+    d.want((void**)&dCen1, B * NP * 4);
+    d.want((void**)&dCen2, B * NP * 4);
+    d.want((void**)&dMv, B * MV * 16);
+    d.want((void**)&dC, B * N * sizeof(Cand));
+    d.want((void**)&dS, B * N * 4);
+    d.want((void**)&dMinC, B * NP * 4);
+    d.want((void**)&dFlow, B * NP * 16);
+    { const hipError_t e = d.commit(device); if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP, "fsgm_calc_pyd_cost_sgm_ng: %s", hipGetErrorString(e)); }
     for (int i = 0; i < n; i++) {
         FSGM_HIP(hipMemcpyAsync(dI1 + i * NP, in[i].I1, NP, hipMemcpyHostToDevice, d.stream));
         FSGM_HIP(hipMemcpyAsync(dI2 + i * NP, in[i].I2, NP, hipMemcpyHostToDevice, d.stream));
@@ -124,15 +156,15 @@ fsgm_status fsgm_calc_cost_sgm_ng_batch_host(int32_t n, const fsgm_otf_in* in, c
     const size_t NP = (size_t)W * H, B = n, rowE = (size_t)W * OTF_E;
     DevBufs d;
     uint8_t *dI1, *dI2; uint32_t *dCen1, *dCen2, *dMinC; double* dFlow; int32_t* dRnd; Cand* dLrow;
-    FSGM_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
-    FSGM_HIP(d.alloc((void**)&dI1, B * NP));
-    FSGM_HIP(d.alloc((void**)&dI2, B * NP));
-    FSGM_HIP(d.alloc((void**)&dCen1, B * NP * 4));
-    FSGM_HIP(d.alloc((void**)&dCen2, B * NP * 4));
-    FSGM_HIP(d.alloc((void**)&dRnd, B * NP * 8 * 4));
-    FSGM_HIP(d.alloc((void**)&dLrow, B * 6 * rowE * sizeof(Cand)));
-    FSGM_HIP(d.alloc((void**)&dMinC, B * NP * 4));
-    FSGM_HIP(d.alloc((void**)&dFlow, B * NP * 16));
+    d.want((void**)&dI1, B * NP);
+    d.want((void**)&dI2, B * NP);
+    d.want((void**)&dCen1, B * NP * 4);
+    d.want((void**)&dCen2, B * NP * 4);
+    d.want((void**)&dRnd, B * NP * 8 * 4);
+    d.want((void**)&dLrow, B * 6 * rowE * sizeof(Cand));
+    d.want((void**)&dMinC, B * NP * 4);
+    d.want((void**)&dFlow, B * NP * 16);
+    { const hipError_t e = d.commit(device); if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP, "fsgm_calc_cost_sgm_ng: %s", hipGetErrorString(e)); }
     std::vector<int32_t> drawn;
     for (int i = 0; i < n; i++) {
         const int32_t* rs = in[i].rand_stream;
