@@ -659,8 +659,10 @@ void fsgm_pyd_shutdown_internal(void);
 void fsgm_pyramid_shutdown_internal(void);
 void fsgm_post_shutdown_internal(void);
 void fsgm_ng_shutdown_internal(void);
+void fsgm_ng_pyramid_shutdown_internal(void);
 
 void fsgm_shutdown(void) {
+    fsgm_ng_pyramid_shutdown_internal();
     fsgm_ng_shutdown_internal();
     fsgm_post_shutdown_internal();
     fsgm_pyramid_shutdown_internal();

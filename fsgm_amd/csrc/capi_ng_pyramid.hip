@@ -7,6 +7,8 @@
 #include "epi_kernels.h"
 #include "ng_kernels.h"
 #include "pyramid_kernels.h"
+#include <mutex>
+#include <string.h>
 #include <vector>
 
 using namespace fsgm;
@@ -201,6 +203,41 @@ fsgm_status fsgm_ng_pyramid_plan_time(fsgm_ng_pyramid_plan* p, int32_t warmup, i
     float ms = 0;
     FSGM_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     *ms_avg = ms / iters;
+    return FSGM_OK;
+}
+
+// ---- host-pointer entry point: one call = the whole loop; plans are cached per shape like fsgm_pyramidal_sgm_host's ----
+static std::mutex g_ngpyr_mu;
+static std::vector<fsgm_ng_pyramid_plan*> g_ngpyr_cache;
+
+void fsgm_ng_pyramid_shutdown_internal(void) {
+    std::lock_guard<std::mutex> lk(g_ngpyr_mu);
+    for (fsgm_ng_pyramid_plan* p : g_ngpyr_cache) fsgm_ng_pyramid_plan_destroy(p);
+    g_ngpyr_cache.clear();
+}
+
+fsgm_status fsgm_pyramidal_sgm_ng_host(const uint8_t* I0, const uint8_t* I1, int32_t width, int32_t height, int32_t channels,
+                                       const fsgm_ng_pyramid_params* prm, double* flow, uint32_t* minC, double* const* flowPyd) {
+    FSGM_REQUIRE(I0 && I1 && prm && flow, "fsgm_pyramidal_sgm_ng: null argument");
+    std::lock_guard<std::mutex> lk(g_ngpyr_mu);
+    fsgm_ng_pyramid_plan* p = nullptr;
+    for (fsgm_ng_pyramid_plan* q : g_ngpyr_cache)
+        if (q->W == width && q->H == height && q->channels == channels && memcmp(&q->prm, prm, sizeof *prm) == 0) p = q;
+    fsgm_status st;
+    if (!p) {
+        if ((st = fsgm_ng_pyramid_plan_create(&p, width, height, channels, prm)) != FSGM_OK) return st;
+        if (g_ngpyr_cache.size() >= 2) {
+            fsgm_ng_pyramid_plan_destroy(g_ngpyr_cache.front());
+            g_ngpyr_cache.erase(g_ngpyr_cache.begin());
+        }
+        g_ngpyr_cache.push_back(p);
+    }
+    if ((st = fsgm_ng_pyramid_plan_upload(p, I0, I1)) != FSGM_OK) return st;
+    if ((st = fsgm_ng_pyramid_plan_run(p)) != FSGM_OK) return st;
+    if ((st = fsgm_ng_pyramid_plan_download(p, 1, flow, minC)) != FSGM_OK) return st;
+    if (flowPyd)
+        for (int l = 1; l <= prm->numPyd; l++)
+            if (flowPyd[l - 1] && (st = fsgm_ng_pyramid_plan_download(p, l, flowPyd[l - 1], nullptr)) != FSGM_OK) return st;
     return FSGM_OK;
 }
 

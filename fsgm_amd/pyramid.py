@@ -157,6 +157,7 @@ def _bind_ng(lib):
     lib.fsgm_ng_pyramid_plan_run.argtypes = [vp]
     lib.fsgm_ng_pyramid_plan_download.argtypes = [vp, i32, vp, vp]
     lib.fsgm_ng_pyramid_plan_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+    lib.fsgm_pyramidal_sgm_ng_host.argtypes = [vp, vp, i32, i32, i32, C.POINTER(NgPyramidParams), vp, vp, vp]
     lib._ng_pyramid_bound = True
 
 
@@ -230,12 +231,22 @@ def pyramidal_sgm_ng(I0, I1, numPyd=3, *, device=0, **overrides):
     everything stays on the device between levels.
 
     Returns (flow of level 1, [flow per level, coarsest first], minC of level 1)."""
+    lib = _lib.load()
+    _bind_ng(lib)
     I0, I1, ch = _check_images(I0, I1)
     H, W = I0.shape[-2:]
-    with NgPyramidPlan(W, H, ch, numPyd, device=device, **overrides) as plan:
-        plan.upload(I0, I1)
-        plan.run()
-        flows = [plan.download(l)[0] for l in range(numPyd, 1, -1)]
-        flow, minC = plan.download(1)
-    flows.append(flow)
-    return flow, flows, minC
+    prm = lib.fsgm_ng_pyramid_params_default()
+    prm.numPyd, prm.device = int(numPyd), int(device)
+    for k, v in overrides.items():
+        if not hasattr(prm, k):
+            raise TypeError(f"unknown pyramidal_sgm_ng parameter {k!r}")
+        setattr(prm, k, int(v))
+    sizes = [(W, H)]
+    for _ in range(1, prm.numPyd):
+        sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+    flow = np.zeros((2, H, W), np.float64)
+    minC = np.zeros((H, W), np.uint32)
+    lv = [np.zeros((2, h, w), np.float64) for (w, h) in sizes]
+    ptrs = (C.c_void_p * len(lv))(*[a.ctypes.data for a in lv])
+    check(lib.fsgm_pyramidal_sgm_ng_host(ptr(I0), ptr(I1), W, H, ch, C.byref(prm), ptr(flow), ptr(minC), ptrs))
+    return flow, lv[::-1], minC

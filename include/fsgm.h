@@ -299,6 +299,12 @@ fsgm_status fsgm_ng_pyramid_plan_run(fsgm_ng_pyramid_plan* plan);        /* asyn
 /* flow [2][h][w] and minC [h][w] of `level` (1 = full resolution); either may be NULL */
 fsgm_status fsgm_ng_pyramid_plan_download(fsgm_ng_pyramid_plan* plan, int32_t level, double* flow, uint32_t* minC);
 fsgm_status fsgm_ng_pyramid_plan_time(fsgm_ng_pyramid_plan* plan, int32_t warmup, int32_t iters, float* ms_avg);
+/* one call = the whole loop on a plan cached per shape and parameters: I0, I1 as for fsgm_pyramidal_sgm_host;
+ * flow [2][height][width] and minC (may be NULL) of level 1; flowPyd (may be NULL): numPyd pointers, entry l-1
+ * receives the flow of level l ([2][h_l][w_l]) or is skipped when NULL */
+fsgm_status fsgm_pyramidal_sgm_ng_host(const uint8_t* I0, const uint8_t* I1, int32_t width, int32_t height,
+                                       int32_t channels, const fsgm_ng_pyramid_params* prm,
+                                       double* flow, uint32_t* minC, double* const* flowPyd);
 
 
 /* ------------------------------------------------------------------------------------------

@@ -91,3 +91,29 @@ def test_fsgm_pyramidal_sgm_gateway_as_a_drop_in_pyramidal_sgm_would_call_it(gpu
         np.testing.assert_array_equal(outs[2 + l], want_lv[l])
     (only,), _ = mh.call("fsgm_pyramidal_sgm", 1, g0, g1)                       # gray pair, default numPyd = 5
     np.testing.assert_array_equal(only, oracle.pyramidal_sgm(g0, g1, 5)[0])
+
+
+def test_fsgm_pyramidal_sgm_ng_gateway(gpu_lib, oracle):
+    """[flow, minC, flowPyd1..3] = fsgm_pyramidal_sgm_ng(I0p, I1p, 3): the level loop around calc_pyd_cost_sgm_ng
+    (BASELINE config 4), against the same composition of the oracle's functions."""
+    W, H = 70, 41
+    g0, g1 = synth.image_pair(W, H, 8, seed=5)
+    I0 = np.stack([g0, 255 - g0, g0 // 3 + 80])
+    I1 = np.stack([g1, 255 - g1, g1 // 3 + 80])
+    outs, _ = mh.call("fsgm_pyramidal_sgm_ng", 5, I0, I1, 3)
+    lv = [(I0, I1)]
+    for _ in range(2):
+        a, b = lv[-1]
+        lv.append((np.stack([oracle.impyramid_reduce(c) for c in a]), np.stack([oracle.impyramid_reduce(c) for c in b])))
+    gray = [(oracle.rgb2gray(a), oracle.rgb2gray(b)) for a, b in lv]
+    mvPre = np.zeros((2,) + gray[-1][0].shape)
+    want = {}
+    for l in (3, 2, 1):
+        mc, fl = oracle.calc_pyd_cost_sgm_ng(gray[l - 1][0], gray[l - 1][1], mvPre, 1, 2, 0, 6, 32)
+        want[l] = fl
+        mvPre = np.ascontiguousarray(2.0 * np.repeat(np.repeat(fl, 2, axis=1), 2, axis=2))
+    assert outs[0].shape == (2, H, W) and outs[0].dtype == np.float64 and outs[1].dtype == np.uint32
+    np.testing.assert_array_equal(outs[0], want[1])
+    np.testing.assert_array_equal(outs[1], mc)
+    for l in (1, 2, 3):
+        np.testing.assert_array_equal(outs[1 + l], want[l])

@@ -8,7 +8,8 @@ import pytest
 from fsgm_amd import synth, _lib
 from tests import mexharness as mh
 
-GATEWAYS = ["calc_cost_sgm", "calc_pyd_cost_sgm", "calc_pyd_cost_sgm_ng", "calc_cost_sgm_ng", "fsgm_pyramidal_sgm"]
+GATEWAYS = ["calc_cost_sgm", "calc_pyd_cost_sgm", "calc_pyd_cost_sgm_ng", "calc_cost_sgm_ng", "fsgm_pyramidal_sgm",
+            "fsgm_pyramidal_sgm_ng"]
 
 
 @pytest.mark.parametrize("name", GATEWAYS)
