@@ -24,6 +24,8 @@ struct fsgm_ng_pyramid_plan {
     std::vector<double*> dFlow;                      // [2][h][w]
     std::vector<uint32_t*> dMinC;                    // [h][w]
     uint32_t *dCen1 = nullptr, *dCen2 = nullptr, *dS = nullptr, *dUnsafe = nullptr;
+    uint16_t* dDd = nullptr;                         // repeats in the candidate lists (launch_ng_dedupe)
+    uint8_t* dDk = nullptr;
     Cand* dC = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -47,7 +49,7 @@ void fsgm_ng_pyramid_plan_destroy(fsgm_ng_pyramid_plan* p) {
     (void)hipSetDevice(p->device);
     auto drop = [](auto& v) { for (auto* b : v) if (b) (void)hipFree(b); };
     drop(p->dP0); drop(p->dP1); drop(p->dG0); drop(p->dG1); drop(p->dMv); drop(p->dFlow); drop(p->dMinC);
-    void* one[] = {p->dCen1, p->dCen2, p->dS, p->dUnsafe, p->dC};
+    void* one[] = {p->dCen1, p->dCen2, p->dS, p->dUnsafe, p->dC, p->dDd, p->dDk};
     for (void* b : one) if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -105,6 +107,8 @@ fsgm_status fsgm_ng_pyramid_plan_create(fsgm_ng_pyramid_plan** out, int32_t W, i
     if (e == hipSuccess) e = hipMalloc((void**)&p->dC, N * sizeof(Cand));
     if (e == hipSuccess) e = hipMalloc((void**)&p->dS, N * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dUnsafe, 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dDd, N * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dDk, NP);
     if (e == hipSuccess) e = hipMemset(p->dMv[n - 1], 0, 2 * (size_t)p->mvW[n - 1] * p->mvH[n - 1] * sizeof(double));   // :34
     if (e != hipSuccess) {
         fsgm_ng_pyramid_plan_destroy(p);
@@ -156,6 +160,11 @@ static fsgm_status ng_pyramid_enqueue(fsgm_ng_pyramid_plan* p) {
         launch_ng_cost(s, ca, 1);
         NgAggArgs ga;
         ga.C = p->dC; ga.S = p->dS; ga.unsafe = p->dUnsafe; ga.W = w; ga.H = h; ga.D = D; ga.P1 = p->prm.P1; ga.P2 = p->prm.P2;
+        ga.dd = nullptr; ga.dk = nullptr;
+        if (D <= 128) {
+            launch_ng_dedupe(s, p->dC, p->dDd, p->dDk, w, h, D, 1);
+            ga.dd = p->dDd; ga.dk = p->dDk;
+        }
         launch_ng_aggregate(s, ga, 1);
         NgWtaArgs wa;
         wa.C = p->dC; wa.S = p->dS; wa.minC = p->dMinC[l]; wa.flow = p->dFlow[l]; wa.W = w; wa.H = h; wa.D = D;

@@ -25,6 +25,8 @@ struct NgAggArgs {
     const Cand* C;          // [frames][NP][D]
     uint32_t* S;            // [frames][NP][D], zeroed before the launch; paths add atomically
     const uint32_t* unsafe; // the cost kernel's flag (null: take the generic kernel)
+    const uint16_t* dd;     // [frames][NP][D] place of a candidate in its pixel's list without repeats, 0xFFFF = a repeat
+    const uint8_t* dk;      //                 (launch_ng_dedupe); [frames][NP] length of that list.  Null: every candidate is staged
     int W, H, D;
     int P1, P2;
     int blk_begin[5];
@@ -63,6 +65,8 @@ struct OtfArgs {
 
 void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames);
 void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames);
+// repeats among the D <= 128 candidates of every pixel (same motion vector and same cost), see ng_dedupe_kernel
+void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, int W, int H, int D, int frames);
 void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames);
 void launch_ng_subpixel(hipStream_t st, const NgSubpixArgs& a, int frames);
 void launch_otf(hipStream_t st, const OtfArgs& a, int frames);

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void ng_agg_kernel(NgAggArgs a) {
 struct NgPre { const int32_t* x; const int32_t* y; const uint32_t* c8; const uint32_t* cp; };
 
 // motion vector as 2 x u16 (valid for |mv| < 0x3FF0: the launch's unsafe flag is raised otherwise)
+constexpr uint32_t NG_PADKEY = 0xC000C000u;   // a staged key no candidate in the packed range is equal or near to
 __device__ __forceinline__ uint32_t ng_pack_mv(int mvx, int mvy) {
     return ((uint32_t)(mvx + 0x4000) << 16) | ((uint32_t)(mvy + 0x4000) & 0xFFFFu);
 }
@@ -215,12 +216,61 @@ __device__ __forceinline__ void ng_match4_pair(const NgPre& q, int D, int mvxa, 
     bestb = min(jump, min(min1b, min2b));
 }
 
+// Repeats in a pixel's candidate list.  The 9 hints of a pixel are samples of a smooth map 8 pixels apart, so
+// their 3x3 expansions overlap: in real flow fields most of the 81 candidates are repeats of one another.
+// Two candidates with the same motion vector and the same cost C get the same path cost on every path (the
+// matcher's result depends on the motion vector alone: calc_pyd_cost_sgm_ng.cpp:39-78), so a predecessor list
+// without repeats gives every candidate the same minima as the full list, as long as of every group of repeats
+// the LAST is kept ("last exact match wins", :60-62: the kept entries stay in their order).  One wave per pixel:
+// keys (mvx, mvy, C) packed into 31 bits, every lane finds the last index holding its key, kept entries are
+// ranked with two ballots.  A pixel with a vector outside +-4095 keeps its whole list.
+__global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__ C, uint16_t* __restrict__ dd, uint8_t* __restrict__ dk,
+                                                        int NPtot, int D) {
+    __shared__ __attribute__((aligned(16))) uint32_t sk[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= NPtot) return;                                   // wave-uniform
+    const Cand* c = C + (size_t)p * D;
+    const int d0 = lane, d1 = lane + 64;
+    const bool has0 = d0 < D, has1 = d1 < D;
+    auto key_of = [](const Cand& e, bool& ok) -> uint32_t {
+        ok = e.mvx > -0x1000 && e.mvx < 0x1000 && e.mvy > -0x1000 && e.mvy < 0x1000 && e.cost >= 0 && e.cost < 32;
+        return ((uint32_t)(e.mvx + 0x1000) << 18) | ((uint32_t)(e.mvy + 0x1000) << 5) | (uint32_t)e.cost;
+    };
+    bool ok0 = true, ok1 = true;
+    const Cand z = {0, 0, 0};
+    const uint32_t k0 = key_of(has0 ? c[d0] : z, ok0), k1 = key_of(has1 ? c[d1] : z, ok1);
+    sk[wave][d0] = has0 ? k0 : 0xFFFFFFFFu;
+    sk[wave][d1] = has1 ? k1 : 0xFFFFFFFFu;
+    const bool all_ok = __builtin_amdgcn_ballot_w64(!(ok0 && ok1)) == 0;
+    __builtin_amdgcn_wave_barrier();
+    int last0 = d0, last1 = d1;
+    if (all_ok) {
+        for (int e = 0; e < D; e += 4) {
+            const uint4 k4 = *(const uint4*)(&sk[wave][e]);
+            const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                last0 = ka[i] == k0 ? e + i : last0;
+                last1 = ka[i] == k1 ? e + i : last1;
+            }
+        }
+    }
+    const bool keep0 = has0 && last0 == d0, keep1 = has1 && last1 == d1;
+    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(keep0), b1 = __builtin_amdgcn_ballot_w64(keep1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int n0 = __popcll(b0);
+    if (has0) dd[(size_t)p * D + d0] = keep0 ? (uint16_t)__popcll(b0 & below) : (uint16_t)0xFFFF;
+    if (has1) dd[(size_t)p * D + d1] = keep1 ? (uint16_t)(n0 + __popcll(b1 & below)) : (uint16_t)0xFFFF;
+    if (lane == 0) dk[p] = (uint8_t)(n0 + __popcll(b1));
+}
+
 // One THREAD per (line, candidate): a 256-thread workgroup advances 256/D lines (3 at D = 81, 95 % of the
 // lanes busy; one wave per line leaves 37 % idle and needs two rounds).  The per-line minimum crosses
 // waves through an LDS atomicMin in a three-slot ring (written at step t, read at t+1, reset at t+2),
 // one barrier per step.
 __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t sNg[];   // [line][2 buffers][4 arrays][Dp], then [line][3] minima
+    extern __shared__ __attribute__((aligned(16))) uint32_t sNg[];   // [line][2 buffers][4 arrays][Dp], then [line][8]: 3 minima, the staged lists' lengths at [4 + step parity]
     int slot = 0;
 #pragma unroll
     for (int i = 1; i < 4; i++)
@@ -243,7 +293,7 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
     uint32_t* __restrict__ Sf = a.S + f * (size_t)NP * D;
     uint32_t* buf0 = sNg + (size_t)ll * 8 * Dp;
     uint32_t* buf1 = buf0 + 4 * Dp;
-    uint32_t* smin = sNg + (size_t)LPB * 8 * Dp + ll * 3;
+    uint32_t* smin = sNg + (size_t)LPB * 8 * Dp + ll * 8;     // [0..2] minima ring, [4 + (t & 1)] entries staged by step t
     if (cand < 3 && tact) smin[cand] = 255u;
     const bool safe = *a.unsafe == 0;                         // no motion vector of this launch near the int range
     auto pix_of = [&](int t) {
@@ -251,12 +301,20 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
         if (mirror) { x = W - 1 - x; y = H - 1 - y; }
         return (size_t)y * W + x;
     };
+    const uint16_t* __restrict__ ddf = a.dd ? a.dd + f * (size_t)NP * D : nullptr;
+    const uint8_t* __restrict__ dkf = a.dk ? a.dk + f * (size_t)NP : nullptr;
     // the candidates of step t+PF are requested while step t computes (a gathered 12-byte load takes
     // longer than one step); the ring rotates by unrolling, not by copying (a copy would wait for the load)
     constexpr int PF = 4;
     Cand ring[PF];
+    uint32_t rpl[PF], rlen[PF];                               // the candidate's place in its pixel's list without repeats, that list's length
 #pragma unroll
-    for (int k = 0; k < PF; k++) ring[k] = Cf[pix_of(min(k, len - 1)) * D + cand];
+    for (int k = 0; k < PF; k++) {
+        const size_t px = pix_of(min(k, len - 1));
+        ring[k] = Cf[px * D + cand];
+        rpl[k] = ddf ? ddf[px * D + cand] : (uint32_t)cand;
+        rlen[k] = dkf ? dkf[px] : (uint32_t)D;
+    }
     __syncthreads();
     for (int t0 = 0; t0 < len; t0 += PF) {
 #pragma unroll
@@ -264,21 +322,34 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
         const int t = t0 + u;
         if (t >= len) break;                                  // block-uniform
         const Cand c = ring[u];
-        ring[u] = Cf[pix_of(min(t + PF, len - 1)) * D + cand];
+        const uint32_t place = rpl[u], K = rlen[u];
+        {
+            const size_t px = pix_of(min(t + PF, len - 1));
+            ring[u] = Cf[px * D + cand];
+            rpl[u] = ddf ? ddf[px * D + cand] : (uint32_t)cand;
+            rlen[u] = dkf ? dkf[px] : (uint32_t)D;
+        }
         const size_t off = pix_of(t) * D;
         const NgPre q{(const int32_t*)buf0, (const int32_t*)buf0 + Dp, buf0 + 2 * Dp, buf0 + 3 * Dp};
         const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
         const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
         int o = c.cost;
         if (t > 0) {
-            o = ng_match4(q, D, c.mvx, c.mvy, c.cost, m, jump, safe);
+            const int Kpre = (int)smin[4 + ((t - 1) & 1)];
+            o = ng_match4(q, safe ? (Kpre + 3) & ~3 : Kpre, c.mvx, c.mvy, c.cost, m, jump, safe);
             if (tact) atomicMin(&smin[t % 3], (uint32_t)o & 0xFF);                // :74 narrowed
         }
         if (tact) {
-            buf1[cand] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + cand] = (uint32_t)c.mvy;
-            buf1[2 * Dp + cand] = (uint32_t)o & 0xFF; buf1[3 * Dp + cand] = (uint32_t)(o + a.P1) & 0xFF;
+            if (place != 0xFFFFu) {
+                buf1[place] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + place] = (uint32_t)c.mvy;
+                buf1[2 * Dp + place] = (uint32_t)o & 0xFF; buf1[3 * Dp + place] = (uint32_t)(o + a.P1) & 0xFF;
+            }
+            if (cand < 3 && K + cand < (uint32_t)Dp) {         // neutral entries up to the next multiple of 4
+                buf1[K + cand] = NG_PADKEY; buf1[Dp + K + cand] = 0x7FFFFFFFu;
+                buf1[2 * Dp + K + cand] = 0xFFFFu; buf1[3 * Dp + K + cand] = 0xFFFFu;
+            }
             if (lact) atomicAdd(&Sf[off + cand], (uint32_t)o);                    // :249
-            if (cand == 0) smin[(t + 1) % 3] = 255u;
+            if (cand == 0) { smin[(t + 1) % 3] = 255u; smin[4 + (t & 1)] = K; }
         }
         __syncthreads();
         uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
@@ -331,7 +402,7 @@ __device__ __forceinline__ void ng_match_range(const NgPre& q, int e0, int e1, i
 template <int PARTS>
 __global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sNg[];
-    // [line][2 buffers][4 arrays][Dp] | [line][4] minima | [line][Dp] candidate mvx | [line][Dp] mvy | [PARTS - 1][line][Dp][2]
+    // [line][2 buffers][4 arrays][Dp] | [line][8]: 3 minima, staged lengths at [4 + step parity] | [line][Dp] candidate mvx | [line][Dp] mvy | [PARTS - 1][line][Dp][2]
     int k = 0;
 #pragma unroll
     for (int i = 1; i < 4; i++)
@@ -355,24 +426,30 @@ __global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) 
     uint32_t* __restrict__ Sf = a.S + f * (size_t)NP * D;
     uint32_t* buf0 = sNg + (size_t)ll * 8 * Dp;
     uint32_t* buf1 = buf0 + 4 * Dp;
-    uint32_t* smin = sNg + (size_t)LPB * 8 * Dp + ll * 4;
-    uint32_t* cxs = sNg + (size_t)LPB * (8 * Dp + 4) + (size_t)ll * Dp;
+    uint32_t* smin = sNg + (size_t)LPB * 8 * Dp + ll * 8;
+    uint32_t* cxs = sNg + (size_t)LPB * (8 * Dp + 8) + (size_t)ll * Dp;
     uint32_t* cys = cxs + (size_t)LPB * Dp;
-    uint32_t* parts = sNg + (size_t)LPB * (10 * Dp + 4);      // [(part - 1) * LPB + ll][Dp][2]
+    uint32_t* parts = sNg + (size_t)LPB * (10 * Dp + 8);      // [(part - 1) * LPB + ll][Dp][2]
     if (part == 0 && cand < 3 && tact) smin[cand] = 255u;
     const bool safe = *a.unsafe == 0;
-    const int nb = Dp >> 2, pb = (nb + PARTS - 1) / PARTS;
-    const int e0 = min(D, 4 * pb * part), e1 = min(D, 4 * pb * (part + 1));
+    const uint16_t* __restrict__ ddf = a.dd ? a.dd + f * (size_t)NP * D : nullptr;
+    const uint8_t* __restrict__ dkf = a.dk ? a.dk + f * (size_t)NP : nullptr;
     auto pix_of = [&](int t) {
         int x = base == 0 ? t : linec, y = base == 0 ? linec : t;
         if (mirror) { x = W - 1 - x; y = H - 1 - y; }
         return (size_t)y * W + x;
     };
     constexpr int PF = 4;
-    Cand ring[PF];                                            // part 0 only: the candidates of steps t .. t+3
+    Cand ring[PF];                                            // part 0 only: the candidates of steps t .. t+3,
+    uint32_t rpl[PF], rlen[PF];                               // their places in the pixel's list without repeats, its length
     if (part == 0) {
 #pragma unroll
-        for (int i = 0; i < PF; i++) ring[i] = Cf[pix_of(min(i, len - 1)) * D + cand];
+        for (int i = 0; i < PF; i++) {
+            const size_t px = pix_of(min(i, len - 1));
+            ring[i] = Cf[px * D + cand];
+            rpl[i] = ddf ? ddf[px * D + cand] : (uint32_t)cand;
+            rlen[i] = dkf ? dkf[px] : (uint32_t)D;
+        }
     }
     __syncthreads();
     for (int t0 = 0; t0 < len; t0 += PF) {
@@ -384,6 +461,9 @@ __global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) 
         // ---- phase 1: partial matchers
         uint32_t m1 = NG_NOMATCH, m2 = NG_BIG;
         if (t > 0) {
+            const int Kpre = (int)smin[4 + ((t - 1) & 1)], Kq = safe ? (Kpre + 3) & ~3 : Kpre;   // safe: neutral entries fill the last block
+            const int pb = (((Kpre + 3) >> 2) + PARTS - 1) / PARTS;
+            const int e0 = min(Kq, 4 * pb * part), e1 = min(Kq, 4 * pb * (part + 1));
             ng_match_range(q, e0, e1, (int)cxs[cand], (int)cys[cand], safe, m1, m2);
             if (part > 0) {
                 uint32_t* pr = parts + (((size_t)(part - 1) * LPB + ll) * Dp + cand) * 2;
@@ -394,7 +474,13 @@ __global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) 
         // ---- phase 2: fold in entry order, finish the step, stage it for the next one
         if (part == 0) {
             const Cand c = ring[u];
-            ring[u] = Cf[pix_of(min(t + PF, len - 1)) * D + cand];
+            const uint32_t place = rpl[u], K = rlen[u];
+            {
+                const size_t px = pix_of(min(t + PF, len - 1));
+                ring[u] = Cf[px * D + cand];
+                rpl[u] = ddf ? ddf[px * D + cand] : (uint32_t)cand;
+                rlen[u] = dkf ? dkf[px] : (uint32_t)D;
+            }
             const size_t off = pix_of(t) * D;
             const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
             const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
@@ -411,10 +497,16 @@ __global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) 
                 if (tact) atomicMin(&smin[t % 3], (uint32_t)o & 0xFF);            // :74 narrowed
             }
             if (tact) {
-                buf1[cand] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + cand] = (uint32_t)c.mvy;
-                buf1[2 * Dp + cand] = (uint32_t)o & 0xFF; buf1[3 * Dp + cand] = (uint32_t)(o + a.P1) & 0xFF;
+                if (place != 0xFFFFu) {
+                    buf1[place] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + place] = (uint32_t)c.mvy;
+                    buf1[2 * Dp + place] = (uint32_t)o & 0xFF; buf1[3 * Dp + place] = (uint32_t)(o + a.P1) & 0xFF;
+                }
+                if (cand < 3 && K + cand < (uint32_t)Dp) {     // neutral entries up to the next multiple of 4
+                    buf1[K + cand] = NG_PADKEY; buf1[Dp + K + cand] = 0x7FFFFFFFu;
+                    buf1[2 * Dp + K + cand] = 0xFFFFu; buf1[3 * Dp + K + cand] = 0xFFFFu;
+                }
                 if (lact) atomicAdd(&Sf[off + cand], (uint32_t)o);                // :249
-                if (cand == 0) smin[(t + 1) % 3] = 255u;
+                if (cand == 0) { smin[(t + 1) % 3] = 255u; smin[4 + (t & 1)] = K; }
                 const Cand cn = ring[(u + 1) % PF];                               // the next step's candidate, for all parts
                 cxs[cand] = (uint32_t)cn.mvx; cys[cand] = (uint32_t)cn.mvy;
             }
@@ -955,6 +1047,7 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         acc += (((i & 1) == 0 ? a.H : a.W) + 3) / 4;
     }
     a.blk_begin[4] = acc;
+    { const char* e = getenv("FSGM_NG_DEDUPE"); if (e && atoi(e) == 0) { a.dd = nullptr; a.dk = nullptr; } }   // A/B switch: stage every candidate
     if (a.D <= 128 && a.unsafe) {
         const int lpb = 256 / a.D, Dp = (a.D + 3) & ~3;
         // long lines first: with few frames their blocks decide when the launch ends
@@ -971,17 +1064,22 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         }
         a.blk_begin[4] = acc;
         if (split) {
-            const size_t lds = ((size_t)lpb * (10 * Dp + 4) + (size_t)(nparts - 1) * lpb * Dp * 2) * sizeof(uint32_t);
+            const size_t lds = ((size_t)lpb * (10 * Dp + 8) + (size_t)(nparts - 1) * lpb * Dp * 2) * sizeof(uint32_t);
             if (nparts == 2)      hipLaunchKernelGGL(ng_agg_split_kernel<2>, dim3(acc, frames), dim3(512), lds, st, a);
             else if (nparts == 3) hipLaunchKernelGGL(ng_agg_split_kernel<3>, dim3(acc, frames), dim3(768), lds, st, a);
             else                  hipLaunchKernelGGL(ng_agg_split_kernel<4>, dim3(acc, frames), dim3(1024), lds, st, a);
             return;
         }
-        const size_t lds = ((size_t)lpb * 8 * Dp + lpb * 3) * sizeof(uint32_t);
+        const size_t lds = ((size_t)lpb * 8 * Dp + lpb * 8) * sizeof(uint32_t);
         hipLaunchKernelGGL(ng_agg_lines_kernel, dim3(acc, frames), dim3(256), lds, st, a);
         return;
     }
     hipLaunchKernelGGL(ng_agg_kernel, dim3(acc, frames), dim3(256), 0, st, a);
+}
+
+void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, int W, int H, int D, int frames) {
+    const int n = W * H * frames;                            // frames are contiguous in all three arrays
+    hipLaunchKernelGGL(ng_dedupe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, dd, dk, n, D);
 }
 
 void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames) {

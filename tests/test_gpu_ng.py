@@ -96,3 +96,26 @@ def test_calc_pyd_cost_sgm_ng_matcher_split(gpu_lib, oracle, monkeypatch, parts)
     np.testing.assert_array_equal(gS, S)
     np.testing.assert_array_equal(gmc, mc)
     np.testing.assert_array_equal(gfl, fl)
+
+
+@pytest.mark.parametrize("kind,amp,sub,P1,P2,dedupe", [
+    ("zero", 1.0, 0, 6, 32, "1"),          # all nine hints equal: 9 distinct candidates of 81
+    ("int", 1.0, 1, 6, 32, "1"),           # neighbouring integer hints: overlapping 3x3 expansions
+    ("general", 0.8, 1, 6, 32, "1"),       # fractional hints: equal integer vectors sampled at different places, i.e. different costs
+    ("general", 0.8, 0, 90, 120, "1"),     # the same with wrapping penalties
+    ("int", 1.0, 1, 6, 32, "0"),           # switch off: every candidate staged
+])
+def test_calc_pyd_cost_sgm_ng_repeated_candidates(gpu_lib, oracle, monkeypatch, kind, amp, sub, P1, P2, dedupe):
+    """The aggregation stages a pixel's candidate list without repeats (same vector and same cost, the last of
+    each group kept): results must not change, whatever the share of repeats."""
+    W, H = 83, 58
+    I1, I2 = synth.image_pair(W, H, 16, seed=13)
+    mv = synth.hint_map(W, H, kind, seed=17, amp=amp)
+    mc, fl, _, S = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, sub, P1, P2, want_volumes=True)
+    monkeypatch.setenv("FSGM_NG_DEDUPE", dedupe)
+    for parts in ("2", "0"):                                  # split and one-thread-per-candidate kernels
+        monkeypatch.setenv("FSGM_NG_SPLIT", parts)
+        gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, sub, P1, P2, return_sum=True)
+        np.testing.assert_array_equal(gS, S)
+        np.testing.assert_array_equal(gmc, mc)
+        np.testing.assert_array_equal(gfl, fl)
