@@ -11,5 +11,5 @@ from .pyd import calc_pyd_cost_sgm, PydPlan  # noqa: F401
 from .pyramid import pyramidal_sgm, pyramidal_sgm_ng, PyramidPlan, NgPyramidPlan  # noqa: F401
 from .post import (speckle_filter, calc_disp_from_first, forward_backward_check, scanline_in_fill, vzInd2Disp, vmf,  # noqa: F401
                    epi_postprocess, PostPlan)
-from .ng import calc_pyd_cost_sgm_ng, calc_cost_sgm_ng  # noqa: F401
+from .ng import calc_pyd_cost_sgm_ng, calc_cost_sgm_ng, calc_pyd_cost_sgm_ng_batch, calc_cost_sgm_ng_batch  # noqa: F401
 from ._lib import FsgmError, load as load_library  # noqa: F401

@@ -38,6 +38,8 @@ def _bind(lib):
         return
     lib.fsgm_calc_pyd_cost_sgm_ng_host.argtypes = [C.POINTER(NgIn), C.POINTER(NgOut), C.c_int32]
     lib.fsgm_calc_cost_sgm_ng_host.argtypes = [C.POINTER(OtfIn), C.POINTER(OtfOut), C.c_int32]
+    lib.fsgm_calc_pyd_cost_sgm_ng_batch_host.argtypes = [C.c_int32, C.POINTER(NgIn), C.POINTER(NgOut), C.c_int32]
+    lib.fsgm_calc_cost_sgm_ng_batch_host.argtypes = [C.c_int32, C.POINTER(OtfIn), C.POINTER(OtfOut), C.c_int32]
     lib.fsgm_sgm_ng_rand_draws.argtypes = [C.c_int32, C.c_int32]
     lib.fsgm_sgm_ng_rand_draws.restype = C.c_int64
     lib._ng_bound = True
@@ -102,3 +104,51 @@ def calc_cost_sgm_ng(I1, I2, preMv=None, halfSearchWinSize=1, aggSize=2, subPixe
     o.minC, o.flow = ptr(minC), ptr(flow)
     check(lib.fsgm_calc_cost_sgm_ng_host(C.byref(a), C.byref(o), int(device)))
     return minC, flow
+
+
+def calc_pyd_cost_sgm_ng_batch(frames, halfSearchWinSize, aggSize, subPixelRefine, P1, P2, *, device=0):
+    """frames: list of (I1, I2, preMv) of one shape; one launch sequence for all of them.
+    Returns a list of (minC, flow)."""
+    lib = _lib.load()
+    _bind(lib)
+    n = len(frames)
+    ins, outs, keep, res = (NgIn * n)(), (NgOut * n)(), [], []
+    for i, (I1, I2, preMv) in enumerate(frames):
+        I1, I2 = _images(I1, I2)
+        preMv = np.ascontiguousarray(preMv, np.float64)
+        if preMv.ndim != 3 or preMv.shape[0] != 2:
+            raise TypeError("preMv must be float64 of shape (2, mvHeight, mvWidth)")
+        H, W = I1.shape
+        a = ins[i]
+        a.I1, a.I2, a.width, a.height = ptr(I1), ptr(I2), W, H
+        a.preMv, a.mvWidth, a.mvHeight = ptr(preMv), preMv.shape[2], preMv.shape[1]
+        a.halfSearchWinSize, a.aggSize, a.subPixelRefine, a.P1, a.P2 = int(halfSearchWinSize), int(aggSize), int(subPixelRefine), int(P1), int(P2)
+        minC, flow = np.zeros((H, W), np.uint32), np.zeros((2, H, W), np.float64)
+        outs[i].minC, outs[i].flow, outs[i].S = ptr(minC), ptr(flow), None
+        keep.append((I1, I2, preMv))
+        res.append((minC, flow))
+    check(lib.fsgm_calc_pyd_cost_sgm_ng_batch_host(n, ins, outs, int(device)))
+    return res
+
+
+def calc_cost_sgm_ng_batch(frames, P1=6, P2=32, *, device=0):
+    """frames: list of (I1, I2, rand_stream) of one shape (rand_stream as for calc_cost_sgm_ng, not None:
+    frames of a batch run side by side, so there is no 'order of draws' between them).  Returns a list of (minC, flow)."""
+    lib = _lib.load()
+    _bind(lib)
+    n = len(frames)
+    ins, outs, keep, res = (OtfIn * n)(), (OtfOut * n)(), [], []
+    for i, (I1, I2, rand_stream) in enumerate(frames):
+        I1, I2 = _images(I1, I2)
+        H, W = I1.shape
+        rs = np.ascontiguousarray(rand_stream, np.int32)
+        if rs.size < sgm_ng_rand_draws(W, H):
+            raise ValueError("rand_stream too short")
+        a = ins[i]
+        a.I1, a.I2, a.width, a.height, a.P1, a.P2, a.rand_stream = ptr(I1), ptr(I2), W, H, int(P1), int(P2), ptr(rs)
+        minC, flow = np.zeros((H, W), np.uint32), np.zeros((2, H, W), np.float64)
+        outs[i].minC, outs[i].flow = ptr(minC), ptr(flow)
+        keep.append((I1, I2, rs))
+        res.append((minC, flow))
+    check(lib.fsgm_calc_cost_sgm_ng_batch_host(n, ins, outs, int(device)))
+    return res

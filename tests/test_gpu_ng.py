@@ -119,3 +119,29 @@ def test_calc_pyd_cost_sgm_ng_repeated_candidates(gpu_lib, oracle, monkeypatch, 
         np.testing.assert_array_equal(gS, S)
         np.testing.assert_array_equal(gmc, mc)
         np.testing.assert_array_equal(gfl, fl)
+
+
+def test_ng_batches_match_single_calls(gpu_lib, oracle):
+    """Frames of a batch share one launch sequence (three or more frames: one thread per (line, candidate), no
+    matcher split; the on-the-fly variant: one workgroup per frame): same results as the oracle frame by frame."""
+    from fsgm_amd import calc_pyd_cost_sgm_ng_batch, calc_cost_sgm_ng_batch
+    W, H = 52, 31
+    frames, want = [], []
+    for i in range(3):
+        I1, I2 = synth.image_pair(W, H, 16, seed=20 + i)
+        mv = synth.hint_map(W, H, ("int", "zero", "general")[i], seed=30 + i, amp=2.0)
+        frames.append((I1, I2, mv))
+        want.append(oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 1, 6, 32))
+    for (gmc, gfl), (mc, fl) in zip(calc_pyd_cost_sgm_ng_batch(frames, 1, 2, 1, 6, 32), want):
+        np.testing.assert_array_equal(gmc, mc)
+        np.testing.assert_array_equal(gfl, fl)
+    W, H = 23, 14
+    frames, want = [], []
+    for i in range(3):
+        I1, I2 = synth.image_pair(W, H, 16, seed=40 + i)
+        rs = oracle.glibc_rand_stream(oracle.sgm_ng_rand_draws(W, H), seed=7 + i)
+        frames.append((I1, I2, rs))
+        want.append(oracle.calc_cost_sgm_ng(I1, I2, 6, 32, rs))
+    for (gmc, gfl), (mc, fl) in zip(calc_cost_sgm_ng_batch(frames, 6, 32), want):
+        np.testing.assert_array_equal(gmc, mc)
+        np.testing.assert_array_equal(gfl, fl)
