@@ -123,3 +123,19 @@ def test_pyramidal_loop_with_the_neighbour_guided_matcher(gpu_lib, oracle, W, H,
         np.testing.assert_array_equal(got, w)
     np.testing.assert_array_equal(minC, mc)
     np.testing.assert_array_equal(flow, want[-1])
+
+
+def test_pyramidal_loop_ng_with_a_wider_search(gpu_lib, oracle):
+    """halfSearchWinSize = 2: 225 candidates per pixel, the generic aggregation kernel (no repeat removal), P2 = 64."""
+    from fsgm_amd import pyramidal_sgm_ng
+    W, H = 29, 22
+    I0, I1 = synth.image_pair(W, H, 8, seed=3)
+    flow, flows, minC = pyramidal_sgm_ng(I0, I1, 2, halfSearchWinSize=2, aggSize=3, P2=64)
+    g = [(I0, I1), (oracle.impyramid_reduce(I0), oracle.impyramid_reduce(I1))]
+    mvPre = np.zeros((2,) + g[1][0].shape)
+    for l in (2, 1):
+        mc, fl = oracle.calc_pyd_cost_sgm_ng(g[l - 1][0], g[l - 1][1], mvPre, 2, 3, 0, 6, 64)
+        np.testing.assert_array_equal(flows[2 - l], fl)
+        mvPre = np.ascontiguousarray(2.0 * np.repeat(np.repeat(fl, 2, axis=1), 2, axis=2))
+    np.testing.assert_array_equal(minC, mc)
+    np.testing.assert_array_equal(flow, fl)
