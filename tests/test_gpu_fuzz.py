@@ -74,7 +74,7 @@ def test_pyd_random_configs(gpu_lib, oracle, seed):
     np.testing.assert_array_equal(gms, ms, err_msg=msg)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(16))
 def test_ng_random_configs(gpu_lib, oracle, seed):
     r = _rng(200 + seed)
     W, H = int(r.randint(1, 40)), int(r.randint(1, 30))
@@ -82,10 +82,11 @@ def test_ng_random_configs(gpu_lib, oracle, seed):
     P1, P2 = (6, 32) if r.rand() < 0.5 else (int(r.randint(0, 256)), int(r.randint(0, 256)))
     half, agg, sub = int(r.choice([0, 1, 1, 2])), int(r.randint(0, 6)), int(r.rand() < 0.5)
     I1, I2 = synth.image_pair(W, H, 16, seed=seed + 50)
-    mv = synth.hint_map(mvW, mvH, "general", seed=seed, amp=6.0)
+    kind, amp = str(r.choice(["zero", "even", "int", "general"])), float(r.choice([0.7, 2.0, 6.0]))   # few to many repeated candidates
+    mv = synth.hint_map(mvW, mvH, kind, seed=seed, amp=amp)
     mc, fl, _, S = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, half, agg, sub, P1, P2, want_volumes=True)
     gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv, half, agg, sub, P1, P2, return_sum=True)
-    msg = f"seed {seed} W{W} H{H} mv{mvW}x{mvH} half{half} agg{agg} P{P1},{P2}"
+    msg = f"seed {seed} W{W} H{H} mv{mvW}x{mvH} half{half} agg{agg} P{P1},{P2} {kind} amp{amp}"
     np.testing.assert_array_equal(gS, S, err_msg=msg)
     np.testing.assert_array_equal(gmc, mc, err_msg=msg)
     np.testing.assert_array_equal(gfl, fl, err_msg=msg)
