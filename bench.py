@@ -22,9 +22,21 @@ sys.path.insert(0, ROOT)
 W, H, D, PATHS = 1242, 375, 128, 8
 P1, P2, VMAX = 6, 64, 0.3
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM/fabric bytes per voxel of the sweep pipeline from rocprofv3 PMC passes (FETCH_SIZE doubled as
-# MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, + WRITE_SIZE), profiles/r01_pmc_traffic.md
-TRAFFIC_BYTES_PER_VOXEL = 9.65
+# HBM/fabric bytes per voxel of the aggregation stage come from the newest rocprofv3 PMC summary under profiles/
+# (tools/pmc_traffic.sh: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950,
+# + WRITE_SIZE; separate passes).  The summary names the kernels it measured; a summary whose kernel set is not the
+# one this build launches is not used (traffic = null).
+TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+
+def measured_traffic(kernel_name, paths):
+    try:
+        t = json.load(open(TRAFFIC_SUMMARY))
+        if t.get("pipeline") != kernel_name or t.get("paths") != paths:
+            return None, None
+        return float(t["bytes_per_voxel"]), os.path.relpath(TRAFFIC_SUMMARY, ROOT)
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(sample_rows=48, PATHS=PATHS):
@@ -227,9 +239,15 @@ def main():
     # distinct volume per (rank, frame): 4 seeded base volumes per rank, the others are column
     # rotations of them (cheap to make, still all different)
     bases = [synth.cost_volume(W, H, D, seed=1000 * rank + s, cmax=24) for s in range(min(4, B))]
+
+    def frame_volume(f):
+        return bases[f] if f < 4 else np.ascontiguousarray(np.roll(bases[f % 4], 37 * (f // 4), axis=1))
+
     for f in range(B):
-        plan.upload_cost(f, bases[f] if f < 4 else np.ascontiguousarray(np.roll(bases[f % 4], 37 * (f // 4), axis=1)))
+        plan.upload_cost(f, frame_volume(f))
         plan.upload_offset(f, off)
+    check_frames = sorted({0, B - 1})
+    check_vols = [frame_volume(f) for f in check_frames]
     del bases
     stages = STAGE_AGGREGATE | STAGE_WTA
 
@@ -251,6 +269,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # self-check of what the timed loop left behind: two frames of the timed plan against the per-direction line
+    # kernels (agg mode 1: a different implementation of the same recurrence, itself checked against the oracle
+    # in tests/) on a second plan holding the same volumes
+    got = [plan.download(f) for f in check_frames]
+    with EpiPlan(W, H, D, len(check_frames), paths=PATHS, device=local_rank) as ref:
+        ref.set_penalties(P1, P2, VMAX)
+        ref.set_agg_mode(1)
+        for i, v in enumerate(check_vols):
+            ref.upload_cost(i, v)
+            ref.upload_offset(i, off)
+        ref.run(stages)
+        checked = all(np.array_equal(got[i][0], r[0]) and np.array_equal(got[i][1], r[1])
+                      for i, r in enumerate(ref.download(i) for i in range(len(check_frames))))
+        ref_kernel = ref.kernel_name
+    del check_vols
+    assert checked, "the timed pipeline's bestD/minC differ from the line kernels' on the same volumes"
+
     # stage timing with HIP events on the plan's own stream (the forked streams join it before the
     # second event), rank 0 reports
     agg_ms = plan.time(STAGE_AGGREGATE, warmup=1, iters=max(3, args.steps // 2))
@@ -261,6 +296,7 @@ def main():
         value = voxel_paths_step * args.steps / dt
         alg_bytes_launch = B * W * H * D * PATHS            # 1 byte of C per voxel-path
         achieved = alg_bytes_launch / (agg_ms * 1e-3) / 1e9
+        bpv, traffic_src = measured_traffic(plan.kernel_name, PATHS)
         out = {
             "metric": f"aggregated cost-volume voxel-paths/s (HxWxDx{PATHS} paths), KITTI 1242x375 D=128",
             "value": value, "unit": "voxel-paths/s", "n_gpus": world, "steps": args.steps,
@@ -276,14 +312,21 @@ def main():
             "roofline": {"bound": "hbm", "kernel": ("aggregation stage: sweep_kernel<8,0> + sweep_kernel<8,2> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>"
                                                      if PATHS == 8 else "aggregation stage: pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + pair_ckpt_kernel<8,1> + pair_sum_kernel<8,1,true>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES_PER_VOXEL * B * W * H * D if plan.kernel_name.startswith("sweep") else None,   # measured for the 8-path pipeline only
+                         "traffic": bpv * B * W * H * D if bpv else None, "traffic_source": traffic_src,
                          "algorithmic_bytes": alg_bytes_launch, "stage_ms": agg_ms, "finish_ms": wta_ms},
+            "checked": bool(checked),
+            "check": f"frames {check_frames} of the timed plan == line kernels ({ref_kernel}) on the same volumes, bestD and minC, all pixels",
         }
         try:
             import ctypes as C
             g = C.c_double()
-            fsgm_amd._lib.check(plan.lib.fsgm_measure_copy_bandwidth(local_rank, 1 << 30, 5, C.byref(g)))
+            # the achievable rate on this device: the library's own 16 B-per-lane copy kernel (read + written bytes)
+            fsgm_amd._lib.check(plan.lib.fsgm_measure_copy_bandwidth2(local_rank, 1 << 30, 10, 0, C.byref(g)))
             out["roofline"]["copy_GBps_measured"] = g.value
+            out["roofline"]["copy_kernel"] = "copy16_kernel (16 B per lane), 1 GiB"
+            out["roofline"]["frac_of_copy"] = achieved / g.value
+            fsgm_amd._lib.check(plan.lib.fsgm_measure_copy_bandwidth2(local_rank, 1 << 30, 10, 1, C.byref(g)))
+            out["roofline"]["memcpy_d2d_GBps_measured"] = g.value
         except Exception as e:                                # pragma: no cover
             out["roofline"]["copy_GBps_measured"] = None
         if world == 1:

@@ -71,12 +71,15 @@ def load():
     lib.fsgm_epi_plan_download_cost.argtypes = [vp, i32, vp]
     lib.fsgm_epi_plan_download_fb.argtypes = [vp, i32, vp, vp]
     lib.fsgm_epi_plan_download_sum.argtypes = [vp, i32, vp]
+    lib.fsgm_epi_plan_download_census.argtypes = [vp, i32, vp, vp]
+    lib.fsgm_census_host.argtypes = [vp, i32, i32, vp, i32]
     lib.fsgm_epi_plan_time.argtypes = [vp, i32, i32, i32, f32p]
     lib.fsgm_epi_plan_stream.argtypes = [vp]
     lib.fsgm_epi_plan_stream.restype = vp
     lib.fsgm_epi_plan_kernel_name.argtypes = [vp]
     lib.fsgm_epi_plan_kernel_name.restype = C.c_char_p
     lib.fsgm_measure_copy_bandwidth.argtypes = [i32, C.c_size_t, i32, C.POINTER(C.c_double)]
+    lib.fsgm_measure_copy_bandwidth2.argtypes = [i32, C.c_size_t, i32, i32, C.POINTER(C.c_double)]
     _lib = lib
     return lib
 

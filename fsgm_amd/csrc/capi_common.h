@@ -29,4 +29,18 @@ inline fsgm_status fail(fsgm_status st, const char* fmt, ...) {
         if (!(cond)) return ::fsgm::fail(FSGM_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// Scope guard for host-pointer entry points: work queued on `st` may still read the caller's input
+// buffers or write its output buffers (async copies), so every exit that is not the normal one
+// (which has synchronised already and calls dismiss()) drains the stream before the caller gets
+// control back.
+struct StreamGuard {
+    hipStream_t st;
+    bool armed = true;
+    explicit StreamGuard(hipStream_t s) : st(s) {}
+    void dismiss() { armed = false; }
+    ~StreamGuard() { if (armed) (void)hipStreamSynchronize(st); }
+    StreamGuard(const StreamGuard&) = delete;
+    StreamGuard& operator=(const StreamGuard&) = delete;
+};
+
 }  // namespace fsgm

@@ -83,6 +83,47 @@ static void select_kernel(fsgm_epi_plan* p) {
     if (nowrap && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
 }
 
+// Lazily allocated buffer sets of the two fused pipelines.  Everything is created into locals and committed to
+// the plan only when the whole set exists, so a failure midway leaves the plan as it was (nothing leaked,
+// nothing half-initialised for the next call to trip over).
+namespace {
+struct LazySet {
+    std::vector<void*> bufs;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> events;
+    hipError_t err = hipSuccess;
+    template <class T> void alloc(T** p, size_t bytes) {
+        *p = nullptr;
+        if (err != hipSuccess) return;
+        void* v = nullptr;
+        err = hipMalloc(&v, bytes ? bytes : 1);
+        if (err == hipSuccess) { bufs.push_back(v); *p = (T*)v; }
+    }
+    void stream(hipStream_t* s) {
+        *s = nullptr;
+        if (err != hipSuccess) return;
+        err = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        if (err == hipSuccess) streams.push_back(*s);
+    }
+    void event(hipEvent_t* e) {
+        *e = nullptr;
+        if (err != hipSuccess) return;
+        err = hipEventCreateWithFlags(e, hipEventDisableTiming);
+        if (err == hipSuccess) events.push_back(*e);
+    }
+    void rollback() {
+        for (void* b : bufs) (void)hipFree(b);
+        for (hipStream_t s : streams) (void)hipStreamDestroy(s);
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+};
+fsgm_status lazy_fail(LazySet& ls, const char* what) {
+    const hipError_t e = ls.err;
+    ls.rollback();
+    return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+}  // namespace
+
 extern "C" {
 
 const char* fsgm_last_error(void) { return last_error_buf(); }
@@ -224,6 +265,7 @@ fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* p, int32_t f, const uint8_t* I1,
     FSGM_REQUIRE(I1 && I2 && pd0 && nd && off, "fsgm_epi_plan_upload: null input");
     FSGM_HIP(hipSetDevice(p->prm.device));
     const size_t NP = p->NP;
+    StreamGuard guard(p->stream);
     FSGM_HIP(hipMemcpyAsync(p->dI1 + f * NP, I1, NP, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(p->dI2 + f * NP, I2, NP, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(p->dPd0 + f * 2 * NP, pd0, NP * 16, hipMemcpyHostToDevice, p->stream));
@@ -258,49 +300,71 @@ fsgm_status fsgm_epi_plan_upload_offset(fsgm_epi_plan* p, int32_t f, const doubl
 static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
     if (p->dCkptV) return FSGM_OK;
     const size_t B = p->batch;
+    LazySet ls;
+    uint8_t *lh, *ck, *ckv; uint4* rec; uint16_t* s0; hipStream_t sh; hipEvent_t ef, eh;
+    ls.alloc(&lh, B * p->N);
+    ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
+    ls.alloc(&ckv, B * pair_ckpt_bytes(p->W, p->H, p->D, 1));
+    ls.alloc(&rec, B * p->NP * sizeof(uint4));
+    ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
+    ls.stream(&sh);
+    ls.event(&ef);
+    ls.event(&eh);
+    if (ls.err != hipSuccess) return lazy_fail(ls, "pair pipeline buffers");
     p->lh_planes = 1;
-    FSGM_HIP(hipMalloc((void**)&p->dLh, B * p->N));
-    FSGM_HIP(hipMalloc((void**)&p->dCkpt, B * pair_ckpt_bytes(p->W, p->H, p->D, 0)));
-    FSGM_HIP(hipMalloc((void**)&p->dRec, B * p->NP * sizeof(uint4)));
-    FSGM_HIP(hipMalloc((void**)&p->dS0, B * p->NP * sizeof(uint16_t)));
-    FSGM_HIP(hipStreamCreateWithFlags(&p->stream_h, hipStreamNonBlocking));
-    FSGM_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-    FSGM_HIP(hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming));
-    FSGM_HIP(hipMalloc((void**)&p->dCkptV, B * pair_ckpt_bytes(p->W, p->H, p->D, 1)));   // last: marks the set complete
+    p->dLh = lh; p->dCkpt = ck; p->dCkptV = ckv; p->dRec = rec; p->dS0 = s0;
+    p->stream_h = sh; p->ev_fork = ef; p->ev_h = eh;
     return FSGM_OK;
 }
 
 static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     if (p->dX) return FSGM_OK;
     const size_t B = p->batch;
-    p->state_stride = sweep_state_bytes(p->W, p->D);
+    const size_t state_stride = sweep_state_bytes(p->W, p->D);
     // FSGM_EPI_HPAIR: 1 = horizontal pair as one excess sum by checkpoint-and-recompute (default),
     // 0 = the two path volumes of the per-direction kernel (A/B switch)
-    { const char* e = getenv("FSGM_EPI_HPAIR"); p->lh_planes = (e && *e && atoi(e) == 0) ? 2 : 1; }
-    FSGM_HIP(hipMalloc((void**)&p->dLh, B * p->N * p->lh_planes));
-    if (p->lh_planes == 1) FSGM_HIP(hipMalloc((void**)&p->dCkpt, B * pair_ckpt_bytes(p->W, p->H, p->D, 0)));
-    FSGM_HIP(hipMalloc((void**)&p->dState, 2 * B * p->state_stride));
-    FSGM_HIP(hipMalloc((void**)&p->dRec, B * p->NP * sizeof(uint4)));
-    FSGM_HIP(hipMalloc((void**)&p->dS0, B * p->NP * sizeof(uint16_t)));
-    FSGM_HIP(hipStreamCreateWithFlags(&p->stream_h, hipStreamNonBlocking));
-    FSGM_HIP(hipStreamCreateWithFlags(&p->stream_b, hipStreamNonBlocking));
-    FSGM_HIP(hipStreamCreateWithFlags(&p->stream_c, hipStreamNonBlocking));
-    FSGM_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-    FSGM_HIP(hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming));
-    FSGM_HIP(hipEventCreateWithFlags(&p->ev_b, hipEventDisableTiming));
-    FSGM_HIP(hipEventCreateWithFlags(&p->ev_c, hipEventDisableTiming));
+    int planes;
+    { const char* e = getenv("FSGM_EPI_HPAIR"); planes = (e && *e && atoi(e) == 0) ? 2 : 1; }
+    LazySet ls;
+    uint8_t *lh, *ck = nullptr, *state, *x; uint4* rec; uint16_t* s0;
+    hipStream_t sh, sb, sc; hipEvent_t ef, eh, eb, ec;
+    ls.alloc(&lh, B * p->N * planes);
+    if (planes == 1) ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
+    ls.alloc(&state, 2 * B * state_stride);
+    ls.alloc(&rec, B * p->NP * sizeof(uint4));
+    ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
+    ls.alloc(&x, B * p->N);
+    ls.stream(&sh); ls.stream(&sb); ls.stream(&sc);
+    ls.event(&ef); ls.event(&eh); ls.event(&eb); ls.event(&ec);
+    if (ls.err != hipSuccess) return lazy_fail(ls, "sweep pipeline buffers");
+    p->state_stride = state_stride;
+    p->lh_planes = planes;
+    p->dLh = lh; p->dCkpt = ck; p->dState = state; p->dRec = rec; p->dS0 = s0; p->dX = x;
+    p->stream_h = sh; p->stream_b = sb; p->stream_c = sc;
+    p->ev_fork = ef; p->ev_h = eh; p->ev_b = eb; p->ev_c = ec;
     { const char* e = getenv("FSGM_EPI_LANES"); const int v = (e && *e) ? atoi(e) : 2; p->lanes = v < 1 ? 1 : (v > 3 ? 3 : v); }
-    FSGM_HIP(hipMalloc((void**)&p->dX, B * p->N));           // last: marks the set complete
+    return FSGM_OK;
+}
+
+// What a run of `stages` needs before anything is queued: the cost stage rewrites C with census costs
+// (values <= 24), so the bound of the cost values -- and with it the kernel selection -- is settled first;
+// then the buffer set of the selected pipeline.
+static fsgm_status prepare(fsgm_epi_plan* p, int stages) {
+    if (stages & FSGM_STAGE_COST) {
+        bool changed = false;
+        for (int& c : p->cmax) { if (c != 24) changed = true; c = 24; }
+        if (changed) select_kernel(p);
+    }
+    if (stages & (FSGM_STAGE_AGGREGATE | FSGM_STAGE_WTA)) {
+        if (p->kernel_kind == AGG_SWEEP) return ensure_sweep_buffers(p);
+        if (p->kernel_kind == AGG_PAIRS) return ensure_pairs_buffers(p);
+    }
     return FSGM_OK;
 }
 
 static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
-    if (p->kernel_kind == AGG_SWEEP && (stages & (FSGM_STAGE_AGGREGATE | FSGM_STAGE_WTA))) {
-        fsgm_status st = ensure_sweep_buffers(p);
-        if (st != FSGM_OK) return st;
-    }
-    if (p->kernel_kind == AGG_PAIRS && (stages & (FSGM_STAGE_AGGREGATE | FSGM_STAGE_WTA))) {
-        fsgm_status st = ensure_pairs_buffers(p);
+    {
+        fsgm_status st = prepare(p, stages);
         if (st != FSGM_OK) return st;
     }
     if (stages & FSGM_STAGE_COST) {
@@ -312,9 +376,6 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         a.cen1 = p->dCen1; a.cen2 = p->dCen2; a.pd0 = p->dPd0; a.nd = p->dNd; a.off = p->dOff;
         a.vz = p->dVz; a.vzmax = p->vzmax; a.Craw = p->dCraw; a.W = p->W; a.H = p->H; a.D = p->D;
         launch_epi_cost(p->stream, a, p->dC, p->batch);
-        bool changed = false;
-        for (int& c : p->cmax) { if (c != 24) changed = true; c = 24; }
-        if (changed) select_kernel(p);
     }
     if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_SWEEP) {
         // One sweep launch (strips x frames workgroups) cannot fill 256 CUs, so the work is forked:
@@ -425,10 +486,10 @@ static int env_graph() {
 }
 
 static fsgm_status run_stages(fsgm_epi_plan* p, int stages) {
+    fsgm_status st = prepare(p, stages);                         // kernel selection and allocations: before the graph decision, outside any capture
+    if (st != FSGM_OK) return st;
     const bool graphable = p->kernel_kind == AGG_SWEEP && !(stages & FSGM_STAGE_COST) && !p->prm.fb_check && env_graph() != 0;
     if (!graphable) return enqueue(p, stages);
-    fsgm_status st = ensure_sweep_buffers(p);                    // allocations stay outside the capture
-    if (st != FSGM_OK) return st;
     fsgm_epi_plan::GraphSlot& g = p->graphs[stages & 7];
     if (!g.exec || g.epoch != p->epoch) {
         if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
@@ -496,6 +557,16 @@ fsgm_status fsgm_epi_plan_download_cost(fsgm_epi_plan* p, int32_t f, uint8_t* C)
     FSGM_HIP(hipSetDevice(p->prm.device));
     FSGM_HIP(hipStreamSynchronize(p->stream));
     FSGM_HIP(hipMemcpy(C, p->dC + f * p->N, p->N, hipMemcpyDeviceToHost));
+    return FSGM_OK;
+}
+
+fsgm_status fsgm_epi_plan_download_census(fsgm_epi_plan* p, int32_t f, uint32_t* cen1, uint32_t* cen2) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    if (cen1) FSGM_HIP(hipMemcpy(cen1, p->dCen1 + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
+    if (cen2) FSGM_HIP(hipMemcpy(cen2, p->dCen2 + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
     return FSGM_OK;
 }
 
@@ -605,20 +676,30 @@ const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* p) {
     }
 }
 
-fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps) {
-    FSGM_REQUIRE(gbps && bytes > 0 && iters > 0, "fsgm_measure_copy_bandwidth: bad argument");
+// The achievable HBM rate of this device, measured the way the aggregation kernels move bytes: a grid-stride
+// copy kernel, 16 B per lane per access (launch_copy16, epi_kernels.hip), device memory to device memory, read + written
+// bytes counted.  mode 0: that kernel; mode 1: hipMemcpyAsync D2D (the runtime's blit kernel), for comparison.
+fsgm_status fsgm_measure_copy_bandwidth2(int32_t device, size_t bytes, int32_t iters, int32_t mode, double* gbps) {
+    FSGM_REQUIRE(gbps && bytes >= 4096 && iters > 0, "fsgm_measure_copy_bandwidth: bad argument");
+    FSGM_REQUIRE(mode == 0 || mode == 1, "fsgm_measure_copy_bandwidth: mode must be 0 (copy kernel) or 1 (hipMemcpyAsync)");
     FSGM_HIP(hipSetDevice(device));
+    bytes &= ~(size_t)4095;
     void *a = nullptr, *b = nullptr;
     hipEvent_t e0, e1;
     FSGM_HIP(hipMalloc(&a, bytes));
     if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); return fail(FSGM_ERR_NOMEM, "copy probe: out of memory"); }
     (void)hipMemset(a, 1, bytes);
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
+    auto once = [&]() {
+        if (mode == 0) launch_copy16(0, b, a, bytes);
+        else (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
+    };
+    once();
     (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; i++) (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
+    for (int i = 0; i < iters; i++) once();
     (void)hipEventRecord(e1, 0);
     hipError_t e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipGetLastError();
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -626,6 +707,10 @@ fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t it
     if (e != hipSuccess) return fail(FSGM_ERR_HIP, "copy probe: %s", hipGetErrorString(e));
     *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
     return FSGM_OK;
+}
+
+fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps) {
+    return fsgm_measure_copy_bandwidth2(device, bytes, iters, 0, gbps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -639,6 +724,8 @@ static fsgm_status cached_plan(fsgm_epi_plan** out, int W, int H, int D, int bat
     for (fsgm_epi_plan* p : g_cache)
         if (p->W == W && p->H == H && p->D == D && p->batch == batch && p->prm.paths == pr.paths &&
             p->prm.device == pr.device && p->prm.fb_check == pr.fb_check) {
+            // subpixel / vz_to_disp are baked into kernel arguments: a captured graph of the old settings must go
+            if (p->prm.subpixel != pr.subpixel || p->prm.vz_to_disp != pr.vz_to_disp) p->epoch++;
             p->prm = pr;
             *out = p;
             return FSGM_OK;
@@ -707,6 +794,27 @@ fsgm_status fsgm_calc_cost_sgm_host(const fsgm_epi_in* in, const fsgm_epi_out* o
     return fsgm_calc_cost_sgm_batch_host(1, in, out, prm);
 }
 
+// census() of common.cpp:3-27 alone (the one function of the path that the reference's own sources pin here)
+fsgm_status fsgm_census_host(const uint8_t* img, int32_t W, int32_t H, uint32_t* cen, int32_t device) {
+    FSGM_REQUIRE(img && cen, "fsgm_census: null argument");
+    FSGM_REQUIRE(W >= 1 && H >= 1, "width/height must be >= 1 (got %d x %d)", W, H);
+    fsgm_epi_params pr = fsgm_epi_params_default();
+    pr.device = device;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    fsgm_epi_plan* p = nullptr;
+    fsgm_status st = cached_plan(&p, W, H, 16, 1, pr);           // any dMax: only the image / census buffers are used
+    if (st != FSGM_OK) return st;
+    FSGM_HIP(hipSetDevice(device));
+    StreamGuard guard(p->stream);
+    FSGM_HIP(hipMemcpyAsync(p->dI1, img, p->NP, hipMemcpyHostToDevice, p->stream));
+    launch_census(p->stream, p->dI1, p->dCen1, W, H, 1);
+    FSGM_HIP(hipGetLastError());
+    FSGM_HIP(hipMemcpyAsync(cen, p->dCen1, p->NP * 4, hipMemcpyDeviceToHost, p->stream));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
+    return FSGM_OK;
+}
+
 // ---- the dense half of the epipolar driver (dense part only) ----
 static EpiGeomArgs geom_args(const fsgm_epi_geometry* g, int W, int H, double* Pd0, double* nd, double* off, double* rflow) {
     EpiGeomArgs a;
@@ -735,6 +843,7 @@ fsgm_status fsgm_epipolar_maps_host(const fsgm_epi_geometry* g, int32_t W, int32
     if (st != FSGM_OK) return st;
     FSGM_HIP(hipSetDevice(device));
     if ((st = ensure_driver_buffers(p, 1)) != FSGM_OK) return st;
+    StreamGuard guard(p->stream);
     launch_epi_maps(p->stream, geom_args(g, W, H, p->dPd0, p->dNd, p->dOff, p->dRflow));
     FSGM_HIP(hipGetLastError());
     FSGM_HIP(hipMemcpyAsync(Pd0, p->dPd0, p->NP * 16, hipMemcpyDeviceToHost, p->stream));
@@ -761,6 +870,7 @@ fsgm_status fsgm_epipolar_sgm_of_host(const uint8_t* I0, const uint8_t* I1, int3
     if ((st = fsgm_epi_plan_set_penalties(p, 6, 64, vMax)) != FSGM_OK) return st;        // epipolar_sgm_of.m:19
     if ((st = ensure_driver_buffers(p, channels)) != FSGM_OK) return st;
     const size_t NP = p->NP;
+    StreamGuard guard(p->stream);
     if (channels == 3) {                                                                 // epipolar_sgm_of.m:35-38
         FSGM_HIP(hipMemcpyAsync(p->dRgb, I0, 3 * NP, hipMemcpyHostToDevice, p->stream));
         FSGM_HIP(hipMemcpyAsync(p->dRgb + 3 * NP, I1, 3 * NP, hipMemcpyHostToDevice, p->stream));

@@ -28,6 +28,10 @@ struct DevBufs {                       // the arena for the duration of one call
     std::unique_lock<std::mutex> lk{g_pool.mu};
     std::vector<std::pair<void**, size_t>> req;
     hipStream_t stream = nullptr;
+    // Every exit drains the arena's stream before the pool mutex (declared first, released last) lets the next
+    // call re-carve the arena or the caller frees its buffers: an early error return may leave copies from the
+    // caller's memory and kernels queued.  On the normal path the stream is already idle.
+    ~DevBufs() { if (stream) (void)hipStreamSynchronize(stream); }
     void want(void** p, size_t bytes) { req.emplace_back(p, (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255); }
     hipError_t commit(int device) {
         size_t total = 0;

@@ -9,6 +9,7 @@
 //
 // No MFMA anywhere: this is integer stencil / scan work bound by HBM and VALU issue.
 #include "epi_kernels.h"
+#include <algorithm>
 #include "fsgm_device.h"
 #include "epi_wta_tail.h"
 
@@ -719,6 +720,23 @@ void launch_epi_cost(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frame
     } else {
         hipLaunchKernelGGL(box5x5_kernel, grid, dim3(256), 0, st, (const uint8_t*)a.Craw, C, a.W, a.H, a.D);
     }
+}
+
+// Bandwidth probe: grid-stride copy, 16 B per lane per access, 4 accesses in flight per lane.
+__global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+void launch_copy16(hipStream_t st, void* dst, const void* src, size_t bytes) {
+    const size_t n16 = bytes / 16;
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 256 * 4 - 1) / (256 * 4), 256 * 16);
+    hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, st, (uint4*)dst, (const uint4*)src, n16);
 }
 
 int agg_packed_lpp(int D) {

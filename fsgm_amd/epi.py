@@ -82,6 +82,16 @@ def calc_cost_sgm(I1, I2, dMax, vMax, pixelPosD0, normlizeDirection, offsetFromP
                                return_volumes=return_volumes, fb_check=fb_check)[0]
 
 
+def census(img, *, device=0):
+    """census(img) of common.cpp:3-27 on the device: (height, width) uint8 -> uint32 codes."""
+    lib = _lib.load()
+    img = _u8img(img, "img")
+    H, W = img.shape
+    cen = np.empty((H, W), np.uint32)
+    check(lib.fsgm_census_host(ptr(img), W, H, ptr(cen), int(device)))
+    return cen
+
+
 class EpiPlan:
     """Device-resident plan: `batch` frames of width x height x dMax stay in HBM across calls."""
 
@@ -156,6 +166,13 @@ class EpiPlan:
         Cv = np.empty((self.H, self.W, self.D), np.uint8)
         check(self.lib.fsgm_epi_plan_download_cost(self._h, frame, ptr(Cv)))
         return Cv
+
+    def download_census(self, frame):
+        """(cen1, cen2): the census codes FSGM_STAGE_COST computed for the two images (debug tap)."""
+        c1 = np.empty((self.H, self.W), np.uint32)
+        c2 = np.empty((self.H, self.W), np.uint32)
+        check(self.lib.fsgm_epi_plan_download_census(self._h, frame, ptr(c1), ptr(c2)))
+        return c1, c2
 
     def download_sum(self, frame):
         S = np.empty((self.H, self.W, self.D), np.uint32)

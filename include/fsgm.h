@@ -131,6 +131,9 @@ fsgm_status fsgm_epi_plan_download(fsgm_epi_plan* plan, int32_t frame, uint32_t*
 fsgm_status fsgm_epi_plan_download_fb(fsgm_epi_plan* plan, int32_t frame, uint8_t* conf, uint32_t* bestD2);
 fsgm_status fsgm_epi_plan_download_cost(fsgm_epi_plan* plan, int32_t frame, uint8_t* C);
 fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* plan, int32_t frame, uint32_t* S);
+/* debug tap: the census codes of the two images as FSGM_STAGE_COST left them (common.cpp:3-27; u32 [H][W],
+ * the reference's bit order: first tap at bit 25, bit 0 always 0); either pointer may be NULL */
+fsgm_status fsgm_epi_plan_download_census(fsgm_epi_plan* plan, int32_t frame, uint32_t* cen1, uint32_t* cen2);
 /* Average milliseconds of one fsgm_epi_plan_run(stages) over `iters` back-to-back runs after
  * `warmup` untimed ones, measured with HIP events on the stream the kernels run on. */
 fsgm_status fsgm_epi_plan_time(fsgm_epi_plan* plan, int32_t stages, int32_t warmup,
@@ -139,8 +142,15 @@ fsgm_status fsgm_epi_plan_time(fsgm_epi_plan* plan, int32_t stages, int32_t warm
 void*       fsgm_epi_plan_stream(fsgm_epi_plan* plan);
 /* which aggregation kernel the plan selected: "sweep16/nowrap", "pairs16/nowrap", "packed16/nowrap", "packed16/wrap", "generic" */
 const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* plan);
-/* device-to-device copy bandwidth probe (GB/s, read+write bytes counted) used by bench.py */
+/* device-to-device copy bandwidth probe (GB/s, read+written bytes counted) used by bench.py: the library's own
+ * grid-stride copy kernel, 16 B per lane per access -- the access width of the aggregation kernels */
 fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps);
+/* mode 0: the same; mode 1: hipMemcpyAsync device-to-device (the runtime's blit kernel), for comparison */
+fsgm_status fsgm_measure_copy_bandwidth2(int32_t device, size_t bytes, int32_t iters, int32_t mode, double* gbps);
+
+/* census(img, cen, width, height) of common.cpp:3-27 on its own: u8 [H][W] -> u32 [H][W], 5x5 window, replicate
+ * border, `neighbour >= centre`, first tap at bit 25, trailing shift (bit 0 = 0).  Any width/height >= 1. */
+fsgm_status fsgm_census_host(const uint8_t* img, int32_t width, int32_t height, uint32_t* cen, int32_t device);
 
 /* ------------------------------------------------------------------------------------------
  * epipolar_sgm_of with the dense maps made on the device  (dense half only)

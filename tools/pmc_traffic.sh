@@ -23,5 +23,23 @@ print("kernel | dispatches | FETCH_SIZE/dispatch MiB (raw) | x2 | WRITE_SIZE/dis
 for k in sorted(set(fa) | set(wa)):
     n = fc.get(k, wc.get(k, 1))
     print(f"{k} | {n} | {fa.get(k,0)/n/1024:.1f} | {2*fa.get(k,0)/n/1024:.1f} | {wa.get(k,0)/max(wc.get(k,1),1)/1024:.1f}")
+# machine-readable summary for bench.py (roofline.traffic): bytes per voxel of the aggregation stage's kernels
+import json, re
+line = [l for l in open("gpurun_out/pmc_f.log") if l.startswith("{")][-1]
+b = json.loads(line)
+steps = b["steps"] + b["warmup"] + max(3, b["steps"] // 2) + 1      # timed loop + warm-up + plan.time(AGGREGATE) incl. its warm-up
+agg = [k for k in set(fa) | set(wa) if re.search(r"sweep_kernel|pair_(ckpt|sum)_kernel|fwd_kernel|bwd_kernel", k)]
+runs = {k: fc.get(k, wc.get(k, 0)) for k in agg}
+tot = sum(2 * fa.get(k, 0) + wa.get(k, 0) * fc.get(k, 1) / max(wc.get(k, 1), 1) for k in agg) * 1024
+vox = b["config"]["frames_per_gpu"] * 1242 * 375 * 128
+# every aggregation run launches each kernel the same number of times: runs of the stage = dispatches of the rarest kernel
+nruns = min(runs.values()) if runs else 0
+out = {"pipeline": b["config"]["kernel"], "paths": 8, "bytes_per_voxel": tot / max(nruns, 1) / vox, "stage_runs_profiled": nruns,
+       "kernels": {k: {"dispatches": runs[k], "fetch_MiB_x2_per_dispatch": 2 * fa.get(k, 0) / max(fc.get(k, 1), 1) / 1024,
+                       "write_MiB_per_dispatch": wa.get(k, 0) / max(wc.get(k, 1), 1) / 1024} for k in agg},
+       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md), summed over the aggregation stage's kernels, per stage run",
+       "command": "tools/pmc_traffic.sh"}
+json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("pipeline", "bytes_per_voxel", "stage_runs_profiled")}))
 PY
 rm -rf gpurun_out/pmc_f gpurun_out/pmc_w

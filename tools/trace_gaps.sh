@@ -12,7 +12,7 @@ print("columns:", list(rows[0].keys()))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:40], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")) for r in rows]
 ev.sort()
 # one step = from one hpair_ckpt start to the next one
-ck = [e[0] for e in ev if "hpair_ckpt" in e[2]]
+ck = [e[0] for e in ev if "pair_ckpt" in e[2]]
 lo, hi = ck[1], ck[2]
 step = [e for e in ev if e[0] >= lo and e[0] < hi]
 hi = max(e[1] for e in step)
