@@ -42,7 +42,6 @@ struct fsgm_epi_plan {
     // epipolar driver (fsgm_epipolar_sgm_of_host): rotation flow, composed flow, RGB staging
     double *dRflow = nullptr, *dFlow = nullptr;
     uint8_t* dRgb = nullptr;
-    int lh_planes = 1;                   // 1: horizontal pair as its excess sum X_h (pair kernels); 2: two path volumes
     uint4* dRec = nullptr;
     uint16_t* dS0 = nullptr;
     size_t state_stride = 0;
@@ -77,10 +76,12 @@ static void select_kernel(fsgm_epi_plan* p) {
     // 8 paths 4 frames 1.53 / 1.77, 6 frames 2.22 / 1.81; 4 paths 8 frames 1.26 / 1.41, 16 frames 2.47 / 1.85.
     const int min_batch = p->prm.paths == 8 ? 5 : 10;
     const bool want = p->agg_mode == 2 || (p->agg_mode == 0 && p->batch >= min_batch);
-    if (nowrap && 3 * p->P2 <= 255 && p->prm.paths == 8 && want) p->kernel_kind = AGG_SWEEP;
+    // (P1 <= P2: the fused kernels' form of the step clamps path states at P2 first, epi_sweep.hip)
+    const bool fusable = nowrap && p->P1 <= p->P2;
+    if (fusable && 3 * p->P2 <= 255 && p->prm.paths == 8 && want) p->kernel_kind = AGG_SWEEP;
     // the shipped 4-path configuration: both axes as pair kernels, the vertical one final (2*P2 <= 255:
     // the excess sum of a pair fits a byte)
-    if (nowrap && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
+    if (fusable && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
 }
 
 // Lazily allocated buffer sets of the two fused pipelines.  Everything is created into locals and committed to
@@ -311,7 +312,6 @@ static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
     ls.event(&ef);
     ls.event(&eh);
     if (ls.err != hipSuccess) return lazy_fail(ls, "pair pipeline buffers");
-    p->lh_planes = 1;
     p->dLh = lh; p->dCkpt = ck; p->dCkptV = ckv; p->dRec = rec; p->dS0 = s0;
     p->stream_h = sh; p->ev_fork = ef; p->ev_h = eh;
     return FSGM_OK;
@@ -321,15 +321,11 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     if (p->dX) return FSGM_OK;
     const size_t B = p->batch;
     const size_t state_stride = sweep_state_bytes(p->W, p->D);
-    // FSGM_EPI_HPAIR: 1 = horizontal pair as one excess sum by checkpoint-and-recompute (default),
-    // 0 = the two path volumes of the per-direction kernel (A/B switch)
-    int planes;
-    { const char* e = getenv("FSGM_EPI_HPAIR"); planes = (e && *e && atoi(e) == 0) ? 2 : 1; }
     LazySet ls;
     uint8_t *lh, *ck = nullptr, *state, *x; uint4* rec; uint16_t* s0;
     hipStream_t sh, sb, sc; hipEvent_t ef, eh, eb, ec;
-    ls.alloc(&lh, B * p->N * planes);
-    if (planes == 1) ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
+    ls.alloc(&lh, B * p->N);
+    ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
     ls.alloc(&state, 2 * B * state_stride);
     ls.alloc(&rec, B * p->NP * sizeof(uint4));
     ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
@@ -338,7 +334,6 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     ls.event(&ef); ls.event(&eh); ls.event(&eb); ls.event(&ec);
     if (ls.err != hipSuccess) return lazy_fail(ls, "sweep pipeline buffers");
     p->state_stride = state_stride;
-    p->lh_planes = planes;
     p->dLh = lh; p->dCkpt = ck; p->dState = state; p->dRec = rec; p->dS0 = s0; p->dX = x;
     p->stream_h = sh; p->stream_b = sb; p->stream_c = sc;
     p->ev_fork = ef; p->ev_h = eh; p->ev_b = eb; p->ev_c = ec;
@@ -387,18 +382,12 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         FSGM_HIP(hipEventRecord(p->ev_fork, p->stream));
         FSGM_HIP(hipStreamWaitEvent(p->stream_h, p->ev_fork, 0));
         for (int l = 1; l < NLN; l++) FSGM_HIP(hipStreamWaitEvent(lane_stream[l], p->ev_fork, 0));
-        if (p->lh_planes == 1) {                     // the two horizontal paths as one excess sum X_h
+        {                                            // the two horizontal paths as one sum Y_h
             PairArgs h{};
             h.C = p->dC; h.c_frame_stride = p->N; h.X = p->dLh; h.x_frame_stride = p->N;
             h.ckpt = p->dCkpt; h.ckpt_frame_stride = pair_ckpt_bytes(p->W, p->H, p->D, 0);
             h.W = p->W; h.H = p->H; h.D = p->D; h.P1 = p->P1; h.P2 = p->P2;
             launch_pair(p->stream_h, h, p->batch, 0, false);
-        } else {                                     // per-direction kernel, 2 slots
-            AggArgs a;
-            a.C = p->dC; a.L = p->dLh;
-            a.c_frame_stride = p->N; a.l_frame_stride = p->N * 2; a.l_dir_stride = p->N;
-            a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
-            launch_aggregate(p->stream_h, a, 2, p->batch, AGG_PACKED_NOWRAP);
         }
         FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
         for (int lane = 0, f0 = 0; lane < NLN; lane++) {
@@ -407,8 +396,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
             SweepArgs w;
             w.C = p->dC + (size_t)f0 * p->N; w.c_frame_stride = p->N;
             w.X = p->dX + (size_t)f0 * p->N; w.x_frame_stride = p->N;
-            w.Lh = p->dLh + (size_t)f0 * p->N * p->lh_planes; w.lh_frame_stride = p->N * p->lh_planes; w.lh_dir_stride = p->N;
-            w.lh_planes = p->lh_planes;
+            w.Lh = p->dLh + (size_t)f0 * p->N; w.lh_frame_stride = p->N;
             w.rec = p->dRec + (size_t)f0 * p->NP; w.s0 = p->dS0 + (size_t)f0 * p->NP;
             w.state_in = w.state_out = p->dState + (size_t)2 * f0 * p->state_stride;
             w.state_frame_stride = p->state_stride;
@@ -585,7 +573,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         SweepArgs w;
         w.C = p->dC + (size_t)f * p->N; w.c_frame_stride = p->N;
         w.X = p->dXup; w.x_frame_stride = p->N;
-        w.Lh = nullptr; w.lh_frame_stride = 0; w.lh_dir_stride = 0; w.lh_planes = p->lh_planes; w.rec = nullptr; w.s0 = nullptr;
+        w.Lh = nullptr; w.lh_frame_stride = 0; w.rec = nullptr; w.s0 = nullptr;
         w.state_in = w.state_out = p->dState + (size_t)2 * f * p->state_stride;   // idle now: scratch for one frame
         w.state_frame_stride = p->state_stride;
         w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
@@ -597,8 +585,8 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
         SweepSumArgs q;
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX + (size_t)f * p->N; q.Xup = p->dXup; q.v_frame_stride = p->N;
-        q.Lh = p->dLh + (size_t)f * p->N * p->lh_planes; q.lh_frame_stride = p->N * p->lh_planes; q.lh_dir_stride = p->N;
-        q.lh_planes = p->lh_planes; q.nC = p->lh_planes == 2 ? 6 : 8; q.Sdbg = p->dS;
+        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N;
+        q.nC = 8; q.P2 = p->P2; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));
@@ -625,8 +613,8 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
         SweepSumArgs q;
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX; q.Xup = nullptr; q.v_frame_stride = p->N;
-        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_dir_stride = p->N;
-        q.lh_planes = 1; q.nC = 4; q.Sdbg = p->dS;
+        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N;
+        q.nC = 4; q.P2 = p->P2; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));

@@ -49,11 +49,10 @@ struct WtaArgs {
 struct SweepArgs {
     const uint8_t* C;         // [frames] cost volumes
     size_t c_frame_stride;
-    uint8_t* X;               // [frames] u8 excess sums: written by modes 0/1, read (the down sweep's) by mode 2
+    uint8_t* X;               // [frames] u8 sums of the sweep's three y (epi_sweep.hip): written by modes 0/1, read (the down sweep's) by mode 2
     size_t x_frame_stride;
-    const uint8_t* Lh;        // mode 2: horizontal pair, lh_planes = 2: [frames][2] path costs (from the left, from the
-    size_t lh_frame_stride, lh_dir_stride;    // right); lh_planes = 1: [frames] their excess sum X_h (pair kernels)
-    int lh_planes;
+    const uint8_t* Lh;        // mode 2: [frames] the horizontal pair's sum Y_h (pair kernels)
+    size_t lh_frame_stride;
     uint4* rec;               // mode 2: [frames][NP] {best, minC, S[best-1], S[best+1]}
     uint16_t* s0;             // mode 2: [frames][NP] S[0] of every pixel
     const uint8_t* state_in;  // [frames][3][W][D] normalised path states of the row above this block
@@ -64,30 +63,30 @@ struct SweepArgs {
     int y0, rows;             // rows [y0, y0+rows) of the sweep frame
 };
 
-struct SweepSumArgs {          // what wta_sweep_kernel adds up (all u8 volumes, one frame stride)
+struct SweepSumArgs {          // what wta_sweep_kernel adds up (u8 volumes; the Y volumes in the sweeps' private byte order)
     const uint8_t* C;
-    const uint8_t* Xdn;       // excess sums of the down sweep
-    const uint8_t* Xup;       // excess sums of the up sweep
+    const uint8_t* Xdn;       // Y of the down sweep (or of the vertical pair)
+    const uint8_t* Xup;       // Y of the up sweep; may be null
     size_t v_frame_stride;
-    const uint8_t* Lh;        // [frames][2] horizontal path costs (from the left, from the right), or [frames] X_h
-    size_t lh_frame_stride, lh_dir_stride;
-    int lh_planes;            // 2 or 1, as in SweepArgs
-    int nC;                   // S = nC*C + Xdn + Xup + (Lh planes); Xup may be null
+    const uint8_t* Lh;        // [frames] Y_h of the horizontal pair
+    size_t lh_frame_stride;
+    int nC;                   // S = nC*(C + P2) - (Xdn + Xup + Lh)
+    int P2;
     uint32_t* Sdbg;           // optional natural-order u32 dump of S [frames][NP][D]
 };
 
 struct PairArgs {              // an opposite pair of paths as one excess sum (epi_sweep.hip, pair kernels)
     const uint8_t* C;         // [frames] cost volumes
     size_t c_frame_stride;
-    uint8_t* X;               // [frames] u8 out: (L_fwd - C) + (L_bwd - C)              (not in the final pass)
+    uint8_t* X;               // [frames] u8 out: y_fwd + y_bwd (epi_sweep.hip)              (not in the final pass)
     size_t x_frame_stride;
     uint8_t* ckpt;            // [frames][lines][ntiles-1][D] normalised backward states at the tile boundaries
     size_t ckpt_frame_stride;
-    const uint8_t* Xother;    // final pass: [frames] the other axis' excess sum
+    const uint8_t* Xother;    // final pass: [frames] the other axis' sum
     size_t xo_frame_stride;
     uint4* rec;               // final pass: [frames][NP] {best, minC, S[best-1], S[best+1]}
     uint16_t* s0;             // final pass: [frames][NP] S[0] of every pixel
-    int nC;                   // final pass: S = X + Xother + nC * C
+    int nC;                   // final pass: S = nC * (C + P2) - (Y + Yother)
     int W, H, D;
     int P1, P2;
 };

@@ -1,4 +1,5 @@
-// epi_sweep.hip -- fused-sweep aggregation for the 8-path calc_cost_sgm case (gfx950).
+// epi_sweep.hip -- fused-sweep aggregation for the 8-path calc_cost_sgm case and the pair kernels of the
+// 4-path case (gfx950).
 //
 // Why: the per-direction kernel (epi_kernels.hip, agg_packed_kernel) moves 24 B per voxel through
 // HBM (8 reads of C, 8 writes + 8 reads of L_r) and is bandwidth-bound at ~1/5 of the algorithmic
@@ -6,24 +7,35 @@
 // (+1,+1) and from above-right (-1,+1), calc_cost_sgm.cpp:193-226 -- are computed TOGETHER for the
 // same pixel, so C is read once per sweep and only their sum leaves the chip:
 //
-//   pair kernels (AXIS 0)   C -> X_h  = (L_left - C) + (L_right - C), the two horizontal paths      (u8)
-//                           (checkpoint-and-recompute, see the pair section below)
-//   down sweep   (MODE 0)   C -> X_dn = sum over the three pass-0 paths from above of (L_r - C)  (u8)
-//   final sweep  (MODE 2)   on the point-mirrored frame (pass 1): its own three paths, then in
-//                           registers S = X_up + X_dn + X_h + 8*C and the WTA;
-//                           writes one 18-byte record per PIXEL
+//   pair kernels (AXIS 0)   C -> Y_h, the two horizontal paths (checkpoint-and-recompute, see the pair section)
+//   down sweep   (MODE 0)   C -> Y_dn, the three pass-0 paths from above
+//   final sweep  (MODE 2)   on the point-mirrored frame (pass 1): its own three paths, then in registers
+//                           S = 8*(C + P2) - (Y_up + Y_dn + Y_h) and the WTA; writes one 18-byte record per PIXEL
 //   sweep_finish_kernel     parabola / vz->disparity from the records -> bestD, minC
 //
-// Every path cost satisfies C <= L_r <= C + P2 when nothing wraps, so the EXCESS L_r - C of three
-// paths fits a byte whenever 3*P2 <= 255 (the reference uses P2 = 64 and 32): X_dn and X_h cost
-// 1 B per voxel each, and neither X_up nor S (u32 in the reference) ever reaches HBM.  8.25 B per
-// voxel by design (9.65 measured) instead of 24.  One sweep launch alone -- strips x frames
-// workgroups -- is too small to fill 256 CUs, so the host forks the work over three streams: the
-// pair kernels, and two lanes of frames that each sweep down and then up (capi_epi.hip).
-// (lh_planes = 2 keeps the earlier form: both horizontal path volumes from agg_packed_kernel,
-// S = ... + 6*C + L_left + L_right; FSGM_EPI_HPAIR=0, for A/B runs.)
-// MODE 1 (plain up sweep writing X_up) and wta_sweep_kernel exist for the debug tap that
-// rebuilds S in natural order (fsgm_epi_plan_download_sum).
+// THE STEP (calc_cost_sgm.cpp:33-66) in the form the kernels compute it.  With L' = L_prev - m_prev the previous
+// pixel's path costs less their stored minimum (m = 0 at a path start, :154), the reference's step is
+//     x[d] = min(L'[d], min(L'[d-1], L'[d+1]) + P1, P2),   L[d] = C[d] + x[d],   m = min_d L[d]
+// when nothing wraps (max C + P2 + max(P1,P2) <= 255, 0 <= P1 <= P2; other parameters use the per-direction
+// kernels).  Clamping the state first, Lc = min(L', P2), does not change x (a term above P2 never wins against
+// Lc[d] <= P2), and in the mirrored variable  s = P2 - Lc  (0 <= s <= P2)  the step needs four packed
+// instructions per register:
+//     t[d] = max(s[d] - P1, 0)                      v_pk_sub_u16 clamp
+//     y[d] = max(s[d], t[d-1], t[d+1])              v_pk_maximum3_f16   (= P2 - x[d]; absent neighbour: 0)
+//     n[d] = (C[d] + P2) - y[d]                     v_pk_sub_u16        (= L[d])
+//     s'[d] = max(P2 + m - n[d], 0),  m = min_d n   v_pk_sub_u16 clamp  (= P2 - min(L[d] - m, P2))
+// All values are below 1024, i.e. denormal fp16 bit patterns, whose order as fp16 numbers is their order as
+// integers: the 3-input fp16 maximum / minimum of gfx950 are exact 3-input u16 maximum / minimum here
+// (probed on the device: tools/ubench/pk_rates.hip, and covered by every parity test).  A path start is the same
+// instruction stream with s = P2 (x = 0) and the stored minimum masked to 0.
+// What leaves the chip are the y of the paths, summed: Y_dn, Y_h (u8; 3*P2 <= 255), and S is rebuilt as
+// paths*(C + P2) - sum of y.
+//
+// Lane layout: LPP = D/16 adjacent lanes own a pixel, 16 consecutive d each.  Register i of a lane (i = 0..7) holds
+// d = 16j+i in its low and d = 16j+8+i in its high half (u16), so the d-1 / d+1 neighbours of a whole register are
+// the whole registers i-1 / i+1 and only registers 0 and 7 need a lane-crossing (one DPP move + one v_perm each).
+// The u8 volumes the kernels exchange (Y_dn, Y_h, path states, checkpoints) keep this order -- dword k of a lane's
+// 16 bytes = registers 2k (bytes 0, 2) and 2k+1 (bytes 1, 3) -- they are private formats; C and the results are not.
 //
 // The diagonal paths couple neighbouring columns, so a workgroup that owns a strip of columns needs
 // its neighbours' boundary values every row.  Instead of in-kernel neighbour synchronisation the
@@ -33,100 +45,141 @@
 // reach the strip within T rows.  At block boundaries the three path states of every column go
 // through a small global buffer.  No spin-waits, no co-residency assumption.
 //
-// Workgroup = 4 waves; wave w owns PXW = 64/LPP adjacent columns (same lane layout as
-// agg_packed_kernel: LPP lanes x 16 d per pixel); strip = 4*PXW columns; T = 2*PXW, so the halo is
+// Workgroup = 4 waves; wave w owns PXW = 64/LPP adjacent columns; strip = 4*PXW columns; T = 2*PXW, so the halo is
 // exactly 2 pixel groups per side = one extra unit of work per wave per row (balanced).
 // Per row every wave runs 4 DP steps: vertical / both diagonals for its own columns + 1 halo step.
 // The diagonal states shift one column per row through LDS (double buffered, one barrier per row).
-//
-// Path states are kept NORMALISED: L' = L - m, with m the stored minimum of that pixel (0 at a path
-// start, calc_cost_sgm.cpp:154).  Then  L_new = C + min( min(L'[d], min(L'[d-1],L'[d+1]) + P1), P2 )
-// needs no separate m.  Valid under the same no-wrap precondition as agg_packed_kernel<.,false>
-// (max C + P2 + max(P1,P2) <= 255, P1,P2 >= 0); other parameters use the per-direction kernels.
+// MODE 1 (plain up sweep writing Y_up) and wta_sweep_kernel exist for the debug tap that
+// rebuilds S in natural order (fsgm_epi_plan_download_sum).
 #include "epi_kernels.h"
 #include "fsgm_device.h"
 #include "epi_wta_tail.h"
+#include <type_traits>
 
 namespace fsgm {
 
 namespace {
 
-constexpr uint32_t SEL_E = 0x0C020C00u;     // v_perm: bytes 0,2 -> 2 x u16
-constexpr uint32_t SEL_O = 0x0C030C01u;     // v_perm: bytes 1,3 -> 2 x u16
-constexpr uint32_t SEL_PACK = 0x06020400u;  // v_perm(O, E): bytes E.lo, O.lo, E.hi, O.hi
+constexpr uint32_t SEL_ODD = 0x0C030C01u;    // v_perm: bytes 1,3 -> 2 x u16
+constexpr uint32_t SEL_PACK = 0x06020400u;   // v_perm(b, a): bytes a.0, b.0, a.2, b.2
+constexpr uint32_t SEL_NB = 0x05040302u;     // v_perm(a, b): (b.hi16, a.lo16)
+constexpr uint32_t SEL_NB_NOLO = 0x05040C0Cu;   // ... with 0 in the low half  (no d-1 neighbour)
+constexpr uint32_t SEL_NB_NOHI = 0x0C0C0302u;   // ... with 0 in the high half (no d+1 neighbour)
 
 __device__ __forceinline__ uint32_t pk_mad16(uint32_t a, uint32_t b, uint32_t c) {        // v_pk_mad_u16
     u16x2 r = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c);
     return __builtin_bit_cast(uint32_t, r);
 }
-__device__ __forceinline__ void unpack16(const uint4 v, uint32_t (&E)[4], uint32_t (&O)[4]) {
+// max(a - b, 0) per half (v_pk_sub_u16 clamp)
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) {
+    u16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+// 3-input maximum / minimum of packed u16 values below 0x7C00 (see the header: fp16 order = integer order there);
+// hipcc fuses the nested 2-input forms into v_pk_maximum3_f16 / v_pk_minimum3_f16 on gfx950
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
+    f16x2 r = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+                                            __builtin_bit_cast(f16x2, c));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
+    f16x2 r = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+                                            __builtin_bit_cast(f16x2, c));
+    return __builtin_bit_cast(uint32_t, r);
+}
+// min(x.lo, x.hi) in the low half, zero above (v_min_u16 with SDWA half selects)
+__device__ __forceinline__ uint32_t min_halves(uint32_t x) {
+    uint32_t r;
+    asm("v_min_u16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// 16 natural-order cost bytes of a lane -> CP[i] = (C[i] + P2, C[i+8] + P2)
+__device__ __forceinline__ void unpack_c(const uint4 w, uint32_t (&CP)[8], const uint32_t P2pk) {
+    CP[0] = pk_add(__builtin_amdgcn_perm(w.z, w.x, 0x0C040C00u), P2pk);
+    CP[1] = pk_add(__builtin_amdgcn_perm(w.z, w.x, 0x0C050C01u), P2pk);
+    CP[2] = pk_add(__builtin_amdgcn_perm(w.z, w.x, 0x0C060C02u), P2pk);
+    CP[3] = pk_add(__builtin_amdgcn_perm(w.z, w.x, 0x0C070C03u), P2pk);
+    CP[4] = pk_add(__builtin_amdgcn_perm(w.w, w.y, 0x0C040C00u), P2pk);
+    CP[5] = pk_add(__builtin_amdgcn_perm(w.w, w.y, 0x0C050C01u), P2pk);
+    CP[6] = pk_add(__builtin_amdgcn_perm(w.w, w.y, 0x0C060C02u), P2pk);
+    CP[7] = pk_add(__builtin_amdgcn_perm(w.w, w.y, 0x0C070C03u), P2pk);
+}
+// private u8 order <-> registers
+__device__ __forceinline__ void unpack_p(const uint4 v, uint32_t (&R)[8]) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        E[k] = __builtin_amdgcn_perm(0u, w[k], SEL_E);
-        O[k] = __builtin_amdgcn_perm(0u, w[k], SEL_O);
+        R[2 * k] = w[k] & 0x00FF00FFu;
+        R[2 * k + 1] = __builtin_amdgcn_perm(0u, w[k], SEL_ODD);
     }
 }
-__device__ __forceinline__ uint4 pack16(const uint32_t (&E)[4], const uint32_t (&O)[4]) {
+__device__ __forceinline__ uint4 pack_p(const uint32_t (&R)[8]) {      // values <= 255 per half
     uint4 o;
-    o.x = __builtin_amdgcn_perm(O[0], E[0], SEL_PACK);
-    o.y = __builtin_amdgcn_perm(O[1], E[1], SEL_PACK);
-    o.z = __builtin_amdgcn_perm(O[2], E[2], SEL_PACK);
-    o.w = __builtin_amdgcn_perm(O[3], E[3], SEL_PACK);
+    o.x = __builtin_amdgcn_perm(R[1], R[0], SEL_PACK);
+    o.y = __builtin_amdgcn_perm(R[3], R[2], SEL_PACK);
+    o.z = __builtin_amdgcn_perm(R[5], R[4], SEL_PACK);
+    o.w = __builtin_amdgcn_perm(R[7], R[6], SEL_PACK);
     return o;
 }
+__device__ __forceinline__ uint4 add4(const uint4 a, const uint4 b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// One DP step on normalised state (calc_cost_sgm.cpp:33-66).  LE/LO: previous pixel's L - m;
-// on return they hold the new pixel's normalised state, and XE/XO its excess L_new - C
-// (= min(L'[d], min(L'[d-1], L'[d+1]) + P1, P2), in [0, P2]).
+// per-lane constants of the step: the v_perm selectors of the two lane-crossing neighbour registers
+struct LaneSel { uint32_t lo, hi; };
 template <int LPP>
-__device__ __forceinline__ void step_norm(uint32_t (&LE)[4], uint32_t (&LO)[4], const uint32_t (&CE)[4],
-                                          const uint32_t (&CO)[4], uint32_t (&XE)[4], uint32_t (&XO)[4],
-                                          const bool start, const uint32_t P1pk, const uint32_t P2pk, const int j) {
-    uint32_t NE[4], NO[4];
-    constexpr uint32_t SENT = 0xFFFFFFFFu;
-    uint32_t prevO3 = dpp_mov<DPP_ROW_SHR1>(SENT, LO[3]);
-    uint32_t nextE0 = dpp_mov<DPP_ROW_SHL1>(SENT, LE[0]);
-    if (j == 0) prevO3 = SENT;                       // d = 0 has no d-1     (:47)
-    if (j == LPP - 1) nextE0 = SENT;                 // d = D-1 has no d+1   (:48)
-    const uint32_t p2lane = start ? 0u : P2pk;       // min(., 0) = 0  ->  L = C at a path start (:152-180)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t nbE = pk_min(align16(LO[k], k ? LO[k - 1] : prevO3), LO[k]);
-        const uint32_t nbO = pk_min(LE[k], align16(k < 3 ? LE[k + 1] : nextE0, LE[k]));
-        XE[k] = pk_min(pk_min(LE[k], pk_add(nbE, P1pk)), p2lane);
-        XO[k] = pk_min(pk_min(LO[k], pk_add(nbO, P1pk)), p2lane);
-        NE[k] = pk_add(CE[k], XE[k]);
-        NO[k] = pk_add(CO[k], XO[k]);
-    }
-    const uint32_t mm = pk_min(pk_min(pk_min(NE[0], NO[0]), pk_min(NE[1], NO[1])),
-                               pk_min(pk_min(NE[2], NO[2]), pk_min(NE[3], NO[3])));
-    uint32_t mx = min(mm & 0xFFFFu, mm >> 16);
-    mx = group_min_u32<LPP>(mx);
-    mx = start ? 0u : mx;                            // stored minimum 0 at a path start (:154,:164)
-    const uint32_t mpk = mx | (mx << 16);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { LE[k] = pk_sub(NE[k], mpk); LO[k] = pk_sub(NO[k], mpk); }
+__device__ __forceinline__ LaneSel lane_sel(const int j) {
+    LaneSel s;
+    s.lo = j == 0 ? SEL_NB_NOLO : SEL_NB;            // d = 0 has no d-1     (:47)
+    s.hi = j == LPP - 1 ? SEL_NB_NOHI : SEL_NB;      // d = D-1 has no d+1   (:48)
+    return s;
 }
 
-// Per-pixel WTA of the final passes: S (packed u16, E/O split) of the LPP lanes of a pixel -> one record
-// {best, minC, S[best-1], S[best+1]} + S[0] (calc_cost_sgm.cpp:263-271; the parabola runs in
+// One DP step (calc_cost_sgm.cpp:33-66) in the mirrored variable, see the header.  S: previous pixel's state
+// s = P2 - min(L - m, P2), replaced by the new pixel's; Y: y = P2 - (L_new - C) of the new pixel, in [0, P2].
+// A path start (:152-180) = S preset to P2 in every element and mmask = 0 (the stored minimum is 0 there, :154).
+template <int LPP>
+__device__ __forceinline__ void step_s(uint32_t (&S)[8], const uint32_t (&CP)[8], uint32_t (&Y)[8], const uint32_t P1pk,
+                                       const uint32_t P2, const LaneSel sel, const uint32_t mmask) {
+    uint32_t T[8], N[8];
+    T[7] = pk_subs(S[7], P1pk);                      // the two registers that cross lanes first: the DPP moves below
+    T[0] = pk_subs(S[0], P1pk);                      // read them two instructions after they are written
+#pragma unroll
+    for (int i = 1; i < 7; i++) T[i] = pk_subs(S[i], P1pk);
+    // d-1 of register 0 = (previous lane's d = 15, own d = 7); d+1 of register 7 = (own d = 8, next lane's d = 0);
+    // lanes without a source lane in their row of 16 read 0
+    const uint32_t LT = __builtin_amdgcn_perm(T[7], (uint32_t)__builtin_amdgcn_mov_dpp((int)T[7], DPP_ROW_SHR1, 0xF, 0xF, true), sel.lo);
+    const uint32_t RT = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_mov_dpp((int)T[0], DPP_ROW_SHL1, 0xF, 0xF, true), T[0], sel.hi);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        Y[i] = pk_max3(S[i], i ? T[i - 1] : LT, i < 7 ? T[i + 1] : RT);
+        N[i] = pk_sub(CP[i], Y[i]);
+    }
+    const uint32_t mm = pk_min(pk_min3(N[0], N[1], N[2]), pk_min3(N[3], N[4], pk_min3(N[5], N[6], N[7])));
+    uint32_t mx = group_min_u32<LPP>(min_halves(mm));
+    const uint32_t p2m = ((mx & mmask) + P2) * 0x10001u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) S[i] = pk_subs(p2m, N[i]);
+}
+
+// Per-pixel WTA of the final passes: S (packed u16, register layout of the header) of the LPP lanes of a pixel -> one
+// record {best, minC, S[best-1], S[best+1]} + S[0] (calc_cost_sgm.cpp:263-271; the parabola runs in
 // sweep_finish_kernel).  First minimum over d: inside a lane as packed u16 keys S*16 + (index in the
 // lane) (S <= 8*255, so a key fits 16 bits and two of them compare per v_pk_min_u16); across the lanes
-// of a pixel as (S << 8 | d).  sRow: 8 u32 per lane, rows private to the wave that writes them.
+// of a pixel as (S << 8 | d).  sRow: 8 u32 per lane, rows private to the wave that writes them; element d of a pixel
+// sits at u16 index ((d >> 4) * 8 + (d & 7)) * 2 + ((d >> 3) & 1).
+__device__ __forceinline__ uint32_t srow_index(uint32_t d) { return (((d >> 4) * 8 + (d & 7)) << 1) + ((d >> 3) & 1); }
+
 template <int LPP>
-__device__ __forceinline__ void wta_row_record(const uint32_t (&SE)[4], const uint32_t (&SO)[4], uint32_t* sRow, int tid, int j,
+__device__ __forceinline__ void wta_row_record(const uint32_t (&ST)[8], uint32_t* sRow, int tid, int j,
                                                bool ok, uint4* rec, uint16_t* s0, size_t idx) {
     constexpr int D = LPP * 16;
     uint32_t* row = sRow + (size_t)(tid / LPP) * (D / 2) + j * 8;
     uint32_t kmin = 0xFFFFFFFFu;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        row[2 * q] = __builtin_amdgcn_perm(SO[q], SE[q], 0x05040100u);       // (S[4q], S[4q+1])   natural d order for the
-        row[2 * q + 1] = __builtin_amdgcn_perm(SO[q], SE[q], 0x07060302u);   // (S[4q+2], S[4q+3]) parabola taps
-        const uint32_t kE = pk_mad16(SE[q], 0x00100010u, (uint32_t)(4 * q) | ((uint32_t)(4 * q + 2) << 16));
-        const uint32_t kO = pk_mad16(SO[q], 0x00100010u, (uint32_t)(4 * q + 1) | ((uint32_t)(4 * q + 3) << 16));
-        kmin = pk_min(kmin, pk_min(kE, kO));
+    for (int i = 0; i < 8; i++) {
+        row[i] = ST[i];
+        kmin = pk_min(kmin, pk_mad16(ST[i], 0x00100010u, (uint32_t)i | ((uint32_t)(i + 8) << 16)));
     }
     const uint32_t k16 = min(kmin & 0xFFFFu, kmin >> 16);
     uint32_t key = ((k16 >> 4) << 8) | ((uint32_t)j * 16u + (k16 & 15u));
@@ -135,8 +188,8 @@ __device__ __forceinline__ void wta_row_record(const uint32_t (&SE)[4], const ui
     if (j == 0 && ok) {
         const uint32_t best = key & 0xFF, minc = key >> 8;
         const uint16_t* srow = (const uint16_t*)(sRow + (size_t)(tid / LPP) * (D / 2));
-        const uint32_t c_1 = best > 0 ? srow[best - 1] : 0u;
-        const uint32_t c1 = best + 1 < (uint32_t)D ? srow[best + 1] : 0u;   // best == D-1: the finish kernel takes the next pixel's S[0]
+        const uint32_t c_1 = best > 0 ? srow[srow_index(best - 1)] : 0u;
+        const uint32_t c1 = best + 1 < (uint32_t)D ? srow[srow_index(best + 1)] : 0u;   // best == D-1: the finish kernel takes the next pixel's S[0]
         rec[idx] = make_uint4(best, minc, c_1, c1);
         s0[idx] = (uint16_t)srow[0];
     }
@@ -146,8 +199,8 @@ __device__ __forceinline__ void wta_row_record(const uint32_t (&SE)[4], const ui
 
 // =============================================================================================
 // sweep kernel: rows [y0, y0+rows) of the sweep frame.
-//   MODE 0: pass-0 frame, writes X_dn.   MODE 1: point-mirrored frame, writes X_up.
-//   MODE 2: point-mirrored frame, final: S = X_dn + X_up + 6C + L_left + L_right in registers,
+//   MODE 0: pass-0 frame, writes Y_dn.   MODE 1: point-mirrored frame, writes Y_up.
+//   MODE 2: point-mirrored frame, final: S = 8*(C + P2) - (Y_up + Y_dn + Y_h) in registers,
 //           WTA per pixel, writes one record {best, minC, S[best-1], S[best+1]} + S[0] per pixel.
 // =============================================================================================
 template <int LPP, int MODE, int NWV>
@@ -160,7 +213,7 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     constexpr int NCOL = STRIP + 2 * T + 2;  // LDS columns: forward column x  <->  index x - (a0 - T - 1)
     constexpr int PF = MODE == 2 ? 2 : 3;    // rows of C in flight per lane
     __shared__ uint4 sDiag[2][2][NCOL * LPP];    // [row parity][0: from above-left, 1: from above-right][column][lane-of-pixel]
-    __shared__ uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 1];   // MODE 2: S of the wave's pixels in natural d order (u16)
+    __shared__ uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 1];   // MODE 2: S of the wave's pixels (u16)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPP, j = lane % LPP;
@@ -180,9 +233,11 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     uint8_t* __restrict__ Xf = a.X + f * a.x_frame_stride;
     const uint8_t* __restrict__ StIn = a.state_in + f * a.state_frame_stride;    // [3][W][D] u8, written by the previous launch
     uint8_t* __restrict__ StOut = a.state_out + f * a.state_frame_stride;        // other buffer: no launch reads what it writes
-    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const uint4 startP = make_uint4(P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u);   // s = P2 everywhere: a path start
     const int y0 = a.y0, rows = min(a.rows, H - y0);
     const bool first_block = y0 == 0;
+    const LaneSel sel = lane_sel<LPP>(j);
 
     // columns in the (possibly mirrored) sweep frame
     const int gx = a0 + wave * PXW + g;                          // own column
@@ -192,27 +247,39 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     //                         waves 2,3 -> from-above-right on the T columns right of it
     const int hdir = wave >= NWV / 2 ? 1 : 0;
     const int hx = hdir == 0 ? a0 - T + wave * PXW + g : a0 + STRIP + (wave - NWV / 2) * PXW + g;
+    const bool halo_ok = hx >= 0 && hx < W;
     const int hxc = min(max(hx, 0), W - 1);
     const int lbase = a0 - T - 1;                                // forward column of LDS index 0
+    // a diagonal restarts where it enters the image (:156-180): its predecessor column -1 / W holds the start state
+    // (never overwritten: stores of columns outside the image are skipped) and the stored minimum is masked to 0
+    const uint32_t mask_dl = gx == 0 ? 0u : 0xFFFFu, mask_dr = gx == W - 1 ? 0u : 0xFFFFu;
+    const uint32_t mask_h = (hdir == 0 ? hx == 0 : hx == W - 1) ? 0u : 0xFFFFu;
 
     auto pix_of = [&](int x, int y) -> int {                     // actual pixel index of sweep-frame (x,y)
         const int p = y * W + x;
         return UP ? NP - 1 - p : p;
     };
-    auto vox_off = [&](int x, int y) -> uint32_t {               // byte offset of (x,y)'s 16 costs of this lane
+    auto vox_off = [&](int x, int y) -> uint32_t {               // byte offset of (x,y)'s 16 bytes of this lane
         return (uint32_t)pix_of(x, y) * D + (uint32_t)j * 16;
     };
 
-    // ---- block prologue: path states of the row above (from the previous launch) ----
-    uint32_t VE[4] = {0, 0, 0, 0}, VO[4] = {0, 0, 0, 0};          // vertical path state of the own column
-    if (!first_block) {
-        unpack16(*(const uint4*)(StIn + (size_t)gxc * D + j * 16), VE, VO);
-        for (int i = tid; i < 2 * NCOL * LPP; i += NWV * 64) {
-            const int dir = i / (NCOL * LPP), r = i - dir * (NCOL * LPP);
-            const int c = r / LPP, jj = r - c * LPP;
-            const int x = min(max(lbase + c, 0), W - 1);
-            sDiag[0][dir][r] = *(const uint4*)(StIn + ((size_t)(1 + dir) * W + x) * D + jj * 16);
-        }
+    // ---- block prologue: path states of the row above (from the previous launch; start states above row 0) ----
+    uint32_t VS[8];
+    if (first_block) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) VS[i] = P2pk;
+    } else {
+        unpack_p(*(const uint4*)(StIn + (size_t)gxc * D + j * 16), VS);
+    }
+    for (int i = tid; i < 2 * NCOL * LPP; i += NWV * 64) {
+        const int dir = i / (NCOL * LPP), r = i - dir * (NCOL * LPP);
+        const int c = r / LPP, jj = r - c * LPP;
+        const int x = lbase + c;
+        const bool inside = x >= 0 && x < W;
+        uint4 v = startP;
+        if (inside && !first_block) v = *(const uint4*)(StIn + ((size_t)(1 + dir) * W + x) * D + jj * 16);
+        sDiag[0][dir][r] = v;
+        sDiag[1][dir][r] = v;                                    // columns outside the image keep the start state in both buffers
     }
     __syncthreads();
 
@@ -229,72 +296,61 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     // one row of the block: 4 DP steps per wave, one barrier
     auto do_row = [&](const int k, const uint4 cOwn, const uint4 cHalo) {
         const int y = y0 + k, par = k & 1;
-        const bool top = y == 0;
+        const uint32_t tmask = y == 0 ? 0u : 0xFFFFu;            // row 0: every path starts (:152-180)
         // MODE 2: the other partial sums of the own pixel; issued now, consumed after the four DP
         // steps of this row, which hide most of their latency
-        uint4 curX, curL0, curL1;
+        uint4 curX, curH;
         if (MODE == 2) {
             const uint32_t off = vox_off(gxc, y);
             curX = *(const uint4*)(Xf + off);
-            curL0 = *(const uint4*)(Lhf + off);
-            if (a.lh_planes == 2) curL1 = *(const uint4*)(Lhf + a.lh_dir_stride + off);
+            curH = *(const uint4*)(Lhf + off);
         }
-        uint32_t CE[4], CO[4], XE[4], XO[4], SE[4], SO[4];
-        unpack16(cOwn, CE, CO);
+        uint32_t CP[8], Y[8], YS[8];
+        unpack_c(cOwn, CP, P2pk);
 
         // from above (0,+1)                                            calc_cost_sgm.cpp:193-202
-        step_norm<LPP>(VE, VO, CE, CO, XE, XO, top, P1pk, P2pk, j);
-#pragma unroll
-        for (int q = 0; q < 4; q++) { SE[q] = XE[q]; SO[q] = XO[q]; }
+        step_s<LPP>(VS, CP, YS, P1pk, P2, sel, tmask);
 
         // from above-left (+1,+1): predecessor column gx-1                        :205-213
         {
-            uint32_t LE[4], LO[4];
-            unpack16(sDiag[par][0][(gx - 1 - lbase) * LPP + j], LE, LO);
-            step_norm<LPP>(LE, LO, CE, CO, XE, XO, top || gx == 0, P1pk, P2pk, j);
-            sDiag[par ^ 1][0][(gx - lbase) * LPP + j] = pack16(LE, LO);
+            uint32_t S[8];
+            unpack_p(sDiag[par][0][(gx - 1 - lbase) * LPP + j], S);
+            step_s<LPP>(S, CP, Y, P1pk, P2, sel, mask_dl & tmask);
+            if (own_ok) sDiag[par ^ 1][0][(gx - lbase) * LPP + j] = pack_p(S);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { SE[q] += XE[q]; SO[q] += XO[q]; }
+            for (int q = 0; q < 8; q++) YS[q] += Y[q];
         }
         // from above-right (-1,+1): predecessor column gx+1                       :215-225
         {
-            uint32_t LE[4], LO[4];
-            unpack16(sDiag[par][1][(gx + 1 - lbase) * LPP + j], LE, LO);
-            step_norm<LPP>(LE, LO, CE, CO, XE, XO, top || gx == W - 1, P1pk, P2pk, j);
-            sDiag[par ^ 1][1][(gx - lbase) * LPP + j] = pack16(LE, LO);
+            uint32_t S[8];
+            unpack_p(sDiag[par][1][(gx + 1 - lbase) * LPP + j], S);
+            step_s<LPP>(S, CP, Y, P1pk, P2, sel, mask_dr & tmask);
+            if (own_ok) sDiag[par ^ 1][1][(gx - lbase) * LPP + j] = pack_p(S);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { SE[q] += XE[q]; SO[q] += XO[q]; }
+            for (int q = 0; q < 8; q++) YS[q] += Y[q];
         }
         // halo unit: keeps the inward-flowing diagonal correct for the next rows
         {
-            uint32_t HE[4], HO[4], LE[4], LO[4];
-            unpack16(cHalo, HE, HO);
+            uint32_t HP[8], S[8];
+            unpack_c(cHalo, HP, P2pk);
             const int px = hdir == 0 ? hx - 1 : hx + 1;
-            unpack16(sDiag[par][hdir][(px - lbase) * LPP + j], LE, LO);
-            const bool st = top || (hdir == 0 ? hx == 0 : hx == W - 1);
-            step_norm<LPP>(LE, LO, HE, HO, XE, XO, st, P1pk, P2pk, j);
-            sDiag[par ^ 1][hdir][(hx - lbase) * LPP + j] = pack16(LE, LO);
+            unpack_p(sDiag[par][hdir][(px - lbase) * LPP + j], S);
+            step_s<LPP>(S, HP, Y, P1pk, P2, sel, mask_h & tmask);
+            if (halo_ok) sDiag[par ^ 1][hdir][(hx - lbase) * LPP + j] = pack_p(S);
         }
         if (MODE != 2) {
-            // excess sum of this sweep's three paths, one byte per voxel (3*P2 <= 255)      :227-232
-            if (own_ok) *(uint4*)(Xf + vox_off(gx, y)) = pack16(SE, SO);
+            // sum of this sweep's three y, one byte per voxel (3*P2 <= 255)      :227-232
+            if (own_ok) *(uint4*)(Xf + vox_off(gx, y)) = pack_p(YS);
         } else {
-            // S = X_up (registers) + X_dn + 6*C + from-the-left + from-the-right, all at this pixel
-            // (lh_planes = 1: the horizontal pair arrives as its excess sum X_h, so 8*C)
-            uint32_t E2[4], O2[4];
-            const uint32_t nC = a.lh_planes == 2 ? 6u : 8u;
-            unpack16(curX, E2, O2);                                               // X_dn
+            // S = 8*(C + P2) - (Y_up (registers) + Y_dn + Y_h), all at this pixel
+            uint32_t E2[8], ST[8];
+            unpack_p(curX, E2);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { SE[q] += E2[q] + nC * CE[q]; SO[q] += O2[q] + nC * CO[q]; }
-            unpack16(curL0, E2, O2);
+            for (int q = 0; q < 8; q++) YS[q] += E2[q];
+            unpack_p(curH, E2);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
-            if (a.lh_planes == 2) {
-                unpack16(curL1, E2, O2);
-#pragma unroll
-                for (int q = 0; q < 4; q++) { SE[q] += E2[q]; SO[q] += O2[q]; }
-            }
-            wta_row_record<LPP>(SE, SO, sRow, tid, j, own_ok, a.rec, a.s0, f * (size_t)NP + pix_of(gx, y));
+            for (int q = 0; q < 8; q++) ST[q] = pk_sub(pk_mad16(CP[q], 0x00080008u, 0u), pk_add(YS[q], E2[q]));
+            wta_row_record<LPP>(ST, sRow, tid, j, own_ok, a.rec, a.s0, f * (size_t)NP + pix_of(gx, y));
         }
         __syncthreads();                                         // diagonal states of row y visible to row y+1
     };
@@ -318,7 +374,7 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     // ---- block epilogue: states of the last row for the next launch ----
     if (y0 + rows < H && own_ok) {
         const int par = rows & 1;                                // buffer the last row wrote into
-        *(uint4*)(StOut + (size_t)gx * D + j * 16) = pack16(VE, VO);
+        *(uint4*)(StOut + (size_t)gx * D + j * 16) = pack_p(VS);
         *(uint4*)(StOut + ((size_t)W + gx) * D + j * 16) = sDiag[par][0][(gx - lbase) * LPP + j];
         *(uint4*)(StOut + ((size_t)2 * W + gx) * D + j * 16) = sDiag[par][1][(gx - lbase) * LPP + j];
     }
@@ -341,8 +397,9 @@ __global__ __launch_bounds__(256) void sweep_finish_kernel(WtaArgs a, const uint
 }
 
 // =============================================================================================
-// WTA over S = X_dn + X_up + 6*C + L_left + L_right  (calc_cost_sgm.cpp:227-232, :259-308, :414-426)
-// for the non-final mode (X_up materialised by a MODE 1 sweep).
+// WTA over S = nC*(C + P2) - (Y_dn + Y_up + Y_h)  (calc_cost_sgm.cpp:227-232, :259-308, :414-426)
+// for the non-final mode (Y_up materialised by a MODE 1 sweep): the debug tap that rebuilds S in natural order.
+// One thread per pixel-lane as in the sweeps; the Y volumes are in the private byte order (header).
 // =============================================================================================
 template <int LPP>
 __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs q) {
@@ -356,41 +413,30 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
     const int p = valid ? gp : NP - 1;
     const size_t f = blockIdx.y;
     const size_t bo = (size_t)p * D + (size_t)j * 16;                    // byte offset in a u8 volume
-    const uint8_t* Lh = q.Lh + f * q.lh_frame_stride;
-    uint32_t E[4], O[4], E2[4], O2[4];
-    unpack16(*(const uint4*)(q.C + f * q.v_frame_stride + bo), E, O);
-    const uint32_t nC = (uint32_t)q.nC;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { E[k] *= nC; O[k] *= nC; }
-    unpack16(*(const uint4*)(q.Xdn + f * q.v_frame_stride + bo), E2, O2);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
+    const uint32_t P2pk = (uint32_t)q.P2 * 0x10001u, nC = (uint32_t)q.nC;
+    uint32_t CP[8], YT[8], E2[8], ST[8];
+    unpack_c(*(const uint4*)(q.C + f * q.v_frame_stride + bo), CP, P2pk);
+    unpack_p(*(const uint4*)(q.Xdn + f * q.v_frame_stride + bo), YT);
     if (q.Xup) {
-        unpack16(*(const uint4*)(q.Xup + f * q.v_frame_stride + bo), E2, O2);
+        unpack_p(*(const uint4*)(q.Xup + f * q.v_frame_stride + bo), E2);
 #pragma unroll
-        for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
+        for (int k = 0; k < 8; k++) YT[k] += E2[k];
     }
-    unpack16(*(const uint4*)(Lh + bo), E2, O2);
+    unpack_p(*(const uint4*)(q.Lh + f * q.lh_frame_stride + bo), E2);
 #pragma unroll
-    for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
-    if (q.lh_planes == 2) {
-        unpack16(*(const uint4*)(Lh + q.lh_dir_stride + bo), E2, O2);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { E[k] += E2[k]; O[k] += O2[k]; }
-    }
+    for (int k = 0; k < 8; k++) ST[k] = pk_sub(pk_mad16(CP[k], nC * 0x10001u, 0u), pk_add(YT[k], E2[k]));
 
     uint32_t key = 0xFFFFFFFFu;
     uint32_t* row = sS + (size_t)(tid / LPP) * (D / 2) + j * 8;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t v0 = E[k] & 0xFFFF, v1 = O[k] & 0xFFFF, v2 = E[k] >> 16, v3 = O[k] >> 16;
-        row[2 * k] = v0 | (v1 << 16);
-        row[2 * k + 1] = v2 | (v3 << 16);
-        const uint32_t dd = (uint32_t)j * 16 + 4 * k;
-        key = min(key, min(min((v0 << 8) | dd, (v1 << 8) | (dd + 1)), min((v2 << 8) | (dd + 2), (v3 << 8) | (dd + 3))));
+    for (int k = 0; k < 8; k++) {
+        row[k] = ST[k];
+        const uint32_t v0 = ST[k] & 0xFFFF, v1 = ST[k] >> 16;
+        const uint32_t d0 = (uint32_t)j * 16 + k, d1 = d0 + 8;
+        key = min(key, min((v0 << 8) | d0, (v1 << 8) | d1));
         if (q.Sdbg && valid) {
-            uint32_t* o = q.Sdbg + f * (size_t)NP * D + (size_t)p * D + dd;
-            o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
+            uint32_t* o = q.Sdbg + f * (size_t)NP * D + (size_t)p * D;
+            o[d0] = v0; o[d1] = v1;
         }
     }
     key = group_min_u32<LPP>(key);
@@ -400,12 +446,12 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
         const uint16_t* srow = (const uint16_t*)(sS + (size_t)(tid / LPP) * (D / 2));
         uint32_t c_1 = 0, c1 = 0;
         if (a.subpixel && best > 1) {
-            c_1 = srow[best - 1];
-            if (best + 1 < (uint32_t)D) c1 = srow[best + 1];
-            else if (p + 1 < NP) {                                           // next pixel's d=0 (:296)
+            c_1 = srow[srow_index(best - 1)];
+            if (best + 1 < (uint32_t)D) c1 = srow[srow_index(best + 1)];
+            else if (p + 1 < NP) {                                           // next pixel's d=0 (:296): byte 0 of its lane 0 in every volume
                 const size_t nb = f * q.v_frame_stride + (size_t)(p + 1) * D;
-                c1 = nC * q.C[nb] + q.Xdn[nb] + (q.Xup ? (uint32_t)q.Xup[nb] : 0u) + Lh[(size_t)(p + 1) * D] +
-                     (q.lh_planes == 2 ? (uint32_t)Lh[q.lh_dir_stride + (size_t)(p + 1) * D] : 0u);
+                const size_t nh = f * q.lh_frame_stride + (size_t)(p + 1) * D;
+                c1 = nC * ((uint32_t)q.C[nb] + (uint32_t)q.P2) - ((uint32_t)q.Xdn[nb] + (q.Xup ? (uint32_t)q.Xup[nb] : 0u) + (uint32_t)q.Lh[nh]);
             }
         }
         wta_finish(a, f, p, best, minc, c_1, c1);
@@ -413,23 +459,22 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
 }
 
 // =============================================================================================
-// An opposite pair of paths as ONE excess sum  X = (L_fwd - C) + (L_bwd - C)  (<= 2*P2, one byte).
+// An opposite pair of paths as ONE sum  Y = y_fwd + y_bwd  (<= 2*P2, one byte).
 // The two paths of an axis (calc_cost_sgm.cpp:183-202 and their pass-1 mirrors) run in opposite
 // directions along a line, so their values for a pixel exist at different times; writing both path
 // volumes and reading them back costs 6 B per voxel (C twice, 2 writes, 2 reads).
 // Checkpoint-and-recompute brings that to ~4.25 B:
-//   pass A (pair_ckpt_kernel)  end -> start of the line, keeps nothing but the normalised backward
+//   pass A (pair_ckpt_kernel)  end -> start of the line, keeps nothing but the backward
 //          state at every HP_TC-th position (1/HP_TC B per voxel);
-//   pass B (pair_sum_kernel)   start -> end in tiles of HP_TC positions: the tile's backward excesses
+//   pass B (pair_sum_kernel)   start -> end in tiles of HP_TC positions: the tile's backward y
 //          are recomputed from the checkpoint on its far edge into registers, then the forward path
-//          crosses the tile, adds them and stores X.  The tile's C stays in registers between the two.
+//          crosses the tile, adds them and stores Y.  The tile's C stays in registers between the two.
 // AXIS 0: lines = image rows (the horizontal pair; 64/LPP rows per wave, consecutive positions 16*LPP
 //         bytes apart); AXIS 1: lines = image columns (the vertical pair; 64/LPP adjacent columns per
 //         wave -- one contiguous run per step -- consecutive positions a row apart).
-// FINAL:  instead of storing X, pass B adds the other axis' X and nC*C and does the WTA on the spot --
-//         the 4-path pipeline (the reference's shipped configuration): horizontal pair -> X_h, vertical
-//         pair final: S = X_v + X_h + 4*C, 7.5 B per voxel for 4 voxel-paths, S never in HBM.
-// Same lane layout as agg_packed_kernel: LPP lanes x 16 d per pixel.
+// FINAL:  instead of storing Y, pass B adds the other axis' Y and does the WTA on the spot --
+//         the 4-path pipeline (the reference's shipped configuration): horizontal pair -> Y_h, vertical
+//         pair final: S = 4*(C + P2) - (Y_v + Y_h), 7.5 B per voxel for 4 voxel-paths, S never in HBM.
 // =============================================================================================
 #ifndef FSGM_HP_TC
 #define FSGM_HP_TC 8            // tile width = checkpoint spacing in positions (A/B knob)
@@ -451,8 +496,11 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
     const size_t lstride = AXIS ? (size_t)D : (size_t)a.W * D, tstride = AXIS ? (size_t)a.W * D : (size_t)D;
     const uint8_t* __restrict__ Cl = a.C + f * a.c_frame_stride + (size_t)l * lstride + (size_t)j * 16;
     uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * (NT - 1)) * D + (size_t)j * 16;
-    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
-    uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const LaneSel sel = lane_sel<LPP>(j);
+    uint32_t S[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) S[i] = P2pk;                    // the path starts at the line's last position
     auto load_c = [&](int t) -> uint4 { return *(const uint4*)(Cl + (size_t)max(t, 0) * tstride); };
     uint4 ring[PF];
 #pragma unroll
@@ -464,11 +512,11 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
             const int t = t0 - i;
             const uint4 cw = ring[i];
             ring[i] = load_c(t - PF);
-            uint32_t CE[4], CO[4], XE[4], XO[4];
-            unpack16(cw, CE, CO);
-            step_norm<LPP>(LE, LO, CE, CO, XE, XO, t == len - 1, P1pk, P2pk, j);
+            uint32_t CP[8], Y[8];
+            unpack_c(cw, CP, P2pk);
+            step_s<LPP>(S, CP, Y, P1pk, P2, sel, t == len - 1 ? 0u : 0xFFFFu);
             // positions below `last` in the final group are computed but not needed; t >= 0 always holds there
-            if (t >= last && (t % HP_TC) == 0) *(uint4*)(Kl + (size_t)(t / HP_TC - 1) * D) = pack16(LE, LO);
+            if (t >= last && (t % HP_TC) == 0) *(uint4*)(Kl + (size_t)(t / HP_TC - 1) * D) = pack_p(S);
         }
     }
 }
@@ -476,7 +524,7 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
 template <int LPP, int AXIS, bool FINAL>
 __global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs a) {
     constexpr int PXW = 64 / LPP, D = LPP * 16, TC = HP_TC;
-    __shared__ uint32_t sRow[FINAL ? 4 * 64 * 8 : 1];            // FINAL: S of the wave's pixels in natural d order (u16)
+    __shared__ uint32_t sRow[FINAL ? 4 * 64 * 8 : 1];            // FINAL: S of the wave's pixels (u16)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPP, j = lane % LPP;
     const int W = a.W, NP = a.W * a.H;
@@ -490,66 +538,86 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs a) {
     const size_t lstride = AXIS ? (size_t)D : (size_t)W * D, tstride = AXIS ? (size_t)W * D : (size_t)D;
     const size_t lbase = (size_t)l * lstride + (size_t)j * 16;
     const uint8_t* __restrict__ Cl = a.C + f * a.c_frame_stride + lbase;
-    uint8_t* __restrict__ Xl = FINAL ? nullptr : a.X + f * a.x_frame_stride + lbase;     // !FINAL: this pair's excess sum, out
+    uint8_t* __restrict__ Xl = FINAL ? nullptr : a.X + f * a.x_frame_stride + lbase;     // !FINAL: this pair's sum, out
     const uint8_t* __restrict__ Ol = FINAL ? a.Xother + f * a.xo_frame_stride + lbase : nullptr;   // FINAL: the other pair's, in
     const uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * max(NT - 1, 1)) * D + (size_t)j * 16;
-    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
-    uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};          // forward state, carried across tiles
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const LaneSel sel = lane_sel<LPP>(j);
+    uint32_t FS[8];                                               // forward state, carried across tiles
+#pragma unroll
+    for (int i = 0; i < 8; i++) FS[i] = P2pk;                    // position 0 starts the forward path
     auto load_c = [&](int t) -> uint4 { return *(const uint4*)(Cl + (size_t)min(t, len - 1) * tstride); };
     auto load_k = [&](int t) -> uint4 { return *(const uint4*)(Kl + (size_t)min(t, max(NT - 2, 0)) * D); };
     uint4 cT[TC], cN[TC], kT = load_k(0), kN;
 #pragma unroll
     for (int c = 0; c < TC; c++) cT[c] = load_c(c);
-    for (int t = 0; t < NT; t++) {
+    // one tile; EDGE: the tile holds position 0 or reaches the line's end, where the paths start (:152-180) -- the
+    // other tiles run without a single select
+    auto tile = [&](const int t, auto edge) {
+        constexpr bool EDGE = decltype(edge)::value;
         const int tb = t * TC;
 #pragma unroll
         for (int c = 0; c < TC; c++) cN[c] = load_c(tb + TC + c);      // next tile, in flight while this one computes
         kN = load_k(t + 1);
         // backward path through the tile: positions past the line end come first and are wiped by the path
-        // start at the last position (:152-180); a tile inside the line starts from its checkpoint
-        uint32_t RE[4], RO[4];
-        unpack16(kT, RE, RO);
+        // start at the last position; a tile inside the line starts from its checkpoint
+        uint32_t RS[8];
+        unpack_p(kT, RS);
         uint4 exR[TC];
 #pragma unroll
         for (int c = TC - 1; c >= 0; c--) {
             const int x = tb + c;
-            uint32_t CE[4], CO[4], XE[4], XO[4];
-            unpack16(cT[c], CE, CO);
-            step_norm<LPP>(RE, RO, CE, CO, XE, XO, x >= len - 1, P1pk, P2pk, j);
-            exR[c] = pack16(XE, XO);
+            uint32_t CP[8], Y[8];
+            unpack_c(cT[c], CP, P2pk);
+            uint32_t mmask = 0xFFFFu;
+            if (EDGE && x >= len - 1) {                           // wave-uniform: the backward path starts here
+#pragma unroll
+                for (int i = 0; i < 8; i++) RS[i] = P2pk;
+                mmask = 0u;
+            }
+            step_s<LPP>(RS, CP, Y, P1pk, P2, sel, mmask);
+            exR[c] = pack_p(Y);
         }
         uint4 xo[TC];
         if (FINAL) {
 #pragma unroll
             for (int c = 0; c < TC; c++) xo[c] = *(const uint4*)(Ol + (size_t)min(tb + c, len - 1) * tstride);
         }
-        // forward path, adding the two excesses
+        // forward path, adding the two y
 #pragma unroll
         for (int c = 0; c < TC; c++) {
             const int x = tb + c;
-            uint32_t CE[4], CO[4], XE[4], XO[4];
-            unpack16(cT[c], CE, CO);
-            step_norm<LPP>(LE, LO, CE, CO, XE, XO, x == 0, P1pk, P2pk, j);
-            // both excesses are <= P2 per byte and 2*P2 <= 255: the packed bytes add as plain words
-            uint4 xs = pack16(XE, XO);
-            xs.x += exR[c].x; xs.y += exR[c].y; xs.z += exR[c].z; xs.w += exR[c].w;
+            uint32_t CP[8], Y[8];
+            unpack_c(cT[c], CP, P2pk);
+            step_s<LPP>(FS, CP, Y, P1pk, P2, sel, (EDGE && x == 0) ? 0u : 0xFFFFu);
             if (!FINAL) {
-                if (x < len) *(uint4*)(Xl + (size_t)x * tstride) = xs;
+                // both y are <= P2 per byte and 2*P2 <= 255: the packed bytes add as plain words
+                if (!EDGE || x < len) *(uint4*)(Xl + (size_t)x * tstride) = add4(pack_p(Y), exR[c]);
             } else {
-                // S = this pair + the other pair + nC*C (calc_cost_sgm.cpp:227-232), WTA on the spot
-                uint32_t SE[4], SO[4], E2[4], O2[4];
-                unpack16(xs, SE, SO);
-                unpack16(xo[c], E2, O2);
-                const uint32_t nC = (uint32_t)a.nC;
+                // S = nC*(C + P2) - (this pair + the other pair) (calc_cost_sgm.cpp:227-232), WTA on the spot
+                uint32_t ST[8], E2[8], E3[8];
+                unpack_p(exR[c], E2);
+                unpack_p(xo[c], E3);
+                const uint32_t nC = (uint32_t)a.nC * 0x10001u;
 #pragma unroll
-                for (int q = 0; q < 4; q++) { SE[q] += E2[q] + nC * CE[q]; SO[q] += O2[q] + nC * CO[q]; }
+                for (int q = 0; q < 8; q++) ST[q] = pk_sub(pk_mad16(CP[q], nC, 0u), pk_add(pk_add(Y[q], E2[q]), E3[q]));
                 const int ap = AXIS ? x * W + l : l * W + x;     // pixel index (wave-uniform validity: x < len)
-                wta_row_record<LPP>(SE, SO, sRow, tid, j, own_ok && x < len, a.rec, a.s0, f * (size_t)NP + (size_t)min(ap, NP - 1));
+                wta_row_record<LPP>(ST, sRow, tid, j, own_ok && (!EDGE || x < len), a.rec, a.s0, f * (size_t)NP + (size_t)min(ap, NP - 1));
             }
         }
 #pragma unroll
         for (int c = 0; c < TC; c++) cT[c] = cN[c];
         kT = kN;
+    };
+    if (NT == 1) {
+        tile(0, std::true_type{});
+    } else {
+        tile(0, std::true_type{});                                // holds position 0 (and, for len <= TC + 1, the end too)
+        for (int t = 1; t < NT - 1; t++) {
+            if ((t + 1) * TC <= len - 1) tile(t, std::false_type{});
+            else tile(t, std::true_type{});
+        }
+        tile(NT - 1, std::true_type{});
     }
 }
 
@@ -578,7 +646,7 @@ static void launch_pair_t(hipStream_t st, const PairArgs& a, int frames, int axi
 
 // One axis (0 horizontal, 1 vertical).  phase 0: checkpoint pass + sum pass; 1: checkpoint pass only;
 // 2: sum pass only (so that the caller can put an event between them).  final_pass: the sum pass adds
-// a.Xother and nC*C and writes WTA records instead of X.
+// a.Xother and writes WTA records instead of Y.
 void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase) {
     switch (agg_packed_lpp(a.D)) {
         case 1: launch_pair_t<1>(st, a, frames, axis, final_pass, phase); break;
