@@ -284,7 +284,8 @@ def main():
                       for i, r in enumerate(ref.download(i) for i in range(len(check_frames))))
         ref_kernel = ref.kernel_name
     del check_vols
-    assert checked, "the timed pipeline's bestD/minC differ from the line kernels' on the same volumes"
+    # (FSGM_BENCH_NOCHECK=1: timing experiments with deliberately broken kernels; the line still says "checked": false)
+    assert checked or os.environ.get("FSGM_BENCH_NOCHECK") == "1", "the timed pipeline's bestD/minC differ from the line kernels' on the same volumes"
 
     # stage timing with HIP events on the plan's own stream (the forked streams join it before the
     # second event), rank 0 reports

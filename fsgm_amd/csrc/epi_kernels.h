@@ -63,6 +63,27 @@ struct SweepArgs {
     int y0, rows;             // rows [y0, y0+rows) of the sweep frame
 };
 
+// a whole sweep in one launch, strips of skewed columns handing their edge states over while they run (epi_sweep.hip)
+struct StripArgs {
+    const uint8_t* C;         // [frames] cost volumes
+    size_t c_frame_stride;
+    uint8_t* X;               // [frames] Y of this sweep: written by modes 0/1; mode 2 reads the down sweep's
+    size_t x_frame_stride;
+    const uint8_t* Lh;        // mode 2: [frames] Y_h
+    size_t lh_frame_stride;
+    uint4* rec;               // mode 2: [frames][NP] records
+    uint16_t* s0;             // mode 2: [frames][NP]
+    uint4* edge;              // [frames][NS][H][3][LPP] hand-off of path states between neighbouring strips
+    uint32_t* ticket;         // work counter of this stream of launches (never reset: ticket_base = its value at launch)
+    uint32_t ticket_base;
+    uint32_t tag;             // 4-bit launch sequence number spread over the top bits of a dword's bytes
+    uint32_t* err;            // set to non-zero when a hand-off wait gave up
+    int W, H, D;
+    int P1, P2;
+    int frames, NS;
+    int nowait;               // timing experiment only (FSGM_STRIP_NOWAIT=1): take whatever the hand-off buffer holds -- WRONG results
+};
+
 struct SweepSumArgs {          // what wta_sweep_kernel adds up (u8 volumes; the Y volumes in the sweeps' private byte order)
     const uint8_t* C;
     const uint8_t* Xdn;       // Y of the down sweep (or of the vertical pair)
@@ -87,6 +108,7 @@ struct PairArgs {              // an opposite pair of paths as one excess sum (e
     uint4* rec;               // final pass: [frames][NP] {best, minC, S[best-1], S[best+1]}
     uint16_t* s0;             // final pass: [frames][NP] S[0] of every pixel
     int nC;                   // final pass: S = nC * (C + P2) - (Y + Yother)
+    int prio;                 // s_setprio level of the pair kernels' waves (0-3)
     int W, H, D;
     int P1, P2;
 };
@@ -113,6 +135,9 @@ void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
 int    sweep_rows_per_launch(int D);
 size_t sweep_state_bytes(int W, int D);   // one state buffer of one frame
 void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode);   // 0 down, 1 up, 2 up + fused WTA
+int    strip_count(int W, int H, int D);                    // strips of skewed columns per frame
+size_t strip_edge_uint4s(int W, int H, int D);              // hand-off buffer per frame, in uint4
+void launch_strips(hipStream_t st, const StripArgs& a, int mode);               // same modes, one launch per sweep
 size_t pair_ckpt_bytes(int W, int H, int D, int axis);      // per frame; axis 0 horizontal, 1 vertical
 void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase = 0);
 void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames);

@@ -55,6 +55,7 @@
 #include "fsgm_device.h"
 #include "epi_wta_tail.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace fsgm {
 
@@ -138,7 +139,7 @@ __device__ __forceinline__ LaneSel lane_sel(const int j) {
 // One DP step (calc_cost_sgm.cpp:33-66) in the mirrored variable, see the header.  S: previous pixel's state
 // s = P2 - min(L - m, P2), replaced by the new pixel's; Y: y = P2 - (L_new - C) of the new pixel, in [0, P2].
 // A path start (:152-180) = S preset to P2 in every element and mmask = 0 (the stored minimum is 0 there, :154).
-template <int LPP>
+template <int LPP, bool MASKED = true>
 __device__ __forceinline__ void step_s(uint32_t (&S)[8], const uint32_t (&CP)[8], uint32_t (&Y)[8], const uint32_t P1pk,
                                        const uint32_t P2, const LaneSel sel, const uint32_t mmask) {
     uint32_t T[8], N[8];
@@ -157,7 +158,8 @@ __device__ __forceinline__ void step_s(uint32_t (&S)[8], const uint32_t (&CP)[8]
     }
     const uint32_t mm = pk_min(pk_min3(N[0], N[1], N[2]), pk_min3(N[3], N[4], pk_min3(N[5], N[6], N[7])));
     uint32_t mx = group_min_u32<LPP>(min_halves(mm));
-    const uint32_t p2m = ((mx & mmask) + P2) * 0x10001u;
+    if (MASKED) mx &= mmask;
+    const uint32_t p2m = __umul24(mx, 0x10001u) + P2 * 0x10001u;     // (P2 + m) in both halves: one v_mad_u32_u24
 #pragma unroll
     for (int i = 0; i < 8; i++) S[i] = pk_subs(p2m, N[i]);
 }
@@ -203,16 +205,23 @@ __device__ __forceinline__ void wta_row_record(const uint32_t (&ST)[8], uint32_t
 //   MODE 2: point-mirrored frame, final: S = 8*(C + P2) - (Y_up + Y_dn + Y_h) in registers,
 //           WTA per pixel, writes one record {best, minC, S[best-1], S[best+1]} + S[0] per pixel.
 // =============================================================================================
-template <int LPP, int MODE, int NWV>
+template <int LPP, int MODE, int NWV, int GPW>
 __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     constexpr bool UP = MODE != 0;
-    constexpr int PXW = 64 / LPP;            // columns per wave
+    constexpr int PXG = 64 / LPP;            // columns per pixel group (one wave-wide DP step)
+    constexpr int PXW = GPW * PXG;           // own columns per wave: GPW groups, each with its three paths, + one halo group
     constexpr int D = LPP * 16;
     constexpr int STRIP = NWV * PXW;         // own columns per workgroup
-    constexpr int T = (NWV / 2) * PXW;       // halo width = max rows per launch (one halo step per wave per row)
-    constexpr int NCOL = STRIP + 2 * T + 2;  // LDS columns: forward column x  <->  index x - (a0 - T - 1)
-    constexpr int PF = MODE == 2 ? 2 : 3;    // rows of C in flight per lane
-    __shared__ uint4 sDiag[2][2][NCOL * LPP];    // [row parity][0: from above-left, 1: from above-right][column][lane-of-pixel]
+    constexpr int T = (NWV / 2) * PXG;       // halo width = max rows per launch (one halo step per wave per row)
+    // LDS: the diagonal states of one row, as the registers hold them (2 x u16 per dword: no packing on the way), in two
+    // planes of 16 bytes per lane (registers 0-3 / 4-7) so that both are conflict-free b128 accesses.  From-above-left
+    // states live on columns [a0-T-1, a0+STRIP), from-above-right states on [a0, a0+STRIP+T]: NCD columns each.
+    // (L16; the final sweep, whose WTA rows take 8 KB more, and the two-group form keep them packed to bytes in one
+    // plane instead -- 12 more instructions per diagonal step, but one more workgroup per CU)
+    constexpr int NCD = STRIP + T + 1;
+    constexpr bool L16 = MODE != 2 && GPW == 1;
+    constexpr int PF = MODE == 2 ? 2 : (GPW > 1 ? 2 : 3);    // rows of C in flight per lane and group
+    __shared__ uint4 sDiag[2][2][L16 ? 2 : 1][NCD * LPP];  // [row parity][direction][plane][column][lane-of-pixel]
     __shared__ uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 1];   // MODE 2: S of the wave's pixels (u16)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -234,26 +243,31 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     const uint8_t* __restrict__ StIn = a.state_in + f * a.state_frame_stride;    // [3][W][D] u8, written by the previous launch
     uint8_t* __restrict__ StOut = a.state_out + f * a.state_frame_stride;        // other buffer: no launch reads what it writes
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
-    const uint4 startP = make_uint4(P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u);   // s = P2 everywhere: a path start
     const int y0 = a.y0, rows = min(a.rows, H - y0);
     const bool first_block = y0 == 0;
     const LaneSel sel = lane_sel<LPP>(j);
 
-    // columns in the (possibly mirrored) sweep frame
-    const int gx = a0 + wave * PXW + g;                          // own column
-    const bool own_ok = gx < W;
-    const int gxc = min(gx, W - 1);
+    // columns in the (possibly mirrored) sweep frame: own group q holds column gx0 + q * PXG
+    const int gx0 = a0 + wave * PXW + g;
     // halo unit of this wave: waves 0,1 -> from-above-left on the T columns left of the strip,
     //                         waves 2,3 -> from-above-right on the T columns right of it
     const int hdir = wave >= NWV / 2 ? 1 : 0;
-    const int hx = hdir == 0 ? a0 - T + wave * PXW + g : a0 + STRIP + (wave - NWV / 2) * PXW + g;
+    const int hx = hdir == 0 ? a0 - T + wave * PXG + g : a0 + STRIP + (wave - NWV / 2) * PXG + g;
     const bool halo_ok = hx >= 0 && hx < W;
     const int hxc = min(max(hx, 0), W - 1);
-    const int lbase = a0 - T - 1;                                // forward column of LDS index 0
+    const int base0 = a0 - T - 1, base1 = a0;                    // forward column of LDS column 0, per direction
     // a diagonal restarts where it enters the image (:156-180): its predecessor column -1 / W holds the start state
     // (never overwritten: stores of columns outside the image are skipped) and the stored minimum is masked to 0
-    const uint32_t mask_dl = gx == 0 ? 0u : 0xFFFFu, mask_dr = gx == W - 1 ? 0u : 0xFFFFu;
     const uint32_t mask_h = (hdir == 0 ? hx == 0 : hx == W - 1) ? 0u : 0xFFFFu;
+    uint32_t mask_dl[GPW], mask_dr[GPW];
+    bool plain = mask_h != 0u;
+#pragma unroll
+    for (int q = 0; q < GPW; q++) {
+        mask_dl[q] = gx0 + q * PXG == 0 ? 0u : 0xFFFFu;
+        mask_dr[q] = gx0 + q * PXG == W - 1 ? 0u : 0xFFFFu;
+        plain = plain && mask_dl[q] != 0u && mask_dr[q] != 0u;
+    }
+    const bool wave_plain = __all(plain);                        // no lane of this wave ever starts a diagonal below row 0
 
     auto pix_of = [&](int x, int y) -> int {                     // actual pixel index of sweep-frame (x,y)
         const int p = y * W + x;
@@ -262,97 +276,133 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     auto vox_off = [&](int x, int y) -> uint32_t {               // byte offset of (x,y)'s 16 bytes of this lane
         return (uint32_t)pix_of(x, y) * D + (uint32_t)j * 16;
     };
+    auto lds_get = [&](int par, int dir, int col, uint32_t (&S)[8]) {
+        if (L16) {
+            const uint4 lo = sDiag[par][dir][0][col * LPP + j], hi = sDiag[par][dir][L16 ? 1 : 0][col * LPP + j];
+            S[0] = lo.x; S[1] = lo.y; S[2] = lo.z; S[3] = lo.w; S[4] = hi.x; S[5] = hi.y; S[6] = hi.z; S[7] = hi.w;
+        } else {
+            unpack_p(sDiag[par][dir][0][col * LPP + j], S);
+        }
+    };
+    auto lds_put = [&](int par, int dir, int col, const uint32_t (&S)[8]) {
+        if (L16) {
+            sDiag[par][dir][0][col * LPP + j] = make_uint4(S[0], S[1], S[2], S[3]);
+            sDiag[par][dir][L16 ? 1 : 0][col * LPP + j] = make_uint4(S[4], S[5], S[6], S[7]);
+        } else {
+            sDiag[par][dir][0][col * LPP + j] = pack_p(S);
+        }
+    };
 
     // ---- block prologue: path states of the row above (from the previous launch; start states above row 0) ----
-    uint32_t VS[8];
-    if (first_block) {
+    uint32_t VS[GPW][8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) VS[i] = P2pk;
-    } else {
-        unpack_p(*(const uint4*)(StIn + (size_t)gxc * D + j * 16), VS);
+    for (int q = 0; q < GPW; q++) {
+        if (first_block) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) VS[q][i] = P2pk;
+        } else {
+            unpack_p(*(const uint4*)(StIn + (size_t)min(gx0 + q * PXG, W - 1) * D + j * 16), VS[q]);
+        }
     }
-    for (int i = tid; i < 2 * NCOL * LPP; i += NWV * 64) {
-        const int dir = i / (NCOL * LPP), r = i - dir * (NCOL * LPP);
+    for (int i = tid; i < 2 * NCD * LPP; i += NWV * 64) {
+        const int dir = i / (NCD * LPP), r = i - dir * (NCD * LPP);
         const int c = r / LPP, jj = r - c * LPP;
-        const int x = lbase + c;
+        const int x = (dir ? base1 : base0) + c;
         const bool inside = x >= 0 && x < W;
-        uint4 v = startP;
-        if (inside && !first_block) v = *(const uint4*)(StIn + ((size_t)(1 + dir) * W + x) * D + jj * 16);
-        sDiag[0][dir][r] = v;
-        sDiag[1][dir][r] = v;                                    // columns outside the image keep the start state in both buffers
+        uint4 pk = make_uint4(P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u);   // the start state, packed
+        if (inside && !first_block) pk = *(const uint4*)(StIn + ((size_t)(1 + dir) * W + x) * D + jj * 16);
+        if (L16) {
+            uint32_t S[8];
+            unpack_p(pk, S);
+            const uint4 lo = make_uint4(S[0], S[1], S[2], S[3]), hi = make_uint4(S[4], S[5], S[6], S[7]);
+            sDiag[0][dir][0][r] = lo; sDiag[0][dir][L16 ? 1 : 0][r] = hi;
+            sDiag[1][dir][0][r] = lo; sDiag[1][dir][L16 ? 1 : 0][r] = hi;     // columns outside the image keep the start state in both buffers
+        } else {
+            sDiag[0][dir][0][r] = pk;
+            sDiag[1][dir][0][r] = pk;
+        }
     }
     __syncthreads();
 
-    uint4 ringOwn[PF], ringHalo[PF];
+    const uint8_t* __restrict__ Lhf = MODE == 2 ? a.Lh + f * a.lh_frame_stride : nullptr;
+    // rows in flight per lane: C of the own groups and of the halo group; MODE 2: the other partial sums of the own
+    // pixels (Y_dn, Y_h) as well -- all requested PF rows ahead, so no row waits for HBM
+    uint4 ringOwn[GPW][PF], ringHalo[PF], ringX[MODE == 2 ? GPW : 1][PF], ringH[MODE == 2 ? GPW : 1][PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) {
         const int y = min(y0 + i, H - 1);
-        ringOwn[i] = *(const uint4*)(Cf + vox_off(gxc, y));
+#pragma unroll
+        for (int q = 0; q < GPW; q++) {
+            const uint32_t off = vox_off(min(gx0 + q * PXG, W - 1), y);
+            ringOwn[q][i] = *(const uint4*)(Cf + off);
+            if (MODE == 2) { ringX[q][i] = *(const uint4*)(Xf + off); ringH[q][i] = *(const uint4*)(Lhf + off); }
+        }
         ringHalo[i] = *(const uint4*)(Cf + vox_off(hxc, y));
     }
 
-    const uint8_t* __restrict__ Lhf = MODE == 2 ? a.Lh + f * a.lh_frame_stride : nullptr;
-
-    // one row of the block: 4 DP steps per wave, one barrier
-    auto do_row = [&](const int k, const uint4 cOwn, const uint4 cHalo) {
+    // one row of the block: 3 * GPW + 1 DP steps per wave, one barrier.  MASKED: a row in which a path of this wave
+    // starts (row 0; waves at an image border): the stored minima go through their masks.
+    auto do_row = [&](const int k, const uint4 (&cOwn)[GPW], const uint4 cHalo, const uint4 (&curX)[GPW], const uint4 (&curH)[GPW], auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const int y = y0 + k, par = k & 1;
         const uint32_t tmask = y == 0 ? 0u : 0xFFFFu;            // row 0: every path starts (:152-180)
-        // MODE 2: the other partial sums of the own pixel; issued now, consumed after the four DP
-        // steps of this row, which hide most of their latency
-        uint4 curX, curH;
-        if (MODE == 2) {
-            const uint32_t off = vox_off(gxc, y);
-            curX = *(const uint4*)(Xf + off);
-            curH = *(const uint4*)(Lhf + off);
-        }
-        uint32_t CP[8], Y[8], YS[8];
-        unpack_c(cOwn, CP, P2pk);
-
-        // from above (0,+1)                                            calc_cost_sgm.cpp:193-202
-        step_s<LPP>(VS, CP, YS, P1pk, P2, sel, tmask);
-
-        // from above-left (+1,+1): predecessor column gx-1                        :205-213
-        {
-            uint32_t S[8];
-            unpack_p(sDiag[par][0][(gx - 1 - lbase) * LPP + j], S);
-            step_s<LPP>(S, CP, Y, P1pk, P2, sel, mask_dl & tmask);
-            if (own_ok) sDiag[par ^ 1][0][(gx - lbase) * LPP + j] = pack_p(S);
 #pragma unroll
-            for (int q = 0; q < 8; q++) YS[q] += Y[q];
-        }
-        // from above-right (-1,+1): predecessor column gx+1                       :215-225
-        {
-            uint32_t S[8];
-            unpack_p(sDiag[par][1][(gx + 1 - lbase) * LPP + j], S);
-            step_s<LPP>(S, CP, Y, P1pk, P2, sel, mask_dr & tmask);
-            if (own_ok) sDiag[par ^ 1][1][(gx - lbase) * LPP + j] = pack_p(S);
+        for (int q = 0; q < GPW; q++) {
+            const int gx = gx0 + q * PXG;
+            const bool own_ok = gx < W;
+            uint32_t CP[8], Y[8], YS[8];
+            unpack_c(cOwn[q], CP, P2pk);
+
+            // from above (0,+1)                                            calc_cost_sgm.cpp:193-202
+            step_s<LPP, MASKED>(VS[q], CP, YS, P1pk, P2, sel, tmask);
+
+            // from above-left (+1,+1): predecessor column gx-1                        :205-213
+            {
+                uint32_t S[8];
+                lds_get(par, 0, gx - 1 - base0, S);
+                step_s<LPP, MASKED>(S, CP, Y, P1pk, P2, sel, mask_dl[q] & tmask);
+                if (own_ok) lds_put(par ^ 1, 0, gx - base0, S);
 #pragma unroll
-            for (int q = 0; q < 8; q++) YS[q] += Y[q];
+                for (int i = 0; i < 8; i++) YS[i] += Y[i];
+            }
+            // from above-right (-1,+1): predecessor column gx+1                       :215-225
+            {
+                uint32_t S[8];
+                lds_get(par, 1, gx + 1 - base1, S);
+                step_s<LPP, MASKED>(S, CP, Y, P1pk, P2, sel, mask_dr[q] & tmask);
+                if (own_ok) lds_put(par ^ 1, 1, gx - base1, S);
+#pragma unroll
+                for (int i = 0; i < 8; i++) YS[i] += Y[i];
+            }
+            if (MODE != 2) {
+                // sum of this sweep's three y, one byte per voxel (3*P2 <= 255)      :227-232
+                if (own_ok) *(uint4*)(Xf + vox_off(gx, y)) = pack_p(YS);
+            } else {
+                // S = 8*(C + P2) - (Y_up (registers) + Y_dn + Y_h), all at this pixel
+                uint32_t E2[8], ST[8];
+                unpack_p(curX[q], E2);
+#pragma unroll
+                for (int i = 0; i < 8; i++) YS[i] += E2[i];
+                unpack_p(curH[q], E2);
+#pragma unroll
+                for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], 0x00080008u, 0u), pk_add(YS[i], E2[i]));
+                wta_row_record<LPP>(ST, sRow, tid, j, own_ok, a.rec, a.s0, f * (size_t)NP + pix_of(min(gx, W - 1), y));
+            }
         }
         // halo unit: keeps the inward-flowing diagonal correct for the next rows
         {
-            uint32_t HP[8], S[8];
+            uint32_t HP[8], S[8], Y[8];
             unpack_c(cHalo, HP, P2pk);
             const int px = hdir == 0 ? hx - 1 : hx + 1;
-            unpack_p(sDiag[par][hdir][(px - lbase) * LPP + j], S);
-            step_s<LPP>(S, HP, Y, P1pk, P2, sel, mask_h & tmask);
-            if (halo_ok) sDiag[par ^ 1][hdir][(hx - lbase) * LPP + j] = pack_p(S);
-        }
-        if (MODE != 2) {
-            // sum of this sweep's three y, one byte per voxel (3*P2 <= 255)      :227-232
-            if (own_ok) *(uint4*)(Xf + vox_off(gx, y)) = pack_p(YS);
-        } else {
-            // S = 8*(C + P2) - (Y_up (registers) + Y_dn + Y_h), all at this pixel
-            uint32_t E2[8], ST[8];
-            unpack_p(curX, E2);
-#pragma unroll
-            for (int q = 0; q < 8; q++) YS[q] += E2[q];
-            unpack_p(curH, E2);
-#pragma unroll
-            for (int q = 0; q < 8; q++) ST[q] = pk_sub(pk_mad16(CP[q], 0x00080008u, 0u), pk_add(YS[q], E2[q]));
-            wta_row_record<LPP>(ST, sRow, tid, j, own_ok, a.rec, a.s0, f * (size_t)NP + pix_of(gx, y));
+            lds_get(par, hdir, px - (hdir ? base1 : base0), S);
+            step_s<LPP, MASKED>(S, HP, Y, P1pk, P2, sel, mask_h & tmask);
+            if (halo_ok) lds_put(par ^ 1, hdir, hx - (hdir ? base1 : base0), S);
         }
         __syncthreads();                                         // diagonal states of row y visible to row y+1
+    };
+    auto row = [&](const int k, const uint4 (&cOwn)[GPW], const uint4 cHalo, const uint4 (&cX)[GPW], const uint4 (&cH)[GPW]) {
+        if (wave_plain && y0 + k > 0) do_row(k, cOwn, cHalo, cX, cH, std::false_type{});      // wave-uniform
+        else do_row(k, cOwn, cHalo, cX, cH, std::true_type{});
     };
 
     // steady state without branches so the prefetched rows stay in flight; then the tail
@@ -360,23 +410,255 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     for (; k0 + PF <= rows; k0 += PF) {
 #pragma unroll
         for (int i = 0; i < PF; i++) {
-            const uint4 cOwn = ringOwn[i], cHalo = ringHalo[i];
+            uint4 cOwn[GPW], cX[GPW], cH[GPW];
+            const uint4 cHalo = ringHalo[i];
             const int yn = min(y0 + k0 + i + PF, H - 1);
-            ringOwn[i] = *(const uint4*)(Cf + vox_off(gxc, yn));
+#pragma unroll
+            for (int q = 0; q < GPW; q++) {
+                const uint32_t off = vox_off(min(gx0 + q * PXG, W - 1), yn);
+                cOwn[q] = ringOwn[q][i];
+                ringOwn[q][i] = *(const uint4*)(Cf + off);
+                if (MODE == 2) {
+                    cX[q] = ringX[q][i]; cH[q] = ringH[q][i];
+                    ringX[q][i] = *(const uint4*)(Xf + off); ringH[q][i] = *(const uint4*)(Lhf + off);
+                }
+            }
             ringHalo[i] = *(const uint4*)(Cf + vox_off(hxc, yn));
-            do_row(k0 + i, cOwn, cHalo);
+            row(k0 + i, cOwn, cHalo, cX, cH);
         }
     }
 #pragma unroll
     for (int i = 0; i < PF - 1; i++)
-        if (k0 + i < rows) do_row(k0 + i, ringOwn[i], ringHalo[i]);   // block-uniform
+        if (k0 + i < rows) {                                     // block-uniform
+            uint4 cOwn[GPW], cX[GPW], cH[GPW];
+#pragma unroll
+            for (int q = 0; q < GPW; q++) { cOwn[q] = ringOwn[q][i]; if (MODE == 2) { cX[q] = ringX[q][i]; cH[q] = ringH[q][i]; } }
+            row(k0 + i, cOwn, ringHalo[i], cX, cH);
+        }
 
     // ---- block epilogue: states of the last row for the next launch ----
-    if (y0 + rows < H && own_ok) {
+    if (y0 + rows < H) {
         const int par = rows & 1;                                // buffer the last row wrote into
-        *(uint4*)(StOut + (size_t)gx * D + j * 16) = pack_p(VS);
-        *(uint4*)(StOut + ((size_t)W + gx) * D + j * 16) = sDiag[par][0][(gx - lbase) * LPP + j];
-        *(uint4*)(StOut + ((size_t)2 * W + gx) * D + j * 16) = sDiag[par][1][(gx - lbase) * LPP + j];
+#pragma unroll
+        for (int q = 0; q < GPW; q++) {
+            const int gx = gx0 + q * PXG;
+            if (gx < W) {
+                uint32_t S[8];
+                *(uint4*)(StOut + (size_t)gx * D + j * 16) = pack_p(VS[q]);
+                lds_get(par, 0, gx - base0, S);
+                *(uint4*)(StOut + ((size_t)W + gx) * D + j * 16) = pack_p(S);
+                lds_get(par, 1, gx - base1, S);
+                *(uint4*)(StOut + ((size_t)2 * W + gx) * D + j * 16) = pack_p(S);
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// strip kernel: a whole sweep (all rows) in ONE launch, without the halo.
+//
+// In the skewed column u = x + y all three paths of a sweep take their predecessor from the left or from the same
+// column: from above (x, y-1) is column u-1, from above-left (x-1, y-1) is u-2, from above-right (x+1, y-1) is u itself.
+// A workgroup owns a strip of 4*PXG skewed columns (a parallelogram that moves one image column to the left per row)
+// and walks down all the rows it crosses: the from-above-right states never leave their registers, the other two shift
+// through LDS (one barrier per row, as in the block sweeps), and the only thing a strip needs from outside is, per
+// row, three states of its LEFT neighbour's last two columns.  The left neighbour hands them over through global
+// memory while both run: 3 x 16*LPP bytes per row, written once (write-through) and read once.  The hand-off needs no
+// flag, fence or ordering: path states are <= P2 <= 127, so the top bit of every byte is free, and the four top bits
+// of each dword carry a tag that changes from launch to launch -- every dword says by itself whether it is this
+// launch's; the reader polls (agent-scope loads) until all of its dwords do.
+// Progress: a workgroup takes its (strip, frame) from a ticket counter, strips in ascending order, so the strip it
+// waits for always holds an earlier ticket -- it is running or done, whatever the dispatch order or placement; every
+// wait is bounded and raises a.err instead of hanging.
+// Columns outside the image hold the path-start state (s = P2), so a diagonal that enters the image starts as the
+// reference's does (:156-180); waves whose columns are all at least 3 columns outside do nothing.
+// =============================================================================================
+__device__ __forceinline__ uint4 edge_load(const uint4* p) {
+    // two 8-byte agent-scope loads: served past the L1 and coherent across the XCDs' L2s
+    const unsigned long long lo = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ void edge_store(uint4* p, const uint4 v) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((unsigned long long*)p + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int LPP, int MODE, bool DEEP>
+__global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
+    constexpr bool UP = MODE != 0;
+    constexpr int PXG = 64 / LPP;            // columns per wave
+    constexpr int D = LPP * 16;
+    constexpr int STRIP = 4 * PXG;           // skewed columns per workgroup
+    constexpr int NSLOT = STRIP + 2;         // LDS slots: local skewed column lu <-> slot lu + 2 (slots 0, 1: the left neighbour's last two)
+    constexpr int PF = MODE == 2 ? 2 : 3;    // rows of C in flight per lane
+    constexpr int MARGIN = 2;                // columns outside the image that still run (to settle on the start state)
+    __shared__ uint4 sD[2][2][NSLOT * LPP];  // [row parity][0: from-above states, 1: from-above-left states][slot][lane-of-pixel]
+    __shared__ uint32_t sRow[MODE == 2 ? 4 * 64 * 8 : 1];
+    __shared__ uint32_t sTicket;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane / LPP, j = lane % LPP;
+    const int W = a.W, H = a.H, NP = W * H;
+    if (tid == 0) sTicket = atomicAdd(a.ticket, 1u) - a.ticket_base;
+    __syncthreads();
+    const uint32_t ticket = __builtin_amdgcn_readfirstlane(sTicket);
+    const int k = (int)(ticket / (uint32_t)a.frames);           // strips in ascending order: the left neighbour (k-1, f) holds an earlier ticket
+    const size_t f = ticket % (uint32_t)a.frames;
+    if (k >= a.NS) return;
+    const int u0 = k * STRIP;
+    // rows in which the strip has a column within MARGIN of the image: x = u - y, u in [u0, u0 + STRIP)
+    const int y_lo = max(0, u0 - (W - 1 + MARGIN)), y_hi = min(H - 1, u0 + STRIP - 1 + MARGIN);
+    if (y_lo > y_hi) return;
+    const int p_lo = max(0, u0 - STRIP - (W - 1 + MARGIN)), p_hi = min(H - 1, u0 - 1 + MARGIN);   // the same for strip k-1
+
+    const uint8_t* __restrict__ Cf = a.C + f * a.c_frame_stride;
+    uint8_t* __restrict__ Xf = a.X + f * a.x_frame_stride;
+    const uint8_t* __restrict__ Lhf = MODE == 2 ? a.Lh + f * a.lh_frame_stride : nullptr;
+    uint4* __restrict__ edgeOut = a.edge + (f * a.NS + k) * (size_t)H * (3 * LPP);
+    const uint4* __restrict__ edgeIn = a.edge + (f * a.NS + (k > 0 ? k - 1 : 0)) * (size_t)H * (3 * LPP);
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const uint4 startP = make_uint4(P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u);   // s = P2 everywhere: a path start
+    const uint32_t tag = a.tag;
+    const LaneSel sel = lane_sel<LPP>(j);
+    const int lu = wave * PXG + g;                               // local skewed column
+    const int ul = u0 + lu;
+
+    auto pix_of = [&](int x, int y) -> int { const int p = y * W + x; return UP ? NP - 1 - p : p; };
+    auto vox_off = [&](int x, int y) -> uint32_t { return (uint32_t)pix_of(x, y) * D + (uint32_t)j * 16; };
+    auto c_addr = [&](int y) -> const uint4* {                   // this lane's costs in row y (clamped into the image)
+        const int yc = min(y, H - 1);
+        return (const uint4*)(Cf + vox_off(min(max(ul - yc, 0), W - 1), yc));
+    };
+
+    // ---- prologue: every state is the start state ----
+    uint32_t VR[8];                                               // from-above-right path: stays in these lanes
+#pragma unroll
+    for (int i = 0; i < 8; i++) VR[i] = P2pk;
+    for (int i = tid; i < 2 * 2 * NSLOT * LPP; i += 256) (&sD[0][0][0])[i] = startP;
+    uint4 pubV = startP, pubD = startP;                           // wave 3: what the right neighbour reads (from-above / from-above-left of the last row done)
+    auto x_off = [&](int y) -> uint32_t { const int yc = min(y, H - 1); return vox_off(min(max(ul - yc, 0), W - 1), yc); };
+    uint4 ring[PF], ringX[MODE == 2 ? PF : 1], ringH[MODE == 2 ? PF : 1];    // C (and, MODE 2, Y_dn and Y_h) of the coming rows
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        ring[i] = *c_addr(y_lo + i);
+        if (MODE == 2) { ringX[i] = *(const uint4*)(Xf + x_off(y_lo + i)); ringH[i] = *(const uint4*)(Lhf + x_off(y_lo + i)); }
+    }
+    // wave 0, lanes 0 .. 3*LPP-1: the left neighbour's hand-off for the coming row, requested one row ahead
+    const bool edge_lane = wave == 0 && lane < 3 * LPP;
+    auto edge_wanted = [&](int yprev) -> bool { return k > 0 && yprev >= p_lo && yprev <= p_hi; };
+    // DEEP: PF rows ahead (the neighbour has to lead by that much before a request finds this launch's data) / else 1
+    constexpr int EPF = DEEP ? PF : 1;
+    uint4 nextB[EPF];
+#pragma unroll
+    for (int i = 0; i < EPF; i++) {
+        nextB[i] = startP;
+        if (edge_lane && edge_wanted(y_lo - 1 + i)) nextB[i] = edge_load(edgeIn + (size_t)(y_lo - 1 + i) * (3 * LPP) + lane);
+    }
+    __syncthreads();
+
+    auto fresh = [&](const uint4 v) -> bool { return (((v.x ^ tag) | (v.y ^ tag) | (v.z ^ tag) | (v.w ^ tag)) & 0x80808080u) == 0u; };
+
+    // one row of this wave's PXG columns; EDGE: row 0 or a column at / outside an image border (selects allowed, rare)
+    auto do_row = [&](const int y, const int par, const uint4 cw, const uint4 curX, const uint4 curH, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const int x = ul - y;
+        const bool inside = !EDGE || (x >= 0 && x < W);
+        const int xc = EDGE ? min(max(x, 0), W - 1) : x;
+        uint32_t CP[8], Y[8], YS[8], S[8];
+        unpack_c(cw, CP, P2pk);
+        const uint32_t top = EDGE && y == 0 ? 0u : 0xFFFFu;      // row 0: every path starts (:152-180)
+        // from above-right (-1,+1): predecessor (x+1, y-1) = this column one row earlier                 :215-225
+        step_s<LPP>(VR, CP, YS, P1pk, P2, sel, EDGE && x == W - 1 ? 0u : top);
+        // from above (0,+1): predecessor skewed column u-1                                               :193-202
+        unpack_p(sD[par][0][(lu + 1) * LPP + j], S);
+        step_s<LPP>(S, CP, Y, P1pk, P2, sel, top);
+        if (EDGE && !inside) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { S[i] = P2pk; VR[i] = P2pk; }
+        }
+        const uint4 sv = pack_p(S);
+        sD[par ^ 1][0][(lu + 2) * LPP + j] = sv;
+#pragma unroll
+        for (int i = 0; i < 8; i++) YS[i] += Y[i];
+        // from above-left (+1,+1): predecessor skewed column u-2                                         :205-213
+        unpack_p(sD[par][1][lu * LPP + j], S);
+        step_s<LPP>(S, CP, Y, P1pk, P2, sel, EDGE && x == 0 ? 0u : top);
+        if (EDGE && !inside) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) S[i] = P2pk;
+        }
+        const uint4 sd = pack_p(S);
+        sD[par ^ 1][1][(lu + 2) * LPP + j] = sd;
+#pragma unroll
+        for (int i = 0; i < 8; i++) YS[i] += Y[i];
+        pubV = sv; pubD = sd;
+        if (MODE != 2) {
+            if (inside) *(uint4*)(Xf + vox_off(xc, y)) = pack_p(YS);                                     // :227-232
+        } else {
+            uint32_t E2[8], ST[8];
+            unpack_p(curX, E2);
+#pragma unroll
+            for (int i = 0; i < 8; i++) YS[i] += E2[i];
+            unpack_p(curH, E2);
+#pragma unroll
+            for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], 0x00080008u, 0u), pk_add(YS[i], E2[i]));
+            wta_row_record<LPP>(ST, sRow, tid, j, inside, a.rec, a.s0, f * (size_t)NP + pix_of(xc, y));
+        }
+    };
+
+    // one row of the workgroup: hand-off in (wave 0), the wave's columns, hand-off out (wave 3), barrier
+    auto row = [&](const int y, const uint4 cw, const uint4 cX, const uint4 cH, uint4& nb) {
+        const int par = (y - y_lo) & 1;
+        // ---- wave 0: the left neighbour's states of row y-1 into slots 0 and 1 ----
+        if (edge_lane) {
+            uint4 b = startP;
+            if (edge_wanted(y - 1)) {
+                b = nb;
+                uint32_t spins = 0;
+                while (!a.nowait && !__all(fresh(b))) {           // over the lanes that take part in the hand-off
+                    if (++spins > (1u << 20)) { if (lane == 0) atomicOr(a.err, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    b = edge_load(edgeIn + (size_t)(y - 1) * (3 * LPP) + lane);
+                }
+                b.x &= 0x7F7F7F7Fu; b.y &= 0x7F7F7F7Fu; b.z &= 0x7F7F7F7Fu; b.w &= 0x7F7F7F7Fu;
+            }
+            // lane = s * LPP + jj: s = 0 from-above of the neighbour's last column, 1 / 2 from-above-left of its last but one / last
+            const int s_ = lane / LPP, jj = lane - s_ * LPP;
+            sD[par][s_ == 0 ? 0 : 1][(s_ == 1 ? 0 : 1) * LPP + jj] = b;
+            if (edge_wanted(y - 1 + EPF)) nb = edge_load(edgeIn + (size_t)(y - 1 + EPF) * (3 * LPP) + lane);   // for a later row, in flight meanwhile
+        }
+        const int xlo = u0 + wave * PXG - y, xhi = xlo + PXG - 1;   // this wave's image columns in row y
+        if (xhi >= -MARGIN && xlo <= W - 1 + MARGIN) {              // wave-uniform
+            if (y > 0 && xlo >= 1 && xhi <= W - 2) do_row(y, par, cw, cX, cH, std::false_type{});
+            else do_row(y, par, cw, cX, cH, std::true_type{});
+        }
+        // ---- wave 3: hand the last two columns' states of row y to the right neighbour ----
+        if (wave == 3 && g >= PXG - 2 && k + 1 < a.NS) {
+            uint4* o = edgeOut + (size_t)y * (3 * LPP);
+            if (g == PXG - 1) {
+                edge_store(o + 0 * LPP + j, make_uint4(pubV.x | tag, pubV.y | tag, pubV.z | tag, pubV.w | tag));
+                edge_store(o + 2 * LPP + j, make_uint4(pubD.x | tag, pubD.y | tag, pubD.z | tag, pubD.w | tag));
+            } else {
+                edge_store(o + 1 * LPP + j, make_uint4(pubD.x | tag, pubD.y | tag, pubD.z | tag, pubD.w | tag));
+            }
+        }
+        __syncthreads();                                            // states of row y visible to row y+1
+    };
+    for (int y = y_lo; y <= y_hi; y += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            if (y + i <= y_hi) {                                    // workgroup-uniform
+                const uint4 cw = ring[i];
+                ring[i] = *c_addr(y + i + PF);
+                uint4 cX = cw, cH = cw;
+                if (MODE == 2) {
+                    cX = ringX[i]; cH = ringH[i];
+                    ringX[i] = *(const uint4*)(Xf + x_off(y + i + PF)); ringH[i] = *(const uint4*)(Lhf + x_off(y + i + PF));
+                }
+                row(y + i, cw, cX, cH, nextB[DEEP ? i : 0]);
+            }
+        }
     }
 }
 
@@ -489,6 +771,9 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
     const int nl = AXIS ? a.W : a.H, len = AXIS ? a.H : a.W;
     const int lg = (int)blockIdx.x * 4 + wave;
     if (lg * PXW >= nl) return;                                 // wave-uniform
+    // the pair kernels are few waves with a long serial chain each (len steps): beside the sweeps' many waves they
+    // must not queue for issue slots, or the whole stage waits for them
+    if (a.prio == 3) __builtin_amdgcn_s_setprio(3); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
     const int l = min(lg * PXW + g, nl - 1);                    // lines past the last redo the last (same bytes, same addresses)
     const int NT = (len + HP_TC - 1) / HP_TC;
     if (NT < 2) return;                                         // a single tile starts at the border: no checkpoint
@@ -531,6 +816,7 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs a) {
     const int nl = AXIS ? a.W : a.H, len = AXIS ? a.H : a.W;
     const int lg = (int)blockIdx.x * 4 + wave;
     if (lg * PXW >= nl) return;
+    if (a.prio == 3) __builtin_amdgcn_s_setprio(3); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
     const bool own_ok = lg * PXW + g < nl;
     const int l = min(lg * PXW + g, nl - 1);
     const int NT = (len + TC - 1) / TC;
@@ -647,7 +933,14 @@ static void launch_pair_t(hipStream_t st, const PairArgs& a, int frames, int axi
 // One axis (0 horizontal, 1 vertical).  phase 0: checkpoint pass + sum pass; 1: checkpoint pass only;
 // 2: sum pass only (so that the caller can put an event between them).  final_pass: the sum pass adds
 // a.Xother and writes WTA records instead of Y.
-void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase) {
+static int pair_prio() {
+    static const int v = [] { const char* e = getenv("FSGM_PAIR_PRIO"); const int x = (e && *e) ? atoi(e) : 3; return x < 0 ? 0 : (x > 3 ? 3 : x); }();
+    return v;
+}
+
+void launch_pair(hipStream_t st, const PairArgs& a0, int frames, int axis, bool final_pass, int phase) {
+    PairArgs a = a0;
+    a.prio = pair_prio();
     switch (agg_packed_lpp(a.D)) {
         case 1: launch_pair_t<1>(st, a, frames, axis, final_pass, phase); break;
         case 2: launch_pair_t<2>(st, a, frames, axis, final_pass, phase); break;
@@ -667,10 +960,18 @@ void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool f
 int sweep_rows_per_launch(int D) { const int lpp = agg_packed_lpp(D); return lpp ? (FSGM_SWEEP_WAVES / 2) * (64 / lpp) : 0; }
 size_t sweep_state_bytes(int W, int D) { return (size_t)3 * W * D; }
 
-template <int LPP>
-static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode) {
+// FSGM_SWEEP_GPW: pixel groups per wave (1 or 2; A/B switch).  With 2 a wave owns 16 columns at D = 128 -- six own DP
+// steps and one halo step per row instead of three and one: the halo (and its cost unpack and LDS round trip) weighs
+// half as much, and the strips are 64 columns wide.
+static int sweep_gpw() {
+    static const int v = [] { const char* e = getenv("FSGM_SWEEP_GPW"); const int x = (e && *e) ? atoi(e) : 2; return x == 1 ? 1 : 2; }();
+    return v;
+}
+
+template <int LPP, int GPW>
+static void launch_sweep_g(hipStream_t st, SweepArgs a, int frames, int mode) {
     constexpr int NWV = FSGM_SWEEP_WAVES;
-    constexpr int STRIP = NWV * (64 / LPP), T = (NWV / 2) * (64 / LPP);
+    constexpr int STRIP = NWV * GPW * (64 / LPP), T = (NWV / 2) * (64 / LPP);
     dim3 grid((a.W + STRIP - 1) / STRIP, frames);
     uint8_t* const buf0 = a.state_out;                     // caller passes the base of 2 x frames x state buffers
     uint8_t* const buf1 = a.state_out + (size_t)frames * a.state_frame_stride;
@@ -680,10 +981,16 @@ static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode) {
         a.rows = T;
         a.state_in = b ? buf0 : buf1;
         a.state_out = b ? buf1 : buf0;
-        if (mode == 0)      hipLaunchKernelGGL((sweep_kernel<LPP, 0, NWV>), grid, dim3(NWV * 64), 0, st, a);
-        else if (mode == 1) hipLaunchKernelGGL((sweep_kernel<LPP, 1, NWV>), grid, dim3(NWV * 64), 0, st, a);
-        else                hipLaunchKernelGGL((sweep_kernel<LPP, 2, NWV>), grid, dim3(NWV * 64), 0, st, a);
+        if (mode == 0)      hipLaunchKernelGGL((sweep_kernel<LPP, 0, NWV, GPW>), grid, dim3(NWV * 64), 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((sweep_kernel<LPP, 1, NWV, GPW>), grid, dim3(NWV * 64), 0, st, a);
+        else                hipLaunchKernelGGL((sweep_kernel<LPP, 2, NWV, GPW>), grid, dim3(NWV * 64), 0, st, a);
     }
+}
+
+template <int LPP>
+static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode) {
+    if (sweep_gpw() == 2) launch_sweep_g<LPP, 2>(st, a, frames, mode);
+    else launch_sweep_g<LPP, 1>(st, a, frames, mode);
 }
 
 void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode) {
@@ -693,6 +1000,40 @@ void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode) {
         case 4: launch_sweep_t<4>(st, a, frames, mode); break;
         case 8: launch_sweep_t<8>(st, a, frames, mode); break;
         case 16: launch_sweep_t<16>(st, a, frames, mode); break;
+        default: break;
+    }
+}
+
+// One whole sweep of `frames` frames as one strip_kernel launch (mode 0 down, 1 up, 2 up + WTA).
+int strip_count(int W, int H, int D) { const int lpp = agg_packed_lpp(D); return lpp ? (W + H - 1 + 4 * (64 / lpp) - 1) / (4 * (64 / lpp)) : 0; }
+size_t strip_edge_uint4s(int W, int H, int D) { return (size_t)strip_count(W, H, D) * H * 3 * agg_packed_lpp(D); }   // per frame
+
+static int strip_deep() {
+    static const int v = [] { const char* e = getenv("FSGM_STRIP_DEEP"); return (e && *e) ? atoi(e) : 1; }();
+    return v;
+}
+
+template <int LPP>
+static void launch_strips_t(hipStream_t st, const StripArgs& a, int mode) {
+    dim3 grid((unsigned)(a.NS * a.frames));
+    if (strip_deep()) {
+        if (mode == 0)      hipLaunchKernelGGL((strip_kernel<LPP, 0, true>), grid, dim3(256), 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((strip_kernel<LPP, 1, true>), grid, dim3(256), 0, st, a);
+        else                hipLaunchKernelGGL((strip_kernel<LPP, 2, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (mode == 0)      hipLaunchKernelGGL((strip_kernel<LPP, 0, false>), grid, dim3(256), 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((strip_kernel<LPP, 1, false>), grid, dim3(256), 0, st, a);
+        else                hipLaunchKernelGGL((strip_kernel<LPP, 2, false>), grid, dim3(256), 0, st, a);
+    }
+}
+
+void launch_strips(hipStream_t st, const StripArgs& a, int mode) {
+    switch (agg_packed_lpp(a.D)) {
+        case 1: launch_strips_t<1>(st, a, mode); break;
+        case 2: launch_strips_t<2>(st, a, mode); break;
+        case 4: launch_strips_t<4>(st, a, mode); break;
+        case 8: launch_strips_t<8>(st, a, mode); break;
+        case 16: launch_strips_t<16>(st, a, mode); break;
         default: break;
     }
 }

@@ -1,0 +1,27 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+FSGM_EPI_STRIPS=0 timeout -k 10 300 python -m pytest tests/test_gpu_epi.py tests/test_gpu_fuzz.py -m gpu -x -q > gpurun_out/r02_pytest7.log 2>&1 || { tail -60 gpurun_out/r02_pytest7.log; exit 1; }
+tail -2 gpurun_out/r02_pytest7.log
+timeout -k 10 300 python -m pytest tests/test_gpu_epi.py -m gpu -x -q > gpurun_out/r02_pytest7b.log 2>&1 || { tail -60 gpurun_out/r02_pytest7b.log; exit 1; }
+tail -2 gpurun_out/r02_pytest7b.log
+python3 - <<'PY'
+import os, subprocess, json
+def run(env, frames=32):
+    e = dict(os.environ); e.update(env); e["FSGM_SWEEP_GPW"] = "1"
+    out = subprocess.run(["python3", "bench.py", "--no-cpu-baseline", "--frames-per-gpu", str(frames), "--steps", "15"], env=e, capture_output=True, text=True, timeout=300)
+    try:
+        d = json.loads(out.stdout.strip().split("\n")[-1])
+        print(env, frames, "ms_per_step %.3f stage %.3f frac %.4f checked %s" % (d["ms_per_step"], d["roofline"]["stage_ms"], d["roofline"]["frac"], d.get("checked")), flush=True)
+    except Exception as ex:
+        print(env, "FAILED", out.stderr[-300:], flush=True)
+run({"FSGM_EPI_STRIPS": "0", "FSGM_EPI_LANES": "2", "FSGM_EPI_PAIRSPLIT": "0"})
+run({"FSGM_EPI_STRIPS": "0", "FSGM_EPI_LANES": "2", "FSGM_EPI_PAIRSPLIT": "1"})
+run({"FSGM_EPI_STRIPS": "0", "FSGM_EPI_LANES": "3", "FSGM_EPI_PAIRSPLIT": "1"})
+run({"FSGM_EPI_STRIPS": "0", "FSGM_EPI_LANES": "2", "FSGM_EPI_PAIRSPLIT": "1"}, 48)
+run({"FSGM_EPI_STRIPS": "0", "FSGM_EPI_LANES": "2", "FSGM_EPI_PAIRSPLIT": "1"}, 64)
+run({"FSGM_EPI_STRIPS": "1", "FSGM_EPI_LANES": "1", "FSGM_STRIP_DEEP": "0"})
+run({"FSGM_EPI_STRIPS": "1", "FSGM_EPI_LANES": "2", "FSGM_STRIP_DEEP": "0", "FSGM_EPI_PAIRSPLIT": "1"})
+run({"FSGM_EPI_STRIPS": "1", "FSGM_EPI_LANES": "1", "FSGM_STRIP_DEEP": "0", "FSGM_STRIP_NOWAIT": "1", "FSGM_BENCH_NOCHECK": "1"})
+run({"FSGM_EPI_STRIPS": "1", "FSGM_EPI_LANES": "2", "FSGM_STRIP_DEEP": "0", "FSGM_STRIP_NOWAIT": "1", "FSGM_BENCH_NOCHECK": "1"})
+PY
