@@ -148,10 +148,18 @@ def pyramid3_ng(args):
         pyramidal_sgm_ng(I0, I1, 3)
     host_ms = (time.perf_counter() - t0) / iters * 1e3
     vp = sum(w * h for (w, h) in sizes) * 81 * 4
+    # throughput form: a batch of pairs resident, every kernel of a level covers all of them
+    batch = {}
+    for Bn in (4, 8, 16):
+        with NgPyramidPlan(W, H, 3, 3, batch=Bn) as plan:
+            for f in range(Bn):
+                plan.upload(np.roll(I0, 13 * f, axis=2), np.roll(I1, 13 * f, axis=2), frame=f)
+            ms = plan.time(1, max(2, iters // 2))
+        batch[str(Bn)] = {"ms_per_batch": ms, "ms_per_pair": ms / Bn, "pairs_per_s": Bn / (ms * 1e-3), "speedup_vs_sequential": total * Bn / ms}
     print(json.dumps({"metric": "pyramidal level loop with calc_pyd_cost_sgm_ng (3 levels), device time per image pair",
                       "value": total, "unit": "ms", "higher_is_better": False, "n_gpus": 1, "dtype": "u8", "data": "synthetic",
                       "config": {"workload": "pyramid 1242x375 / 621x188 / 311x94 RGB, 81 candidates per pixel, 4 paths, 2 passes"},
-                      "voxel_paths_per_s": vp / (total * 1e-3), "host_call_ms": host_ms}), flush=True)
+                      "voxel_paths_per_s": vp / (total * 1e-3), "host_call_ms": host_ms, "batched": batch}), flush=True)
 
 
 def postprocess(args):
@@ -194,6 +202,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-gpu", type=int, default=32)
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="strong scaling: a fixed batch of this many frames split over the ranks by fsgm_amd.batch.shard_indices "
+                         "(BASELINE config 5 literally = 8); default 0 = weak scaling with --frames-per-gpu frames on every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--paths", type=int, default=8, choices=[4, 8],
@@ -232,7 +243,11 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    B = args.frames_per_gpu
+    from fsgm_amd.batch import shard_indices
+    strong = args.total_frames > 0
+    my_frames = shard_indices(args.total_frames, rank, world) if strong else list(range(args.frames_per_gpu))
+    assert my_frames, f"rank {rank} of {world} gets no frame out of --total-frames {args.total_frames}"
+    B = len(my_frames)
     plan = EpiPlan(W, H, D, B, paths=PATHS, device=local_rank)
     plan.set_penalties(P1, P2, VMAX)
     _, _, off = synth.epi_maps(W, H, "axis")
@@ -293,7 +308,8 @@ def main():
     wta_ms = plan.time(STAGE_WTA, warmup=1, iters=max(3, args.steps // 2))
 
     if rank == 0:
-        voxel_paths_step = world * B * W * H * D * PATHS
+        total_frames = args.total_frames if strong else world * B
+        voxel_paths_step = total_frames * W * H * D * PATHS
         value = voxel_paths_step * args.steps / dt
         alg_bytes_launch = B * W * H * D * PATHS            # 1 byte of C per voxel-path
         achieved = alg_bytes_launch / (agg_ms * 1e-3) / 1e9
@@ -302,9 +318,9 @@ def main():
             "metric": f"aggregated cost-volume voxel-paths/s (HxWxDx{PATHS} paths), KITTI 1242x375 D=128",
             "value": value, "unit": "voxel-paths/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"KITTI 1242x375 D=128, {PATHS} paths, aggregation stage (C resident in HBM -> bestD/minC)",
-                       "frames_per_gpu": B, "P1": P1, "P2": P2, "kernel": plan.kernel_name,
+                       "frames_per_gpu": B, "total_frames": total_frames, "P1": P1, "P2": P2, "kernel": plan.kernel_name,
                        "step": f"aggregate({PATHS} paths) + sum/WTA/subpixel", "sharding": "frames, no collective"},
             # the aggregation is one stage of four kernel types that run concurrently on three streams
             # (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane; pair_ckpt_kernel<8,0> +
@@ -345,6 +361,28 @@ def main():
                 out[key] = {"ms_per_frame": all_ms / B, "frames_per_s": B / (all_ms * 1e-3),
                             "stages": f"census x2, cost fill, box, aggregate({PATHS} paths), WTA", "inputs": "resident in HBM",
                             "maps": "SURVEY 8(d) timing maps" if kind == "axis" else "random direction per pixel"}
+        if world == 1:
+            # the boundary as a MATLAB caller feels it: host pointers in, host pointers out (pageable memory, PCIe
+            # included; never `value`), one frame per call like epipolar_sgm_of.m:45, and 8 frames per call
+            from fsgm_amd import calc_cost_sgm, calc_cost_sgm_batch
+            plan.close()
+            I1, I2 = synth.image_pair(W, H, D, seed=3)
+            frames8 = [(I1, I2) + synth.epi_maps(W, H, "general", seed=40 + s) for s in range(8)]
+            f0 = frames8[0]
+            calc_cost_sgm(f0[0], f0[1], D, VMAX, f0[2], f0[3], f0[4], P1, P2, paths=PATHS)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                calc_cost_sgm(f0[0], f0[1], D, VMAX, f0[2], f0[3], f0[4], P1, P2, paths=PATHS)
+            one = (time.perf_counter() - t0) / 10 * 1e3
+            calc_cost_sgm_batch(frames8, D, VMAX, P1, P2, paths=PATHS)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                calc_cost_sgm_batch(frames8, D, VMAX, P1, P2, paths=PATHS)
+            eight = (time.perf_counter() - t0) / 3 * 1e3
+            bytes_frame = 2 * W * H + 5 * 8 * W * H + 2 * 4 * W * H
+            out["host_call_ms"] = {"one_frame": one, "eight_frames": eight, "ms_per_frame_in_batch": eight / 8,
+                                   "pcie_bytes_per_frame": bytes_frame,
+                                   "note": "fsgm_calc_cost_sgm(_batch)_host from pageable numpy buffers, whole call incl. H2D of 2 images + 5 fp64 map planes and D2H of bestD/minC"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(PATHS=PATHS)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(PATHS=PATHS)

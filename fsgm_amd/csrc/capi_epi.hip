@@ -382,6 +382,17 @@ static fsgm_status prepare(fsgm_epi_plan* p, int stages) {
     return FSGM_OK;
 }
 
+// census x2 + cost fill + box of frames [f0, f0 + nf) on the plan's stream (ensure_vz done by the caller)
+static void enqueue_cost(fsgm_epi_plan* p, int f0, int nf) {
+    const size_t NP = p->NP, o = (size_t)f0;
+    launch_census(p->stream, p->dI1 + o * NP, p->dCen1 + o * NP, p->W, p->H, nf);
+    launch_census(p->stream, p->dI2 + o * NP, p->dCen2 + o * NP, p->W, p->H, nf);
+    EpiCostArgs a;
+    a.cen1 = p->dCen1 + o * NP; a.cen2 = p->dCen2 + o * NP; a.pd0 = p->dPd0 + o * 2 * NP; a.nd = p->dNd + o * 2 * NP;
+    a.off = p->dOff + o * NP; a.vz = p->dVz; a.vzmax = p->vzmax; a.Craw = p->dCraw + o * p->N; a.W = p->W; a.H = p->H; a.D = p->D;
+    launch_epi_cost(p->stream, a, p->dC + o * p->N, nf);
+}
+
 static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
     {
         fsgm_status st = prepare(p, stages);
@@ -390,12 +401,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
     if (stages & FSGM_STAGE_COST) {
         fsgm_status st = ensure_vz(p);
         if (st != FSGM_OK) return st;
-        launch_census(p->stream, p->dI1, p->dCen1, p->W, p->H, p->batch);
-        launch_census(p->stream, p->dI2, p->dCen2, p->W, p->H, p->batch);
-        EpiCostArgs a;
-        a.cen1 = p->dCen1; a.cen2 = p->dCen2; a.pd0 = p->dPd0; a.nd = p->dNd; a.off = p->dOff;
-        a.vz = p->dVz; a.vzmax = p->vzmax; a.Craw = p->dCraw; a.W = p->W; a.H = p->H; a.D = p->D;
-        launch_epi_cost(p->stream, a, p->dC, p->batch);
+        enqueue_cost(p, 0, p->batch);
     }
     if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_SWEEP) {
         // One sweep launch (strips x frames workgroups) cannot fill 256 CUs, so the work is forked:
@@ -828,17 +834,38 @@ fsgm_status fsgm_calc_cost_sgm_batch_host(int32_t n, const fsgm_epi_in* in, cons
     fsgm_status st = cached_plan(&p, in[0].width, in[0].height, in[0].dMax, n, pr);
     if (st != FSGM_OK) return st;
     if ((st = fsgm_epi_plan_set_penalties(p, in[0].P1, in[0].P2, in[0].vMax)) != FSGM_OK) return st;
-    for (int i = 0; i < n; i++)
-        if ((st = fsgm_epi_plan_upload(p, i, in[i].I1, in[i].I2, in[i].pixelPosD0, in[i].normDir, in[i].offset)) != FSGM_OK)
-            return st;
-    if ((st = fsgm_epi_plan_run(p, FSGM_STAGE_ALL)) != FSGM_OK) return st;
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    // One call = one stream-ordered sequence with a single host wait: every frame's inputs go up asynchronously on the
+    // plan's stream (hipMemcpyAsync from the caller's pageable memory runs at the pinned rate here, ~50 GB/s, so there is
+    // no staging copy: tools/ubench/h2d_rates.hip), the batched kernels follow, the results come down at the end.
+    // Measured alternatives that lost (A/B on one box): uploads on a second stream with each frame's cost stage started
+    // as the frame arrives -- the per-frame launches cost more than the overlap saves (1.29 vs 1.20 ms for one
+    // 1242x375x128 frame, 9.2 vs 7.9 ms for eight); a pinned staging ring (an extra host copy at 25-34 GB/s).
+    StreamGuard guard(p->stream);                                // every early exit drains the stream: the copies use caller memory
+    const size_t NP = p->NP;
     for (int i = 0; i < n; i++) {
-        if ((st = fsgm_epi_plan_download(p, i, out[i].bestD, out[i].minC)) != FSGM_OK) return st;
-        if (pr.fb_check && (out[i].conf || out[i].bestD2) &&
-            (st = fsgm_epi_plan_download_fb(p, i, out[i].conf, out[i].bestD2)) != FSGM_OK) return st;
-        if (out[i].C && (st = fsgm_epi_plan_download_cost(p, i, out[i].C)) != FSGM_OK) return st;
-        if (out[i].S && (st = fsgm_epi_plan_download_sum(p, i, out[i].S)) != FSGM_OK) return st;
+        FSGM_HIP(hipMemcpyAsync(p->dI1 + i * NP, in[i].I1, NP, hipMemcpyHostToDevice, p->stream));
+        FSGM_HIP(hipMemcpyAsync(p->dI2 + i * NP, in[i].I2, NP, hipMemcpyHostToDevice, p->stream));
+        FSGM_HIP(hipMemcpyAsync(p->dPd0 + (size_t)i * 2 * NP, in[i].pixelPosD0, NP * 16, hipMemcpyHostToDevice, p->stream));
+        FSGM_HIP(hipMemcpyAsync(p->dNd + (size_t)i * 2 * NP, in[i].normDir, NP * 16, hipMemcpyHostToDevice, p->stream));
+        FSGM_HIP(hipMemcpyAsync(p->dOff + i * NP, in[i].offset, NP * 8, hipMemcpyHostToDevice, p->stream));
     }
+    if ((st = run_stages(p, FSGM_STAGE_ALL)) != FSGM_OK) return st;
+    bool taps = false;
+    for (int i = 0; i < n; i++) {
+        FSGM_HIP(hipMemcpyAsync(out[i].bestD, p->dBestD + i * NP, NP * 4, hipMemcpyDeviceToHost, p->stream));
+        FSGM_HIP(hipMemcpyAsync(out[i].minC, p->dMinC + i * NP, NP * 4, hipMemcpyDeviceToHost, p->stream));
+        if (pr.fb_check && out[i].conf) FSGM_HIP(hipMemcpyAsync(out[i].conf, p->dConf + i * NP, NP, hipMemcpyDeviceToHost, p->stream));
+        if (pr.fb_check && out[i].bestD2) FSGM_HIP(hipMemcpyAsync(out[i].bestD2, p->dD2 + i * NP, NP * 4, hipMemcpyDeviceToHost, p->stream));
+        if (out[i].C) FSGM_HIP(hipMemcpyAsync(out[i].C, p->dC + (size_t)i * p->N, p->N, hipMemcpyDeviceToHost, p->stream));
+        taps = taps || out[i].S;
+    }
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
+    if ((st = check_handoff(p)) != FSGM_OK) return st;
+    if (taps)
+        for (int i = 0; i < n; i++)
+            if (out[i].S && (st = fsgm_epi_plan_download_sum(p, i, out[i].S)) != FSGM_OK) return st;
     return FSGM_OK;
 }
 

@@ -15,6 +15,7 @@ using namespace fsgm;
 
 struct fsgm_ng_pyramid_plan {
     int W = 0, H = 0, channels = 1, device = 0, D = 0;
+    int batch = 1;                                   // image pairs resident at once: every buffer below holds `batch` frames, frame-major
     fsgm_ng_pyramid_params prm{};
     std::vector<int> Ws, Hs;                         // level l (0-based) size
     std::vector<uint8_t*> dP0, dP1;                  // colour pyramids [3][h][w] (channels == 3 only)
@@ -59,8 +60,14 @@ void fsgm_ng_pyramid_plan_destroy(fsgm_ng_pyramid_plan* p) {
 
 fsgm_status fsgm_ng_pyramid_plan_create(fsgm_ng_pyramid_plan** out, int32_t W, int32_t H, int32_t channels,
                                         const fsgm_ng_pyramid_params* prm) {
+    return fsgm_ng_pyramid_plan_create_batch(out, W, H, channels, 1, prm);
+}
+
+fsgm_status fsgm_ng_pyramid_plan_create_batch(fsgm_ng_pyramid_plan** out, int32_t W, int32_t H, int32_t channels, int32_t batch,
+                                              const fsgm_ng_pyramid_params* prm) {
     FSGM_REQUIRE(out, "fsgm_ng_pyramid_plan_create: null plan pointer");
     *out = nullptr;
+    FSGM_REQUIRE(batch >= 1 && batch <= 1024, "batch must be in 1..1024 (got %d)", batch);
     FSGM_REQUIRE(prm, "fsgm_ng_pyramid_plan_create: null parameters");
     FSGM_REQUIRE(W >= 1 && H >= 1, "width/height must be >= 1 (got %d x %d)", W, H);
     FSGM_REQUIRE(channels == 1 || channels == 3, "channels must be 1 (gray) or 3 (RGB planes), got %d", channels);
@@ -69,13 +76,14 @@ fsgm_status fsgm_ng_pyramid_plan_create(fsgm_ng_pyramid_plan** out, int32_t W, i
     const long long D = 9LL * (2 * prm->halfSearchWinSize + 1) * (2 * prm->halfSearchWinSize + 1);
     if (D > FSGM_NG_MAX_D) return fail(FSGM_ERR_UNSUPPORTED, "%lld candidates per pixel exceed %d", D, FSGM_NG_MAX_D);
     if ((double)W * H * D >= 2147483648.0) return fail(FSGM_ERR_UNSUPPORTED, "candidate volume exceeds 2^31 entries");
+    const size_t B = (size_t)batch;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(FSGM_ERR_HIP, "no HIP device available (libfsgm_hip has no CPU fallback)");
     FSGM_REQUIRE(prm->device >= 0 && prm->device < ndev, "device %d out of range (have %d)", prm->device, ndev);
     FSGM_HIP(hipSetDevice(prm->device));
     fsgm_ng_pyramid_plan* p = new fsgm_ng_pyramid_plan;
-    p->W = W; p->H = H; p->channels = channels; p->device = prm->device; p->prm = *prm; p->D = (int)D;
+    p->W = W; p->H = H; p->channels = channels; p->device = prm->device; p->prm = *prm; p->D = (int)D; p->batch = batch;
     const int n = prm->numPyd;
     p->Ws.resize(n); p->Hs.resize(n); p->mvW.resize(n); p->mvH.resize(n);
     p->Ws[0] = W; p->Hs[0] = H;
@@ -92,24 +100,24 @@ fsgm_status fsgm_ng_pyramid_plan_create(fsgm_ng_pyramid_plan** out, int32_t W, i
         p->mvH[l] = l == n - 1 ? p->Hs[l] : 2 * p->Hs[l + 1];
         const size_t np = (size_t)p->Ws[l] * p->Hs[l], mv = (size_t)p->mvW[l] * p->mvH[l];
         if (channels == 3) {
-            e = hipMalloc((void**)&p->dP0[l], 3 * np);
-            if (e == hipSuccess) e = hipMalloc((void**)&p->dP1[l], 3 * np);
+            e = hipMalloc((void**)&p->dP0[l], B * 3 * np);
+            if (e == hipSuccess) e = hipMalloc((void**)&p->dP1[l], B * 3 * np);
         }
-        if (e == hipSuccess) e = hipMalloc((void**)&p->dG0[l], np);
-        if (e == hipSuccess) e = hipMalloc((void**)&p->dG1[l], np);
-        if (e == hipSuccess) e = hipMalloc((void**)&p->dMv[l], 2 * mv * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void**)&p->dFlow[l], 2 * np * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void**)&p->dMinC[l], np * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dG0[l], B * np);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dG1[l], B * np);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dMv[l], B * 2 * mv * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dFlow[l], B * 2 * np * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dMinC[l], B * np * 4);
     }
     const size_t NP = (size_t)W * H, N = NP * (size_t)D;
-    if (e == hipSuccess) e = hipMalloc((void**)&p->dCen1, NP * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->dCen2, NP * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->dC, N * sizeof(Cand));
-    if (e == hipSuccess) e = hipMalloc((void**)&p->dS, N * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dCen1, B * NP * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dCen2, B * NP * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dC, B * N * sizeof(Cand));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dS, B * N * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dUnsafe, 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->dDd, N * 2);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->dDk, NP);
-    if (e == hipSuccess) e = hipMemset(p->dMv[n - 1], 0, 2 * (size_t)p->mvW[n - 1] * p->mvH[n - 1] * sizeof(double));   // :34
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dDd, B * N * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dDk, B * NP);
+    if (e == hipSuccess) e = hipMemset(p->dMv[n - 1], 0, B * 2 * (size_t)p->mvW[n - 1] * p->mvH[n - 1] * sizeof(double));   // :34
     if (e != hipSuccess) {
         fsgm_ng_pyramid_plan_destroy(p);
         return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP, "fsgm_ng_pyramid_plan_create: %s", hipGetErrorString(e));
@@ -125,56 +133,68 @@ fsgm_status fsgm_ng_pyramid_plan_level_size(fsgm_ng_pyramid_plan* p, int32_t lev
     return FSGM_OK;
 }
 
-fsgm_status fsgm_ng_pyramid_plan_upload(fsgm_ng_pyramid_plan* p, const uint8_t* I0, const uint8_t* I1) {
+fsgm_status fsgm_ng_pyramid_plan_upload_frame(fsgm_ng_pyramid_plan* p, int32_t frame, const uint8_t* I0, const uint8_t* I1) {
     FSGM_REQUIRE(p && I0 && I1, "fsgm_ng_pyramid_plan_upload: null argument");
+    FSGM_REQUIRE(frame >= 0 && frame < p->batch, "frame %d out of range (batch %d)", frame, p->batch);
     FSGM_HIP(hipSetDevice(p->device));
     const size_t n = (size_t)p->channels * p->W * p->H;
-    FSGM_HIP(hipMemcpyAsync(p->channels == 3 ? p->dP0[0] : p->dG0[0], I0, n, hipMemcpyHostToDevice, p->stream));
-    FSGM_HIP(hipMemcpyAsync(p->channels == 3 ? p->dP1[0] : p->dG1[0], I1, n, hipMemcpyHostToDevice, p->stream));
+    StreamGuard guard(p->stream);
+    FSGM_HIP(hipMemcpyAsync((p->channels == 3 ? p->dP0[0] : p->dG0[0]) + frame * n, I0, n, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipMemcpyAsync((p->channels == 3 ? p->dP1[0] : p->dG1[0]) + frame * n, I1, n, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 
+fsgm_status fsgm_ng_pyramid_plan_upload(fsgm_ng_pyramid_plan* p, const uint8_t* I0, const uint8_t* I1) {
+    return fsgm_ng_pyramid_plan_upload_frame(p, 0, I0, I1);
+}
+
 static fsgm_status ng_pyramid_enqueue(fsgm_ng_pyramid_plan* p) {
-    const int n = p->prm.numPyd, ch = p->channels, D = p->D;
+    const int n = p->prm.numPyd, ch = p->channels, D = p->D, B = p->batch;
     hipStream_t s = p->stream;
-    for (int l = 1; l < n; l++) {                                                // pyramidal_sgm.m:28-31
-        launch_pyr_reduce(s, ch == 3 ? p->dP0[l - 1] : p->dG0[l - 1], ch == 3 ? p->dP0[l] : p->dG0[l], p->Ws[l - 1], p->Hs[l - 1], ch);
-        launch_pyr_reduce(s, ch == 3 ? p->dP1[l - 1] : p->dG1[l - 1], ch == 3 ? p->dP1[l] : p->dG1[l], p->Ws[l - 1], p->Hs[l - 1], ch);
+    for (int l = 1; l < n; l++) {                                                // pyramidal_sgm.m:28-31 (all frames' planes in one launch)
+        launch_pyr_reduce(s, ch == 3 ? p->dP0[l - 1] : p->dG0[l - 1], ch == 3 ? p->dP0[l] : p->dG0[l], p->Ws[l - 1], p->Hs[l - 1], ch * B);
+        launch_pyr_reduce(s, ch == 3 ? p->dP1[l - 1] : p->dG1[l - 1], ch == 3 ? p->dP1[l] : p->dG1[l], p->Ws[l - 1], p->Hs[l - 1], ch * B);
     }
     if (ch == 3)
         for (int l = 0; l < n; l++) {                                            // :44-45
-            launch_pyr_gray(s, p->dP0[l], p->dG0[l], p->Ws[l], p->Hs[l]);
-            launch_pyr_gray(s, p->dP1[l], p->dG1[l], p->Ws[l], p->Hs[l]);
+            const size_t np = (size_t)p->Ws[l] * p->Hs[l];
+            for (int f = 0; f < B; f++) {
+                launch_pyr_gray(s, p->dP0[l] + f * 3 * np, p->dG0[l] + f * np, p->Ws[l], p->Hs[l]);
+                launch_pyr_gray(s, p->dP1[l] + f * 3 * np, p->dG1[l] + f * np, p->Ws[l], p->Hs[l]);
+            }
         }
     for (int l = n - 1; l >= 0; l--) {                                           // :37
         const int w = p->Ws[l], h = p->Hs[l];
         const size_t N = (size_t)w * h * D;
-        FSGM_HIP(hipMemsetAsync(p->dS, 0, N * 4, s));                            // calc_pyd_cost_sgm_ng.cpp:111
+        FSGM_HIP(hipMemsetAsync(p->dS, 0, (size_t)B * N * 4, s));                // calc_pyd_cost_sgm_ng.cpp:111
         FSGM_HIP(hipMemsetAsync(p->dUnsafe, 0, 4, s));
-        launch_census(s, p->dG0[l], p->dCen1, w, h, 1);                          // :485-486
-        launch_census(s, p->dG1[l], p->dCen2, w, h, 1);
+        launch_census(s, p->dG0[l], p->dCen1, w, h, B);                          // :485-486
+        launch_census(s, p->dG1[l], p->dCen2, w, h, B);
         NgCostArgs ca;
         ca.cen1 = p->dCen1; ca.cen2 = p->dCen2; ca.mv = p->dMv[l]; ca.C = p->dC; ca.unsafe = p->dUnsafe; ca.W = w; ca.H = h;
         ca.mvW = p->mvW[l]; ca.mvH = p->mvH[l]; ca.rAgg = p->prm.aggSize / 2; ca.rX = p->prm.halfSearchWinSize; ca.rY = p->prm.halfSearchWinSize;
-        launch_ng_cost(s, ca, 1);
+        launch_ng_cost(s, ca, B);
         NgAggArgs ga;
         ga.C = p->dC; ga.S = p->dS; ga.unsafe = p->dUnsafe; ga.W = w; ga.H = h; ga.D = D; ga.P1 = p->prm.P1; ga.P2 = p->prm.P2;
         ga.dd = nullptr; ga.dk = nullptr;
         if (D <= 128) {
-            launch_ng_dedupe(s, p->dC, p->dDd, p->dDk, w, h, D, 1);
+            launch_ng_dedupe(s, p->dC, p->dDd, p->dDk, w, h, D, B);
             ga.dd = p->dDd; ga.dk = p->dDk;
         }
-        launch_ng_aggregate(s, ga, 1);
+        launch_ng_aggregate(s, ga, B);
         NgWtaArgs wa;
         wa.C = p->dC; wa.S = p->dS; wa.minC = p->dMinC[l]; wa.flow = p->dFlow[l]; wa.W = w; wa.H = h; wa.D = D;
-        launch_ng_wta(s, wa, 1);
+        launch_ng_wta(s, wa, B);
         if (p->prm.subPixelRefine) {                                             // :516-517
             NgSubpixArgs sa;
             sa.cen1 = p->dCen1; sa.cen2 = p->dCen2; sa.flow = p->dFlow[l]; sa.W = w; sa.H = h;
-            launch_ng_subpixel(s, sa, 1);
+            launch_ng_subpixel(s, sa, B);
         }
-        if (l > 0) launch_pyr_upsample2(s, p->dFlow[l], p->dMv[l - 1], w, h);    // pyramidal_sgm.m:72
+        if (l > 0)                                                               // pyramidal_sgm.m:72
+            for (int f = 0; f < B; f++)
+                launch_pyr_upsample2(s, p->dFlow[l] + (size_t)f * 2 * w * h, p->dMv[l - 1] + (size_t)f * 2 * p->mvW[l - 1] * p->mvH[l - 1], w, h);
     }
     FSGM_HIP(hipGetLastError());
     return FSGM_OK;
@@ -186,16 +206,21 @@ fsgm_status fsgm_ng_pyramid_plan_run(fsgm_ng_pyramid_plan* p) {
     return ng_pyramid_enqueue(p);
 }
 
-fsgm_status fsgm_ng_pyramid_plan_download(fsgm_ng_pyramid_plan* p, int32_t level, double* flow, uint32_t* minC) {
+fsgm_status fsgm_ng_pyramid_plan_download_frame(fsgm_ng_pyramid_plan* p, int32_t frame, int32_t level, double* flow, uint32_t* minC) {
     FSGM_REQUIRE(p, "null plan");
     FSGM_REQUIRE(level >= 1 && level <= p->prm.numPyd, "level %d out of range 1..%d", level, p->prm.numPyd);
+    FSGM_REQUIRE(frame >= 0 && frame < p->batch, "frame %d out of range (batch %d)", frame, p->batch);
     FSGM_HIP(hipSetDevice(p->device));
     FSGM_HIP(hipStreamSynchronize(p->stream));
     const int l = level - 1;
     const size_t np = (size_t)p->Ws[l] * p->Hs[l];
-    if (flow) FSGM_HIP(hipMemcpy(flow, p->dFlow[l], 2 * np * sizeof(double), hipMemcpyDeviceToHost));
-    if (minC) FSGM_HIP(hipMemcpy(minC, p->dMinC[l], np * 4, hipMemcpyDeviceToHost));
+    if (flow) FSGM_HIP(hipMemcpy(flow, p->dFlow[l] + (size_t)frame * 2 * np, 2 * np * sizeof(double), hipMemcpyDeviceToHost));
+    if (minC) FSGM_HIP(hipMemcpy(minC, p->dMinC[l] + (size_t)frame * np, np * 4, hipMemcpyDeviceToHost));
     return FSGM_OK;
+}
+
+fsgm_status fsgm_ng_pyramid_plan_download(fsgm_ng_pyramid_plan* p, int32_t level, double* flow, uint32_t* minC) {
+    return fsgm_ng_pyramid_plan_download_frame(p, 0, level, flow, minC);
 }
 
 fsgm_status fsgm_ng_pyramid_plan_time(fsgm_ng_pyramid_plan* p, int32_t warmup, int32_t iters, float* ms_avg) {
@@ -231,7 +256,7 @@ fsgm_status fsgm_pyramidal_sgm_ng_host(const uint8_t* I0, const uint8_t* I1, int
     std::lock_guard<std::mutex> lk(g_ngpyr_mu);
     fsgm_ng_pyramid_plan* p = nullptr;
     for (fsgm_ng_pyramid_plan* q : g_ngpyr_cache)
-        if (q->W == width && q->H == height && q->channels == channels && memcmp(&q->prm, prm, sizeof *prm) == 0) p = q;
+        if (q->W == width && q->H == height && q->channels == channels && q->batch == 1 && memcmp(&q->prm, prm, sizeof *prm) == 0) p = q;
     fsgm_status st;
     if (!p) {
         if ((st = fsgm_ng_pyramid_plan_create(&p, width, height, channels, prm)) != FSGM_OK) return st;

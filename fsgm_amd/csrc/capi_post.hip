@@ -68,6 +68,7 @@ fsgm_status fsgm_post_plan_create(fsgm_post_plan** out, int32_t W, int32_t H, in
 fsgm_status fsgm_post_plan_upload(fsgm_post_plan* p, const double* D1, const double* Pd0, const double* normDirect, const double* O) {
     FSGM_REQUIRE(p, "null plan");
     FSGM_HIP(hipSetDevice(p->device));
+    StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     if (D1) FSGM_HIP(hipMemcpyAsync(p->dIn, D1, p->NP * 8, hipMemcpyHostToDevice, p->stream));
     if (Pd0) FSGM_HIP(hipMemcpyAsync(p->dPd0, Pd0, p->NP * 16, hipMemcpyHostToDevice, p->stream));
     if (normDirect) FSGM_HIP(hipMemcpyAsync(p->dNd, normDirect, p->NP * 16, hipMemcpyHostToDevice, p->stream));
@@ -160,6 +161,7 @@ fsgm_status fsgm_speckle_filter_host(const double* image, int32_t W, int32_t H, 
     fsgm_post_plan* p;
     fsgm_status st = cached_plan(&p, W, H, device);
     if (st != FSGM_OK) return st;
+    StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(p->dIn, image, p->NP * 8, hipMemcpyHostToDevice, p->stream));
     launch_speckle_filter(p->stream, p->dIn, p->dOut, labelImage ? p->dLabels : nullptr, p->dParent, p->dSize, p->dScan,
                           W, H, maxDiff, maxSpeckleSize);
@@ -182,6 +184,7 @@ fsgm_status fsgm_calc_disp_from_first_host(const double* D1, int32_t W, int32_t 
     if ((st = fsgm_post_plan_upload(p, D1, Pd0, normDirect, O)) != FSGM_OK) return st;
     launch_disp_from_first(p->stream, p->dIn, p->dD2, PostGeom{p->dPd0, p->dNd, p->dO, vMax, n}, W, H);
     FSGM_HIP(hipGetLastError());
+    StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(D2, p->dD2, p->NP * 8, hipMemcpyDeviceToHost, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
     return FSGM_OK;
@@ -196,6 +199,7 @@ fsgm_status fsgm_forward_backward_check_host(const double* D1, const double* D2,
     fsgm_status st = cached_plan(&p, W, H, device);
     if (st != FSGM_OK) return st;
     if ((st = fsgm_post_plan_upload(p, D1, Pd0, normDirect, O)) != FSGM_OK) return st;
+    StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(p->dD2, D2, p->NP * 8, hipMemcpyHostToDevice, p->stream));
     launch_fb_check(p->stream, p->dIn, p->dD2, p->dOut, PostGeom{p->dPd0, p->dNd, p->dO, vMax, n}, W, H);
     FSGM_HIP(hipGetLastError());
@@ -210,6 +214,7 @@ fsgm_status fsgm_scanline_in_fill_host(const double* input, int32_t W, int32_t H
     fsgm_post_plan* p;
     fsgm_status st = cached_plan(&p, W, H, device);
     if (st != FSGM_OK) return st;
+    StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(p->dIn, input, p->NP * 8, hipMemcpyHostToDevice, p->stream));
     launch_scanline_in_fill(p->stream, p->dIn, p->dOut, p->dLeft, W, H);
     FSGM_HIP(hipGetLastError());
@@ -224,6 +229,7 @@ fsgm_status fsgm_vzind2disp_host(const double* w, const double* O, int32_t W, in
     fsgm_post_plan* p;
     fsgm_status st = cached_plan(&p, W, H, device);
     if (st != FSGM_OK) return st;
+    StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(p->dIn, w, p->NP * 8, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(p->dO, O, p->NP * 8, hipMemcpyHostToDevice, p->stream));
     launch_vzind2disp(p->stream, p->dIn, p->dO, p->dDisp, p->NP, vMax, n);
@@ -243,6 +249,7 @@ fsgm_status fsgm_vmf_host(const double* flow, int32_t W, int32_t H, int32_t chan
     double* src[3] = {p->dIn, p->dA, p->dB};                     // one plane per scratch map
     double* dst[3] = {p->dOut, p->dD2, p->dDisp};
     for (int c = 0; c < channels; c++) {
+        StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
         FSGM_HIP(hipMemcpyAsync(src[c], flow + (size_t)c * p->NP, p->NP * 8, hipMemcpyHostToDevice, p->stream));
         launch_vmf(p->stream, src[c], dst[c], W, H, 1);
         FSGM_HIP(hipMemcpyAsync(flowMed + (size_t)c * p->NP, dst[c], p->NP * 8, hipMemcpyDeviceToHost, p->stream));

@@ -88,6 +88,7 @@ fsgm_status fsgm_pyd_plan_upload(fsgm_pyd_plan* p, int32_t f, const uint8_t* I1,
     FSGM_REQUIRE(p && I1 && I2 && mv, "fsgm_pyd_plan_upload: null argument");
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_HIP(hipSetDevice(p->device));
+    StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(p->dI1 + f * p->NP, I1, p->NP, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(p->dI2 + f * p->NP, I2, p->NP, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(p->dMv + f * 2 * p->MV, mv, p->MV * 16, hipMemcpyHostToDevice, p->stream));
@@ -111,6 +112,7 @@ fsgm_status fsgm_pyd_plan_upload_cost(fsgm_pyd_plan* p, int32_t f, const uint8_t
                 memcpy(&p->stage[px * p->PS + (size_t)sx * p->RS], C + px * p->D + (size_t)sx * p->Sy, p->Sy);
         src = p->stage.data();
     }
+    StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(p->dC + f * p->N, src, p->N, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
     return FSGM_OK;

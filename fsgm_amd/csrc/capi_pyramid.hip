@@ -119,6 +119,7 @@ fsgm_status fsgm_pyramid_plan_upload(fsgm_pyramid_plan* p, const uint8_t* I0, co
     const size_t n = (size_t)p->channels * p->W * p->H;
     uint8_t* d0 = p->channels == 3 ? p->dP0[0] : p->lv[0]->dI1;
     uint8_t* d1 = p->channels == 3 ? p->dP1[0] : p->lv[0]->dI2;
+    StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(d0, I0, n, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(d1, I1, n, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));

@@ -150,6 +150,9 @@ def _bind_ng(lib):
     vp, i32 = C.c_void_p, C.c_int32
     lib.fsgm_ng_pyramid_params_default.restype = NgPyramidParams
     lib.fsgm_ng_pyramid_plan_create.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(NgPyramidParams)]
+    lib.fsgm_ng_pyramid_plan_create_batch.argtypes = [C.POINTER(vp), i32, i32, i32, i32, C.POINTER(NgPyramidParams)]
+    lib.fsgm_ng_pyramid_plan_upload_frame.argtypes = [vp, i32, vp, vp]
+    lib.fsgm_ng_pyramid_plan_download_frame.argtypes = [vp, i32, i32, vp, vp]
     lib.fsgm_ng_pyramid_plan_destroy.argtypes = [vp]
     lib.fsgm_ng_pyramid_plan_destroy.restype = None
     lib.fsgm_ng_pyramid_plan_level_size.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -162,9 +165,10 @@ def _bind_ng(lib):
 
 
 class NgPyramidPlan:
-    """Device-resident level loop around calc_pyd_cost_sgm_ng for one image shape (see pyramidal_sgm_ng)."""
+    """Device-resident level loop around calc_pyd_cost_sgm_ng for one image shape (see pyramidal_sgm_ng); `batch` image
+    pairs stay resident and go through every level together."""
 
-    def __init__(self, width, height, channels=1, numPyd=3, *, device=0, **overrides):
+    def __init__(self, width, height, channels=1, numPyd=3, *, device=0, batch=1, **overrides):
         self.lib = _lib.load()
         _bind_ng(self.lib)
         prm = self.lib.fsgm_ng_pyramid_params_default()
@@ -175,8 +179,9 @@ class NgPyramidPlan:
             setattr(prm, k, int(v))
         self.prm = prm
         self.W, self.H, self.channels = int(width), int(height), int(channels)
+        self.batch = int(batch)
         self._h = C.c_void_p()
-        check(self.lib.fsgm_ng_pyramid_plan_create(C.byref(self._h), self.W, self.H, self.channels, C.byref(prm)))
+        check(self.lib.fsgm_ng_pyramid_plan_create_batch(C.byref(self._h), self.W, self.H, self.channels, self.batch, C.byref(prm)))
 
     def close(self):
         if self._h:
@@ -200,20 +205,20 @@ class NgPyramidPlan:
         check(self.lib.fsgm_ng_pyramid_plan_level_size(self._h, int(level), C.byref(w), C.byref(h)))
         return w.value, h.value
 
-    def upload(self, I0, I1):
+    def upload(self, I0, I1, frame=0):
         I0, I1, ch = _check_images(I0, I1)
         if ch != self.channels or I0.shape[-2:] != (self.H, self.W):
             raise ValueError("shape mismatch with the plan")
-        check(self.lib.fsgm_ng_pyramid_plan_upload(self._h, ptr(I0), ptr(I1)))
+        check(self.lib.fsgm_ng_pyramid_plan_upload_frame(self._h, int(frame), ptr(I0), ptr(I1)))
 
     def run(self):
         check(self.lib.fsgm_ng_pyramid_plan_run(self._h))
 
-    def download(self, level=1):
+    def download(self, level=1, frame=0):
         w, h = self.level_size(level)
         flow = np.empty((2, h, w), np.float64)
         minC = np.empty((h, w), np.uint32)
-        check(self.lib.fsgm_ng_pyramid_plan_download(self._h, int(level), ptr(flow), ptr(minC)))
+        check(self.lib.fsgm_ng_pyramid_plan_download_frame(self._h, int(frame), int(level), ptr(flow), ptr(minC)))
         return flow, minC
 
     def time(self, warmup=1, iters=5):

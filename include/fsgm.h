@@ -302,6 +302,12 @@ fsgm_ng_pyramid_params fsgm_ng_pyramid_params_default(void);
 typedef struct fsgm_ng_pyramid_plan fsgm_ng_pyramid_plan;
 fsgm_status fsgm_ng_pyramid_plan_create(fsgm_ng_pyramid_plan** plan, int32_t width, int32_t height, int32_t channels,
                                         const fsgm_ng_pyramid_params* prm);
+/* the same with `batch` image pairs resident: one run takes all of them through every level together (frames are
+ * independent; every kernel of a level covers the whole batch) */
+fsgm_status fsgm_ng_pyramid_plan_create_batch(fsgm_ng_pyramid_plan** plan, int32_t width, int32_t height, int32_t channels,
+                                              int32_t batch, const fsgm_ng_pyramid_params* prm);
+fsgm_status fsgm_ng_pyramid_plan_upload_frame(fsgm_ng_pyramid_plan* plan, int32_t frame, const uint8_t* I0, const uint8_t* I1);
+fsgm_status fsgm_ng_pyramid_plan_download_frame(fsgm_ng_pyramid_plan* plan, int32_t frame, int32_t level, double* flow, uint32_t* minC);
 void        fsgm_ng_pyramid_plan_destroy(fsgm_ng_pyramid_plan* plan);
 fsgm_status fsgm_ng_pyramid_plan_level_size(fsgm_ng_pyramid_plan* plan, int32_t level, int32_t* width, int32_t* height);
 fsgm_status fsgm_ng_pyramid_plan_upload(fsgm_ng_pyramid_plan* plan, const uint8_t* I0, const uint8_t* I1);

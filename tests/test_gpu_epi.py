@@ -402,3 +402,50 @@ def test_strip_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, monkeypatch)
                 gbd, gmc = plan.download(f)
                 np.testing.assert_array_equal(gmc, want[f][1], err_msg=f"rep {rep} frame {f}")
                 np.testing.assert_array_equal(gbd, want[f][0], err_msg=f"rep {rep} frame {f}")
+
+
+def _sharded_gpu_worker(rank, world, port, n_frames, q):
+    """One rank of test_two_processes_shard_frames_on_the_gpu: started before anything touches the GPU in this process."""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from fsgm_amd import batch, synth as sy, calc_cost_sgm_batch as run
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames = []
+        for s in range(n_frames):
+            I1, I2 = sy.image_pair(96, 64, 64, seed=70 + s)
+            frames.append((I1, I2) + sy.epi_maps(96, 64, "general", seed=80 + s))
+        full = batch.run_sharded(frames, lambda fs: run(fs, 64, 0.3, 6, 64, paths=8, device=0))   # both ranks on the one GPU of the box
+        q.put((rank, [(bd.copy(), mc.copy()) for bd, mc in full]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_shard_frames_on_the_gpu(gpu_lib, oracle):
+    """The N > 1 path with the real compute: two worker processes (gloo rendezvous, both on device 0 -- the box has one
+    GPU) run fsgm_amd.batch.run_sharded over calc_cost_sgm_batch; every rank must end up with the oracle's result for
+    every frame, in frame order."""
+    import socket
+    import torch.multiprocessing as mp
+    n_frames, world = 5, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_gpu_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for s in range(n_frames):
+        I1, I2 = synth.image_pair(96, 64, 64, seed=70 + s)
+        pd0, nd, off = synth.epi_maps(96, 64, "general", seed=80 + s)
+        bd, mc = oracle.calc_cost_sgm(I1, I2, 64, 0.3, pd0, nd, off, 6, 64, 8)
+        for r in range(world):
+            np.testing.assert_array_equal(got[r][s][0], bd, err_msg=f"rank {r} frame {s}")
+            np.testing.assert_array_equal(got[r][s][1], mc, err_msg=f"rank {r} frame {s}")

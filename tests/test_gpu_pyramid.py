@@ -139,3 +139,25 @@ def test_pyramidal_loop_ng_with_a_wider_search(gpu_lib, oracle):
         mvPre = np.ascontiguousarray(2.0 * np.repeat(np.repeat(fl, 2, axis=1), 2, axis=2))
     np.testing.assert_array_equal(minC, mc)
     np.testing.assert_array_equal(flow, fl)
+
+
+def test_ng_pyramid_batch_matches_single_pairs(gpu_lib, oracle):
+    """A batch of image pairs through one NgPyramidPlan (every kernel of a level covers all frames) = the same pairs one
+    at a time = the oracle composition (frame 0), all levels."""
+    from fsgm_amd import NgPyramidPlan, pyramidal_sgm_ng
+    W, H, B = 83, 61, 5
+    pairs = []
+    for f in range(B):
+        g0, g1 = synth.image_pair(W, H, 8, seed=11 + f)
+        pairs.append((np.stack([g0, 255 - g0, g0 // 2 + 40]), np.stack([g1, 255 - g1, g1 // 2 + 40])))
+    with NgPyramidPlan(W, H, 3, 3, batch=B) as plan:
+        for f, (a, b) in enumerate(pairs):
+            plan.upload(a, b, frame=f)
+        for _ in range(2):                                      # twice: buffers are reused
+            plan.run()
+        got = [[plan.download(l, frame=f) for l in (3, 2, 1)] for f in range(B)]
+    for f, (a, b) in enumerate(pairs):
+        flow, flows, minC = pyramidal_sgm_ng(a, b, 3)
+        for li in range(3):
+            np.testing.assert_array_equal(got[f][li][0], flows[li], err_msg=f"frame {f} level {3 - li}")
+        np.testing.assert_array_equal(got[f][2][1], minC, err_msg=f"frame {f}")
