@@ -445,7 +445,6 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
                 sa.edge = p->dEdge + (size_t)f0 * strip_edge_uint4s(p->W, p->H, p->D);
                 sa.ticket = p->dTicket + lane; sa.err = p->dErr;
                 sa.W = p->W; sa.H = p->H; sa.D = p->D; sa.P1 = p->P1; sa.P2 = p->P2; sa.frames = nf;
-                { const char* e = getenv("FSGM_STRIP_NOWAIT"); sa.nowait = (e && *e) ? atoi(e) : 0; }
                 auto next_launch = [&]() {                            // bookkeeping of one launch of this lane
                     sa.ticket_base = p->ticket_host[lane];
                     p->ticket_host[lane] += (uint32_t)(sa.NS * nf);

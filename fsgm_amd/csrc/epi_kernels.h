@@ -81,7 +81,6 @@ struct StripArgs {
     int W, H, D;
     int P1, P2;
     int frames, NS;
-    int nowait;               // timing experiment only (FSGM_STRIP_NOWAIT=1): take whatever the hand-off buffer holds -- WRONG results
 };
 
 struct SweepSumArgs {          // what wta_sweep_kernel adds up (u8 volumes; the Y volumes in the sweeps' private byte order)

@@ -255,6 +255,10 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     const int hx = hdir == 0 ? a0 - T + wave * PXG + g : a0 + STRIP + (wave - NWV / 2) * PXG + g;
     const bool halo_ok = hx >= 0 && hx < W;
     const int hxc = min(max(hx, 0), W - 1);
+    // A halo column at distance c from the strip feeds the strip's row r + c from its row r: the wave whose nearest halo
+    // column is hmin columns away has nothing left to contribute after row rows - 1 - hmin of the block (the far
+    // waves' halo is a triangle, not a square)
+    const int hmin = hdir == 0 ? T - wave * PXG - PXG + 1 : (wave - NWV / 2) * PXG + 1;
     const int base0 = a0 - T - 1, base1 = a0;                    // forward column of LDS column 0, per direction
     // a diagonal restarts where it enters the image (:156-180): its predecessor column -1 / W holds the start state
     // (never overwritten: stores of columns outside the image are skipped) and the stored minimum is masked to 0
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
             }
         }
         // halo unit: keeps the inward-flowing diagonal correct for the next rows
-        {
+        if (k + hmin < rows) {                                   // wave-uniform
             uint32_t HP[8], S[8], Y[8];
             unpack_c(cHalo, HP, P2pk);
             const int px = hdir == 0 ? hx - 1 : hx + 1;
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
             if (edge_wanted(y - 1)) {
                 b = nb;
                 uint32_t spins = 0;
-                while (!a.nowait && !__all(fresh(b))) {           // over the lanes that take part in the hand-off
+                while (!__all(fresh(b))) {                        // over the lanes that take part in the hand-off
                     if (++spins > (1u << 20)) { if (lane == 0) atomicOr(a.err, 1u); break; }
                     __builtin_amdgcn_s_sleep(1);
                     b = edge_load(edgeIn + (size_t)(y - 1) * (3 * LPP) + lane);

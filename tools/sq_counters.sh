@@ -29,7 +29,7 @@ print("per dispatch averages (serialised dispatches); cycles of SQ_WAVE_CYCLES /
 print("| kernel | n | avg us | " + " | ".join(names) + " |")
 print("|---|---|---|" + "---|" * len(names))
 for k in sorted(acc):
-    if not any(s in k for s in ("sweep", "pair", "agg_", "wta", "fwd", "bwd", "copy16")): continue
+    if not any(s in k for s in ("sweep", "strip", "pair", "agg_", "wta", "fwd", "bwd", "copy16")): continue
     n = max(cnt[k].values())
     row = [f"{acc[k][c] / max(cnt[k][c], 1):.4g}" if cnt[k][c] else "-" for c in names]
     d = dur[k]
@@ -40,7 +40,7 @@ print("| kernel | VALU inst/wave | active% | wait_any% | wait_inst% | VALU busy 
 print("|---|---|---|---|---|---|---|")
 for k in sorted(acc):
     a = acc[k]
-    if not a.get("SQ_WAVES") or not any(s in k for s in ("sweep", "pair", "agg_", "wta", "fwd", "bwd")): continue
+    if not a.get("SQ_WAVES") or not any(s in k for s in ("sweep", "strip", "pair", "agg_", "wta", "fwd", "bwd")): continue
     wc = a["SQ_WAVE_CYCLES"] or 1
     gui = a.get("GRBM_GUI_ACTIVE", 0)
     print(f"| {k} | {a['SQ_INSTS_VALU'] / a['SQ_WAVES']:.0f} | {100 * a['SQ_ACTIVE_INST_ANY'] / wc:.1f} | {100 * a['SQ_WAIT_ANY'] / wc:.1f} | "
