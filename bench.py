@@ -341,7 +341,7 @@ def main():
             # the achievable rate on this device: the library's own 16 B-per-lane copy kernel (read + written bytes)
             fsgm_amd._lib.check(plan.lib.fsgm_measure_copy_bandwidth2(local_rank, 1 << 30, 10, 0, C.byref(g)))
             out["roofline"]["copy_GBps_measured"] = g.value
-            out["roofline"]["copy_kernel"] = "copy16_kernel (16 B per lane), 1 GiB"
+            out["roofline"]["copy_kernel"] = "copy16_kernel (one 16-B element per thread, non-temporal), 1 GiB"
             out["roofline"]["frac_of_copy"] = achieved / g.value
             fsgm_amd._lib.check(plan.lib.fsgm_measure_copy_bandwidth2(local_rank, 1 << 30, 10, 1, C.byref(g)))
             out["roofline"]["memcpy_d2d_GBps_measured"] = g.value

@@ -73,6 +73,7 @@ def load():
     lib.fsgm_epi_plan_download_sum.argtypes = [vp, i32, vp]
     lib.fsgm_epi_plan_download_census.argtypes = [vp, i32, vp, vp]
     lib.fsgm_census_host.argtypes = [vp, i32, i32, vp, i32]
+    lib.fsgm_sgm_host.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32]
     lib.fsgm_epi_plan_time.argtypes = [vp, i32, i32, i32, f32p]
     lib.fsgm_epi_plan_stream.argtypes = [vp]
     lib.fsgm_epi_plan_stream.restype = vp

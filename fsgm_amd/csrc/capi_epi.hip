@@ -872,6 +872,24 @@ fsgm_status fsgm_calc_cost_sgm_host(const fsgm_epi_in* in, const fsgm_epi_out* o
     return fsgm_calc_cost_sgm_batch_host(1, in, out, prm);
 }
 
+// sgm(C, P1, P2): sgm.m's call shape on the MEX's aggregation + WTA (MEX semantics: include/fsgm.h)
+fsgm_status fsgm_sgm_host(const uint8_t* C, int32_t W, int32_t H, int32_t D, int32_t P1, int32_t P2, int32_t paths,
+                          uint32_t* bestD, uint32_t* minC, uint32_t* S, int32_t device) {
+    FSGM_REQUIRE(C && bestD && minC, "fsgm_sgm: null argument");
+    fsgm_epi_params pr = fsgm_epi_params_default();
+    pr.paths = paths; pr.device = device; pr.vz_to_disp = 0; pr.subpixel = 1;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    fsgm_epi_plan* p = nullptr;
+    fsgm_status st = cached_plan(&p, W, H, D, 1, pr);
+    if (st != FSGM_OK) return st;
+    if ((st = fsgm_epi_plan_set_penalties(p, P1, P2, p->vMax)) != FSGM_OK) return st;
+    if ((st = fsgm_epi_plan_upload_cost(p, 0, C)) != FSGM_OK) return st;
+    if ((st = fsgm_epi_plan_run(p, FSGM_STAGE_AGGREGATE | FSGM_STAGE_WTA)) != FSGM_OK) return st;
+    if ((st = fsgm_epi_plan_download(p, 0, bestD, minC)) != FSGM_OK) return st;
+    if (S && (st = fsgm_epi_plan_download_sum(p, 0, S)) != FSGM_OK) return st;
+    return FSGM_OK;
+}
+
 // census() of common.cpp:3-27 alone (the one function of the path that the reference's own sources pin here)
 fsgm_status fsgm_census_host(const uint8_t* img, int32_t W, int32_t H, uint32_t* cen, int32_t device) {
     FSGM_REQUIRE(img && cen, "fsgm_census: null argument");

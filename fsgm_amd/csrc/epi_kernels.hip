@@ -722,21 +722,17 @@ void launch_epi_cost(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frame
     }
 }
 
-// Bandwidth probe: grid-stride copy, 16 B per lane per access, 4 accesses in flight per lane.
+// Bandwidth probe: one 16-byte element per thread, streaming (non-temporal) loads and stores, as many 256-thread
+// workgroups as elements / 256 -- the shape that copies fastest on this chip (tools/ubench/copy_rates.hip: 6.5 TB/s,
+// against 5.2-5.5 TB/s for grid-stride loops with 2-8 elements in flight per thread and 4.7-5.4 for hipMemcpyAsync).
 __global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) store_nt(dst + i, load_nt(src + i));
 }
 
 void launch_copy16(hipStream_t st, void* dst, const void* src, size_t bytes) {
     const size_t n16 = bytes / 16;
-    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 256 * 4 - 1) / (256 * 4), 256 * 16);
-    hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, st, (uint4*)dst, (const uint4*)src, n16);
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (uint4*)dst, (const uint4*)src, n16);
 }
 
 int agg_packed_lpp(int D) {

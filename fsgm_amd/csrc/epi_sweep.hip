@@ -205,8 +205,17 @@ __device__ __forceinline__ void wta_row_record(const uint32_t (&ST)[8], uint32_t
 //   MODE 2: point-mirrored frame, final: S = 8*(C + P2) - (Y_up + Y_dn + Y_h) in registers,
 //           WTA per pixel, writes one record {best, minC, S[best-1], S[best+1]} + S[0] per pixel.
 // =============================================================================================
+#ifndef FSGM_SWEEP_L16
+#define FSGM_SWEEP_L16 1        // diagonal states in LDS as 2 x u16 per dword (A/B knob; 0: packed bytes, half the LDS)
+#endif
+#ifndef FSGM_SWEEP_MINW
+#define FSGM_SWEEP_MINW 1       // minimum waves per SIMD the register allocation must allow (A/B knob)
+#endif
+#ifndef FSGM_SWEEP_PF
+#define FSGM_SWEEP_PF 2         // rows of C in flight per lane in the non-final sweeps (A/B knob; 3: -2 %)
+#endif
 template <int LPP, int MODE, int NWV, int GPW>
-__global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepArgs a) {
     constexpr bool UP = MODE != 0;
     constexpr int PXG = 64 / LPP;            // columns per pixel group (one wave-wide DP step)
     constexpr int PXW = GPW * PXG;           // own columns per wave: GPW groups, each with its three paths, + one halo group
@@ -219,8 +228,8 @@ __global__ __launch_bounds__(NWV * 64) void sweep_kernel(SweepArgs a) {
     // (L16; the final sweep, whose WTA rows take 8 KB more, and the two-group form keep them packed to bytes in one
     // plane instead -- 12 more instructions per diagonal step, but one more workgroup per CU)
     constexpr int NCD = STRIP + T + 1;
-    constexpr bool L16 = MODE != 2 && GPW == 1;
-    constexpr int PF = MODE == 2 ? 2 : (GPW > 1 ? 2 : 3);    // rows of C in flight per lane and group
+    constexpr bool L16 = MODE != 2 && GPW == 1 && FSGM_SWEEP_L16 != 0;
+    constexpr int PF = MODE == 2 ? 2 : (GPW > 1 ? 2 : FSGM_SWEEP_PF);    // rows of C in flight per lane and group
     __shared__ uint4 sDiag[2][2][L16 ? 2 : 1][NCD * LPP];  // [row parity][direction][plane][column][lane-of-pixel]
     __shared__ uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 1];   // MODE 2: S of the wave's pixels (u16)
 
@@ -811,7 +820,7 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
 }
 
 template <int LPP, int AXIS, bool FINAL>
-__global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs a) {
+__global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        // two waves per SIMD: at most 256 registers
     constexpr int PXW = 64 / LPP, D = LPP * 16, TC = HP_TC;
     __shared__ uint32_t sRow[FINAL ? 4 * 64 * 8 : 1];            // FINAL: S of the wave's pixels (u16)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -964,11 +973,12 @@ void launch_pair(hipStream_t st, const PairArgs& a0, int frames, int axis, bool 
 int sweep_rows_per_launch(int D) { const int lpp = agg_packed_lpp(D); return lpp ? (FSGM_SWEEP_WAVES / 2) * (64 / lpp) : 0; }
 size_t sweep_state_bytes(int W, int D) { return (size_t)3 * W * D; }
 
-// FSGM_SWEEP_GPW: pixel groups per wave (1 or 2; A/B switch).  With 2 a wave owns 16 columns at D = 128 -- six own DP
-// steps and one halo step per row instead of three and one: the halo (and its cost unpack and LDS round trip) weighs
-// half as much, and the strips are 64 columns wide.
+// FSGM_SWEEP_GPW: pixel groups per wave (1 = default, or 2; A/B switch).  With 2 a wave owns 16 columns at D = 128 -- six
+// own DP steps and one halo step per row instead of three and one: the halo (and its cost unpack and LDS round trip)
+// weighs half as much, the strips are 64 columns wide -- but twice the registers and half the workgroups: measured
+// 7 % slower (4.04 vs 3.78 ms per 32 frames).
 static int sweep_gpw() {
-    static const int v = [] { const char* e = getenv("FSGM_SWEEP_GPW"); const int x = (e && *e) ? atoi(e) : 2; return x == 1 ? 1 : 2; }();
+    static const int v = [] { const char* e = getenv("FSGM_SWEEP_GPW"); const int x = (e && *e) ? atoi(e) : 1; return x == 2 ? 2 : 1; }();
     return v;
 }
 

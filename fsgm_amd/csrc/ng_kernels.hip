@@ -39,17 +39,41 @@ __global__ __launch_bounds__(256) void ng_cost_kernel(NgCostArgs a) {
     const uint32_t* cen2 = a.cen2 + f * (size_t)NP;
     const int r = a.rAgg;
     uint32_t sum = 0;
-    for (int ay = -r; ay <= r; ay++) {
-        const int y1 = y + ay;
-        const int y2 = f64_to_i32_x86(__dadd_rn((double)(offy + y1), mvy));
-        const bool yok = y1 >= 0 && y1 <= H - 1 && y2 >= 0 && y2 <= H - 1;
-        for (int ax = -r; ax <= r; ax++) {
-            const int x1 = x + ax;
-            const int x2 = f64_to_i32_x86(__dadd_rn((double)(offx + x1), mvx));
-            if (yok && x1 >= 0 && x1 <= W - 1 && x2 >= 0 && x2 <= W - 1)
-                sum += __popc(cen1[(size_t)W * y1 + x1] ^ cen2[(size_t)W * y2 + x2]);
-            else
-                sum += 5;
+    if (r == 1) {
+        // the reference's window (aggSize = 2, ng_sgm.m:20): the sample column depends on ax only and the sample row on ay
+        // only (:417-418), so the 18 double -> int conversions of the 9 taps are 6
+        int x2v[3], y2v[3];
+        bool xok[3], yokv[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int x1 = x + t - 1, y1 = y + t - 1;
+            x2v[t] = f64_to_i32_x86(__dadd_rn((double)(offx + x1), mvx));
+            y2v[t] = f64_to_i32_x86(__dadd_rn((double)(offy + y1), mvy));
+            xok[t] = x1 >= 0 && x1 <= W - 1 && x2v[t] >= 0 && x2v[t] <= W - 1;
+            yokv[t] = y1 >= 0 && y1 <= H - 1 && y2v[t] >= 0 && y2v[t] <= H - 1;
+        }
+#pragma unroll
+        for (int ty = 0; ty < 3; ty++)
+#pragma unroll
+            for (int tx = 0; tx < 3; tx++) {
+                if (yokv[ty] && xok[tx])
+                    sum += __popc(cen1[(size_t)W * (y + ty - 1) + (x + tx - 1)] ^ cen2[(size_t)W * y2v[ty] + x2v[tx]]);
+                else
+                    sum += 5;
+            }
+    } else {
+        for (int ay = -r; ay <= r; ay++) {
+            const int y1 = y + ay;
+            const int y2 = f64_to_i32_x86(__dadd_rn((double)(offy + y1), mvy));
+            const bool yok = y1 >= 0 && y1 <= H - 1 && y2 >= 0 && y2 <= H - 1;
+            for (int ax = -r; ax <= r; ax++) {
+                const int x1 = x + ax;
+                const int x2 = f64_to_i32_x86(__dadd_rn((double)(offx + x1), mvx));
+                if (yok && x1 >= 0 && x1 <= W - 1 && x2 >= 0 && x2 <= W - 1)
+                    sum += __popc(cen1[(size_t)W * y1 + x1] ^ cen2[(size_t)W * y2 + x2]);
+                else
+                    sum += 5;
+            }
         }
     }
     const int win = (2 * r + 1) * (2 * r + 1);

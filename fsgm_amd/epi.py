@@ -82,6 +82,21 @@ def calc_cost_sgm(I1, I2, dMax, vMax, pixelPosD0, normlizeDirection, offsetFromP
                                return_volumes=return_volumes, fb_check=fb_check)[0]
 
 
+def sgm(Cvol, P1=7, P2=100, *, paths=4, device=0, return_sum=False):
+    """[bestD, minC] = sgm(C, P1, P2): sgm.m's call shape (sgm.m:1, defaults :4-10; test.m:36 passes 6, 64) on the MEX's
+    aggregation and WTA.  C: (height, width, dMax) uint8.  bestD = disparity index * 256 (MEX parabola).  MEX semantics
+    (mod-256 path arithmetic, path start stores minimum 0), not sgm.m's saturating ones: see include/fsgm.h."""
+    lib = _lib.load()
+    Cvol = np.ascontiguousarray(Cvol)
+    if Cvol.dtype != np.uint8 or Cvol.ndim != 3:
+        raise TypeError("C must be a (height, width, dMax) uint8 array")
+    H, W, D = Cvol.shape
+    bestD, minC = np.empty((H, W), np.uint32), np.empty((H, W), np.uint32)
+    S = np.empty((H, W, D), np.uint32) if return_sum else None
+    check(lib.fsgm_sgm_host(ptr(Cvol), W, H, D, int(P1), int(P2), int(paths), ptr(bestD), ptr(minC), ptr(S), int(device)))
+    return (bestD, minC, S) if return_sum else (bestD, minC)
+
+
 def census(img, *, device=0):
     """census(img) of common.cpp:3-27 on the device: (height, width) uint8 -> uint32 codes."""
     lib = _lib.load()

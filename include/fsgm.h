@@ -148,6 +148,16 @@ fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t it
 /* mode 0: the same; mode 1: hipMemcpyAsync device-to-device (the runtime's blit kernel), for comparison */
 fsgm_status fsgm_measure_copy_bandwidth2(int32_t device, size_t bytes, int32_t iters, int32_t mode, double* gbps);
 
+/* sgm(C, P1, P2) -- the call shape of sgm.m:1 / test.m:36 ("perform SGM on cost volume C"), served by the calc_cost_sgm
+ * path's aggregation + WTA (calc_cost_sgm.cpp:86-316): C u8 [H][W][dMax] (d fastest) in; bestD u32 [H][W] = disparity
+ * index * 256 with the MEX's parabola (no vz conversion), minC u32 [H][W], optionally S u32 [H][W][dMax] out.
+ * SEMANTICS ARE THE MEX'S, NOT sgm.m's: path arithmetic is mod 256 where sgm.m saturates (MATLAB uint8), a path's
+ * first pixel stores minimum 0 (calc_cost_sgm.cpp:154) where sgm.m takes min(C), and d = 1 is never refined
+ * (SURVEY 8(a) note on sgm.m) -- results differ from sgm.m's from the second pixel of every path on.
+ * paths: 4 (sgm.m's enableDiagonalPath = false) or 8. */
+fsgm_status fsgm_sgm_host(const uint8_t* C, int32_t width, int32_t height, int32_t dMax, int32_t P1, int32_t P2,
+                          int32_t paths, uint32_t* bestD, uint32_t* minC, uint32_t* S, int32_t device);
+
 /* census(img, cen, width, height) of common.cpp:3-27 on its own: u8 [H][W] -> u32 [H][W], 5x5 window, replicate
  * border, `neighbour >= centre`, first tap at bit 25, trailing shift (bit 0 = 0).  Any width/height >= 1. */
 fsgm_status fsgm_census_host(const uint8_t* img, int32_t width, int32_t height, uint32_t* cen, int32_t device);

@@ -449,3 +449,17 @@ def test_two_processes_shard_frames_on_the_gpu(gpu_lib, oracle):
         for r in range(world):
             np.testing.assert_array_equal(got[r][s][0], bd, err_msg=f"rank {r} frame {s}")
             np.testing.assert_array_equal(got[r][s][1], mc, err_msg=f"rank {r} frame {s}")
+
+
+@pytest.mark.parametrize("W,H,D,P1,P2,paths", [(64, 48, 64, 6, 64, 4), (33, 21, 128, 6, 64, 8), (40, 30, 24, 7, 100, 4), (21, 17, 16, 100, 200, 8)])
+def test_sgm_call_shape(gpu_lib, oracle, W, H, D, P1, P2, paths):
+    """sgm(C, P1, P2) (sgm.m:1, test.m:36) served by the MEX's aggregation + WTA: S, minC and bestD (index * 256 with the
+    MEX parabola, no vz conversion) against the oracle, incl. sgm.m's own defaults 7 / 100 and wrapping penalties."""
+    from fsgm_amd import sgm
+    Cv = synth.cost_volume(W, H, D, seed=W + D, cmax=24)
+    want = oracle.epi_aggregate(Cv, P1, P2, paths)
+    bd, mc = oracle.epi_wta(want, W, H, D, 1)
+    gbd, gmc, gS = sgm(Cv, P1, P2, paths=paths, return_sum=True)
+    np.testing.assert_array_equal(gS, want[:-1].reshape(H, W, D))
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gbd, bd)

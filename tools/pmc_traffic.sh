@@ -1,45 +1,51 @@
-# HBM/fabric traffic of the headline bench: two separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE do
-# not fit one pass), as MI355X_MICROARCH.md prescribes.  Run on the GPU box through gpurun; the per-kernel
-# sums land in gpurun_out/pmc_traffic.txt.
+# HBM/fabric traffic of the headline bench's aggregation stage: rocprofv3 PMC passes, FETCH_SIZE and WRITE_SIZE in
+# separate passes (they do not fit one), as MI355X_MICROARCH.md prescribes.  Each counter is collected for two runs of
+# the bench that differ only in the number of timed steps; the difference of the totals is exactly (S2 - S1) steps of
+# the stage, whatever else the bench launches around them.  Run on the GPU box through gpurun; results land in
+# gpurun_out/pmc_traffic.{txt,json} (copy to profiles/rNN_pmc_traffic.*).
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-rm -rf gpurun_out/pmc_f gpurun_out/pmc_w
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_f.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_w.log 2>&1
-python3 - <<'PY' | tee gpurun_out/pmc_traffic.txt
-import csv, glob, collections
+S1=2; S2=6
+for C in FETCH_SIZE WRITE_SIZE; do
+  for S in $S1 $S2; do
+    rm -rf gpurun_out/pmc_${C}_$S
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmc_${C}_$S -- python3 bench.py --steps $S --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${C}_$S.log 2>&1
+  done
+done
+python3 - $S1 $S2 <<'PY' | tee gpurun_out/pmc_traffic.txt
+import csv, glob, collections, json, re, sys
+S1, S2 = int(sys.argv[1]), int(sys.argv[2])
 def load(d, name):
     f = glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True)[0]
     acc, cnt = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != name: continue
-        k = r["Kernel_Name"][:70]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k] += float(r["Counter_Value"]); cnt[k] += 1
     return acc, cnt
-fa, fc = load("pmc_f", "FETCH_SIZE")
-wa, wc = load("pmc_w", "WRITE_SIZE")
-print("kernel | dispatches | FETCH_SIZE/dispatch MiB (raw) | x2 | WRITE_SIZE/dispatch MiB")
-for k in sorted(set(fa) | set(wa)):
-    n = fc.get(k, wc.get(k, 1))
-    print(f"{k} | {n} | {fa.get(k,0)/n/1024:.1f} | {2*fa.get(k,0)/n/1024:.1f} | {wa.get(k,0)/max(wc.get(k,1),1)/1024:.1f}")
-# machine-readable summary for bench.py (roofline.traffic): bytes per voxel of the aggregation stage's kernels
-import json, re
-line = [l for l in open("gpurun_out/pmc_f.log") if l.startswith("{")][-1]
-b = json.loads(line)
-steps = b["steps"] + b["warmup"] + max(3, b["steps"] // 2) + 1      # timed loop + warm-up + plan.time(AGGREGATE) incl. its warm-up
-agg = [k for k in set(fa) | set(wa) if re.search(r"sweep_kernel|pair_(ckpt|sum)_kernel|fwd_kernel|bwd_kernel", k)]
-runs = {k: fc.get(k, wc.get(k, 0)) for k in agg}
-tot = sum(2 * fa.get(k, 0) + wa.get(k, 0) * fc.get(k, 1) / max(wc.get(k, 1), 1) for k in agg) * 1024
+f1, fc1 = load(f"pmc_FETCH_SIZE_{S1}", "FETCH_SIZE"); f2, fc2 = load(f"pmc_FETCH_SIZE_{S2}", "FETCH_SIZE")
+w1, wc1 = load(f"pmc_WRITE_SIZE_{S1}", "WRITE_SIZE"); w2, wc2 = load(f"pmc_WRITE_SIZE_{S2}", "WRITE_SIZE")
+b = json.loads([l for l in open(f"gpurun_out/pmc_FETCH_SIZE_{S2}.log") if l.startswith("{")][-1])
 vox = b["config"]["frames_per_gpu"] * 1242 * 375 * 128
-# every aggregation run launches each kernel the same number of times: runs of the stage = dispatches of the rarest kernel
-nruns = min(runs.values()) if runs else 0
-out = {"pipeline": b["config"]["kernel"], "paths": 8, "bytes_per_voxel": tot / max(nruns, 1) / vox, "stage_runs_profiled": nruns,
-       "kernels": {k: {"dispatches": runs[k], "fetch_MiB_x2_per_dispatch": 2 * fa.get(k, 0) / max(fc.get(k, 1), 1) / 1024,
-                       "write_MiB_per_dispatch": wa.get(k, 0) / max(wc.get(k, 1), 1) / 1024} for k in agg},
-       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md), summed over the aggregation stage's kernels, per stage run",
+n = S2 - S1
+print(f"difference of a {S2}-step and a {S1}-step run = {n} steps of {b['config']['frames_per_gpu']} frames; counter unit KiB; FETCH_SIZE doubled (gfx950)")
+print("kernel | dispatches per step | FETCH_SIZE x2 per dispatch MiB | WRITE_SIZE per dispatch MiB | bytes per voxel per step")
+tot = 0.0
+kern = {}
+for k in sorted(set(f2) | set(w2)):
+    dn = fc2.get(k, 0) - fc1.get(k, 0)
+    if dn <= 0 or not re.search(r"sweep_kernel|strip_kernel|pair_(ckpt|sum)_kernel|sweep_finish", k): continue
+    fb = 2 * (f2.get(k, 0) - f1.get(k, 0)) * 1024; wb = (w2.get(k, 0) - w1.get(k, 0)) * 1024
+    if "sweep_finish" not in k: tot += fb + wb
+    kern[k] = {"dispatches_per_step": dn / n, "fetch_MiB_x2_per_dispatch": fb / dn / 2**20, "write_MiB_per_dispatch": wb / dn / 2**20,
+               "bytes_per_voxel": (fb + wb) / n / vox}
+    print(f"{k} | {dn / n:g} | {fb / dn / 2**20:.1f} | {wb / dn / 2**20:.1f} | {(fb + wb) / n / vox:.3f}")
+out = {"pipeline": b["config"]["kernel"], "paths": 8, "frames_per_gpu": b["config"]["frames_per_gpu"], "bytes_per_voxel": tot / n / vox,
+       "steps_profiled": n, "kernels": kern,
+       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md); per step = difference of two bench runs that differ only in --steps; aggregation-stage kernels only (the finish kernel is listed, not summed)",
        "command": "tools/pmc_traffic.sh"}
 json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("pipeline", "bytes_per_voxel", "stage_runs_profiled")}))
+print(json.dumps({k: out[k] for k in ("pipeline", "frames_per_gpu", "bytes_per_voxel", "steps_profiled")}))
 PY
-rm -rf gpurun_out/pmc_f gpurun_out/pmc_w
+rm -rf gpurun_out/pmc_FETCH_SIZE_* gpurun_out/pmc_WRITE_SIZE_*
