@@ -497,7 +497,7 @@ __device__ __forceinline__ void edge_store(uint4* p, const uint4 v) {
     __hip_atomic_store((unsigned long long*)p + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int LPP, int MODE, bool DEEP>
+template <int LPP, int MODE>
 __global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
     constexpr bool UP = MODE != 0;
     constexpr int PXG = 64 / LPP;            // columns per wave
@@ -560,14 +560,8 @@ __global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
     // wave 0, lanes 0 .. 3*LPP-1: the left neighbour's hand-off for the coming row, requested one row ahead
     const bool edge_lane = wave == 0 && lane < 3 * LPP;
     auto edge_wanted = [&](int yprev) -> bool { return k > 0 && yprev >= p_lo && yprev <= p_hi; };
-    // DEEP: PF rows ahead (the neighbour has to lead by that much before a request finds this launch's data) / else 1
-    constexpr int EPF = DEEP ? PF : 1;
-    uint4 nextB[EPF];
-#pragma unroll
-    for (int i = 0; i < EPF; i++) {
-        nextB[i] = startP;
-        if (edge_lane && edge_wanted(y_lo - 1 + i)) nextB[i] = edge_load(edgeIn + (size_t)(y_lo - 1 + i) * (3 * LPP) + lane);
-    }
+    uint4 nextB = startP;
+    if (edge_lane && edge_wanted(y_lo - 1)) nextB = edge_load(edgeIn + (size_t)(y_lo - 1) * (3 * LPP) + lane);
     __syncthreads();
 
     auto fresh = [&](const uint4 v) -> bool { return (((v.x ^ tag) | (v.y ^ tag) | (v.z ^ tag) | (v.w ^ tag)) & 0x80808080u) == 0u; };
@@ -621,26 +615,41 @@ __global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
     };
 
     // one row of the workgroup: hand-off in (wave 0), the wave's columns, hand-off out (wave 3), barrier
-    auto row = [&](const int y, const uint4 cw, const uint4 cX, const uint4 cH, uint4& nb) {
+    // one row of the workgroup: hand-off in (wave 0), requests for the rows to come, the wave's columns, hand-off out
+    // (wave 3), barrier.  Order matters for the wait counters (vmcnt retires in order): the hand-off words requested a
+    // row ago are waited for BEFORE this row's ring requests are issued, so that wait never drains the ring.
+    auto poll = [&](const int yprev) -> uint4 {                   // slow path: the neighbour has not got there yet
+        uint4 b;
+        for (uint32_t spins = 0;; spins++) {
+            __builtin_amdgcn_s_sleep(1);
+            b = edge_load(edgeIn + (size_t)yprev * (3 * LPP) + lane);
+            if (__all(fresh(b))) break;                           // over the lanes that take part in the hand-off
+            if (spins > (1u << 20)) { if (lane == 0) atomicOr(a.err, 1u); break; }
+        }
+        // the words have arrived (the test above read them): say so to the compiler, or it drains every request in
+        // flight -- the ring included -- where this path joins the fast one
+        asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+        return b;
+    };
+    auto row = [&](const int y, uint4& rC, uint4& rX, uint4& rH) {
         const int par = (y - y_lo) & 1;
         // ---- wave 0: the left neighbour's states of row y-1 into slots 0 and 1 ----
         if (edge_lane) {
             uint4 b = startP;
             if (edge_wanted(y - 1)) {
-                b = nb;
-                uint32_t spins = 0;
-                while (!__all(fresh(b))) {                        // over the lanes that take part in the hand-off
-                    if (++spins > (1u << 20)) { if (lane == 0) atomicOr(a.err, 1u); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    b = edge_load(edgeIn + (size_t)(y - 1) * (3 * LPP) + lane);
-                }
+                b = nextB;
+                if (!__all(fresh(b))) b = poll(y - 1);
                 b.x &= 0x7F7F7F7Fu; b.y &= 0x7F7F7F7Fu; b.z &= 0x7F7F7F7Fu; b.w &= 0x7F7F7F7Fu;
             }
             // lane = s * LPP + jj: s = 0 from-above of the neighbour's last column, 1 / 2 from-above-left of its last but one / last
             const int s_ = lane / LPP, jj = lane - s_ * LPP;
             sD[par][s_ == 0 ? 0 : 1][(s_ == 1 ? 0 : 1) * LPP + jj] = b;
-            if (edge_wanted(y - 1 + EPF)) nb = edge_load(edgeIn + (size_t)(y - 1 + EPF) * (3 * LPP) + lane);   // for a later row, in flight meanwhile
+            if (edge_wanted(y)) nextB = edge_load(edgeIn + (size_t)y * (3 * LPP) + lane);     // for the next row, in flight during this one
         }
+        // ---- this row's operands (requested PF rows ago) out of the ring, the row PF ahead into it ----
+        const uint4 cw = rC, cX = rX, cH = rH;
+        rC = *c_addr(y + PF);
+        if (MODE == 2) { rX = *(const uint4*)(Xf + x_off(y + PF)); rH = *(const uint4*)(Lhf + x_off(y + PF)); }
         const int xlo = u0 + wave * PXG - y, xhi = xlo + PXG - 1;   // this wave's image columns in row y
         if (xhi >= -MARGIN && xlo <= W - 1 + MARGIN) {              // wave-uniform
             if (y > 0 && xlo >= 1 && xhi <= W - 2) do_row(y, par, cw, cX, cH, std::false_type{});
@@ -658,21 +667,16 @@ __global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
         }
         __syncthreads();                                            // states of row y visible to row y+1
     };
-    for (int y = y_lo; y <= y_hi; y += PF) {
+    // steady state: PF rows per trip with the ring slots named statically (no register shuffling, so no wait for the
+    // requests just issued); then the tail
+    int y = y_lo;
+    for (; y + PF - 1 <= y_hi; y += PF) {
 #pragma unroll
-        for (int i = 0; i < PF; i++) {
-            if (y + i <= y_hi) {                                    // workgroup-uniform
-                const uint4 cw = ring[i];
-                ring[i] = *c_addr(y + i + PF);
-                uint4 cX = cw, cH = cw;
-                if (MODE == 2) {
-                    cX = ringX[i]; cH = ringH[i];
-                    ringX[i] = *(const uint4*)(Xf + x_off(y + i + PF)); ringH[i] = *(const uint4*)(Lhf + x_off(y + i + PF));
-                }
-                row(y + i, cw, cX, cH, nextB[DEEP ? i : 0]);
-            }
-        }
+        for (int i = 0; i < PF; i++) row(y + i, ring[i], ringX[MODE == 2 ? i : 0], ringH[MODE == 2 ? i : 0]);
     }
+#pragma unroll
+    for (int i = 0; i < PF - 1; i++)
+        if (y + i <= y_hi) row(y + i, ring[i], ringX[MODE == 2 ? i : 0], ringH[MODE == 2 ? i : 0]);   // workgroup-uniform
 }
 
 // =============================================================================================
@@ -1022,23 +1026,12 @@ void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode) {
 int strip_count(int W, int H, int D) { const int lpp = agg_packed_lpp(D); return lpp ? (W + H - 1 + 4 * (64 / lpp) - 1) / (4 * (64 / lpp)) : 0; }
 size_t strip_edge_uint4s(int W, int H, int D) { return (size_t)strip_count(W, H, D) * H * 3 * agg_packed_lpp(D); }   // per frame
 
-static int strip_deep() {
-    static const int v = [] { const char* e = getenv("FSGM_STRIP_DEEP"); return (e && *e) ? atoi(e) : 1; }();
-    return v;
-}
-
 template <int LPP>
 static void launch_strips_t(hipStream_t st, const StripArgs& a, int mode) {
     dim3 grid((unsigned)(a.NS * a.frames));
-    if (strip_deep()) {
-        if (mode == 0)      hipLaunchKernelGGL((strip_kernel<LPP, 0, true>), grid, dim3(256), 0, st, a);
-        else if (mode == 1) hipLaunchKernelGGL((strip_kernel<LPP, 1, true>), grid, dim3(256), 0, st, a);
-        else                hipLaunchKernelGGL((strip_kernel<LPP, 2, true>), grid, dim3(256), 0, st, a);
-    } else {
-        if (mode == 0)      hipLaunchKernelGGL((strip_kernel<LPP, 0, false>), grid, dim3(256), 0, st, a);
-        else if (mode == 1) hipLaunchKernelGGL((strip_kernel<LPP, 1, false>), grid, dim3(256), 0, st, a);
-        else                hipLaunchKernelGGL((strip_kernel<LPP, 2, false>), grid, dim3(256), 0, st, a);
-    }
+    if (mode == 0)      hipLaunchKernelGGL((strip_kernel<LPP, 0>), grid, dim3(256), 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((strip_kernel<LPP, 1>), grid, dim3(256), 0, st, a);
+    else                hipLaunchKernelGGL((strip_kernel<LPP, 2>), grid, dim3(256), 0, st, a);
 }
 
 void launch_strips(hipStream_t st, const StripArgs& a, int mode) {
