@@ -281,13 +281,16 @@ __global__ __launch_bounds__(256) void box5x5_sliding_kernel(const uint8_t* __re
 // u8 narrowings changes a value and 16-bit lanes are exact.  WRAP=true reduces mod 256 at every
 // point where the reference narrows to unsigned char.
 // =============================================================================================
-template <int LPP, bool WRAP, int BASE>
+template <int D, int DPL, bool WRAP, int BASE>
 __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot, const bool mirror) {
+    constexpr int LPP = D / DPL;        // lanes per pixel
+    constexpr int NK = DPL / 4;         // cost dwords per lane
     constexpr int PXW = 64 / LPP;       // lines per wave
-    constexpr int D = LPP * 16;
     constexpr int PF = 4;               // prefetch depth (steps of C in flight per lane)
     constexpr uint32_t SENT = 0xFFFFFFFFu;
     constexpr uint32_t MASK = 0x00FF00FFu;
+    static_assert(LPP >= 1 && LPP <= 32 && (NK == 1 || NK == 2 || NK == 4), "lane split");
+    struct __attribute__((aligned(NK * 4))) Words { uint32_t v[NK]; };
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / LPP, j = lane % LPP;
@@ -319,41 +322,42 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
     };
     auto byte_off = [&](int cpix) -> uint32_t {
         const int ap = mirror ? NP - 1 - cpix : cpix;
-        return (uint32_t)ap * D + (uint32_t)j * 16;
+        return (uint32_t)ap * D + (uint32_t)j * DPL;
     };
     // the load cursor runs PF steps ahead of the line's end: keep its address inside the volume
-    auto load_c = [&](int cpix) -> uint4 { return *(const uint4*)(Cf + byte_off(min(cpix, NP - 1))); };
+    auto load_c = [&](int cpix) -> Words { return *(const Words*)(Cf + byte_off(min(cpix, NP - 1))); };
 
     const uint32_t P1pk = WRAP ? (uint32_t)(a.P1 & 0xFF) * 0x10001u : (uint32_t)a.P1 * 0x10001u;
     const uint32_t P2pk = (uint32_t)a.P2 * 0x10001u;        // NOWRAP only
     const uint32_t P2b = (uint32_t)(a.P2 & 0xFF);           // WRAP only
 
-    uint32_t LE[4] = {0, 0, 0, 0}, LO[4] = {0, 0, 0, 0};    // previous pixel's path costs
+    uint32_t LE[NK], LO[NK];                                 // previous pixel's path costs
+#pragma unroll
+    for (int k = 0; k < NK; k++) LE[k] = LO[k] = 0;
     uint32_t m = 0;                                          // previous pixel's stored minimum
 
-    // one DP step on the 16 costs of this lane; returns the packed output dwords
-    auto step = [&](const uint4 cw, const bool start) -> uint4 {
-        const uint32_t cv[4] = {cw.x, cw.y, cw.z, cw.w};
-        uint32_t CE[4], CO[4];
+    // one DP step on the DPL costs of this lane; returns the packed output dwords
+    auto step = [&](const Words cw, const bool start) -> Words {
+        uint32_t CE[NK], CO[NK];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            CE[k] = __builtin_amdgcn_perm(0u, cv[k], 0x0C020C00u);     // bytes 0,2 -> 2 x u16
-            CO[k] = __builtin_amdgcn_perm(0u, cv[k], 0x0C030C01u);     // bytes 1,3 -> 2 x u16
+        for (int k = 0; k < NK; k++) {
+            CE[k] = __builtin_amdgcn_perm(0u, cw.v[k], 0x0C020C00u);   // bytes 0,2 -> 2 x u16
+            CO[k] = __builtin_amdgcn_perm(0u, cw.v[k], 0x0C030C01u);   // bytes 1,3 -> 2 x u16
         }
-        // lane-boundary neighbours
-        uint32_t prevO3 = dpp_mov<DPP_ROW_SHR1>(SENT, LO[3]);
-        uint32_t nextE0 = dpp_mov<DPP_ROW_SHL1>(SENT, LE[0]);
+        // lane-boundary neighbours (a pixel of 32 lanes spans two DPP rows: whole-wave shifts there)
+        uint32_t prevO3 = LPP > 16 ? dpp_mov<DPP_WAVE_SHR1>(SENT, LO[NK - 1]) : dpp_mov<DPP_ROW_SHR1>(SENT, LO[NK - 1]);
+        uint32_t nextE0 = LPP > 16 ? dpp_mov<DPP_WAVE_SHL1>(SENT, LE[0]) : dpp_mov<DPP_ROW_SHL1>(SENT, LE[0]);
         if (j == 0) prevO3 = SENT;                   // d = 0 has no d-1      (:47)
         if (j == LPP - 1) nextE0 = SENT;             // d = D-1 has no d+1    (:48)
 
         const uint32_t mpk = m | (m << 16);
-        uint32_t NE[4], NO[4];
+        uint32_t NE[NK], NO[NK];
         if (!WRAP) {
             const uint32_t p2lane = start ? 0u : P2pk;   // min(.,0)=0 -> L = C at a path start
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < NK; k++) {
                 const uint32_t nbE = pk_min(align16(LO[k], k ? LO[k - 1] : prevO3), LO[k]);
-                const uint32_t nbO = pk_min(LE[k], align16(k < 3 ? LE[k + 1] : nextE0, LE[k]));
+                const uint32_t nbO = pk_min(LE[k], align16(k < NK - 1 ? LE[k + 1] : nextE0, LE[k]));
                 const uint32_t tE = pk_min(LE[k], pk_add(nbE, P1pk));
                 const uint32_t tO = pk_min(LO[k], pk_add(nbO, P1pk));
                 // C + min(t, m+P2) - m  ==  C + min(t-m, P2)   (no wrap: t >= m)
@@ -368,13 +372,13 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
             const uint32_t noL = j == 0 ? 0x000000FFu : 0u;
             const uint32_t noR = j == LPP - 1 ? 0x00FF0000u : 0u;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t lE = align16(LO[k], k ? LO[k - 1] : prevO3);          // d-1 of E[k]
-                const uint32_t rO = align16(k < 3 ? LE[k + 1] : nextE0, LE[k]);      // d+1 of O[k]
+            for (int k = 0; k < NK; k++) {
+                const uint32_t lE = align16(LO[k], k ? LO[k - 1] : prevO3);            // d-1 of E[k]
+                const uint32_t rO = align16(k < NK - 1 ? LE[k + 1] : nextE0, LE[k]);   // d+1 of O[k]
                 uint32_t cEl = pk_add(lE, P1pk) & MASK;
                 uint32_t cOr = pk_add(rO, P1pk) & MASK;
                 if (k == 0) cEl |= noL;
-                if (k == 3) cOr |= noR;
+                if (k == NK - 1) cOr |= noR;
                 const uint32_t cEr = pk_add(LO[k], P1pk) & MASK;                     // d+1 of E[k] = O[k]
                 const uint32_t cOl = pk_add(LE[k], P1pk) & MASK;                     // d-1 of O[k] = E[k]
                 const uint32_t tE = pk_min(pk_min(LE[k], jpk), pk_min(cEl, cEr));
@@ -386,23 +390,28 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
             }
         }
         // minimum over d of the new costs (:61,:65); 0 at a path start (:154,:164)
-        uint32_t mm = pk_min(pk_min(pk_min(NE[0], NO[0]), pk_min(NE[1], NO[1])),
-                             pk_min(pk_min(NE[2], NO[2]), pk_min(NE[3], NO[3])));
+        uint32_t mk[NK];
+#pragma unroll
+        for (int k = 0; k < NK; k++) mk[k] = pk_min(NE[k], NO[k]);
+#pragma unroll
+        for (int w = 1; w < NK; w *= 2)
+#pragma unroll
+            for (int k = 0; k + w < NK; k += 2 * w) mk[k] = pk_min(mk[k], mk[k + w]);
+        const uint32_t mm = mk[0];
         uint32_t mx = min(mm & 0xFFFFu, mm >> 16);
         mx = group_min_u32<LPP>(mx);
         m = start ? 0u : mx;
-        uint4 o;
-        uint32_t* ov = &o.x;
+        Words o;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < NK; k++) {
             LE[k] = NE[k]; LO[k] = NO[k];
-            ov[k] = __builtin_amdgcn_perm(NO[k], NE[k], 0x06020400u);   // bytes E.lo, O.lo, E.hi, O.hi
+            o.v[k] = __builtin_amdgcn_perm(NO[k], NE[k], 0x06020400u);  // bytes E.lo, O.lo, E.hi, O.hi
         }
         return o;
     };
     auto is_start = [&](int t) -> bool { return (t == 0) || (BASE == 2 && x == 0) || (BASE == 3 && x == W - 1); };
 
-    uint4 ring[PF];
+    Words ring[PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) { ring[i] = load_c(pixl); advance(xl, pixl); }
 
@@ -411,11 +420,11 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
     for (; t0 + PF <= len; t0 += PF) {
 #pragma unroll
         for (int i = 0; i < PF; i++) {
-            const uint4 cw = ring[i];
+            const Words cw = ring[i];
             ring[i] = load_c(pixl);
             advance(xl, pixl);
-            const uint4 o = step(cw, is_start(t0 + i));
-            *(uint4*)(Lf + byte_off(pix)) = o;
+            const Words o = step(cw, is_start(t0 + i));
+            *(Words*)(Lf + byte_off(pix)) = o;
             advance(x, pix);
         }
     }
@@ -423,14 +432,28 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
 #pragma unroll
     for (int i = 0; i < PF - 1; i++) {
         if (t0 + i < len) {
-            const uint4 o = step(ring[i], is_start(t0 + i));
-            *(uint4*)(Lf + byte_off(pix)) = o;
+            const Words o = step(ring[i], is_start(t0 + i));
+            *(Words*)(Lf + byte_off(pix)) = o;
             advance(x, pix);
         }
     }
 }
 
-template <int LPP, bool WRAP>
+// The along-x lines are the long serial chains (W steps against H for every other direction) and there are
+// few of them (2 H lines a frame): split finer over the lanes, 4 costs a lane (8 at D = 256), they take a
+// third of the instructions per step; every other direction keeps 16 costs a lane.
+#ifndef FSGM_AGG_DX
+#define FSGM_AGG_DX 4
+#endif
+#ifndef FSGM_AGG_DO
+#define FSGM_AGG_DO 16
+#endif
+template <int D> struct AggSplit {
+    static constexpr int along_x = D >= 256 && FSGM_AGG_DX < 8 ? 8 : FSGM_AGG_DX;
+    static constexpr int other = D >= 256 && FSGM_AGG_DO < 8 ? 8 : FSGM_AGG_DO;
+};
+
+template <int D, bool WRAP, bool FINE>
 __global__ __launch_bounds__(256) void agg_packed_kernel(AggArgs a) {
     // which direction slot does this block belong to (block-uniform)
     int slot = 0;
@@ -439,11 +462,12 @@ __global__ __launch_bounds__(256) void agg_packed_kernel(AggArgs a) {
         if (i < a.ndirs && (int)blockIdx.x >= a.blk_begin[i]) slot = i;
     const int code = a.dir_code[slot];
     const bool mirror = (code & 4) != 0;
+    constexpr int DO = AggSplit<D>::other, DX = FINE ? AggSplit<D>::along_x : DO;
     switch (code & 3) {                 // 0: along x, 1: along y, 2: x+1,y+1, 3: x-1,y+1
-        case 0: agg_packed_body<LPP, WRAP, 0>(a, slot, mirror); break;
-        case 1: agg_packed_body<LPP, WRAP, 1>(a, slot, mirror); break;
-        case 2: agg_packed_body<LPP, WRAP, 2>(a, slot, mirror); break;
-        default: agg_packed_body<LPP, WRAP, 3>(a, slot, mirror); break;
+        case 0: agg_packed_body<D, DX, WRAP, 0>(a, slot, mirror); break;
+        case 1: agg_packed_body<D, DO, WRAP, 1>(a, slot, mirror); break;
+        case 2: agg_packed_body<D, DO, WRAP, 2>(a, slot, mirror); break;
+        default: agg_packed_body<D, DO, WRAP, 3>(a, slot, mirror); break;
     }
 }
 
@@ -742,7 +766,7 @@ int agg_packed_lpp(int D) {
 
 // Fill blk_begin / dir_code for `paths` directions.  Long (horizontal) lines first so that the
 // W-step chains start before the H-step ones.
-static void plan_dirs(AggArgs& a, int paths, int lines_per_block) {
+static void plan_dirs(AggArgs& a, int paths, int lines_per_block_x, int lines_per_block) {
     static const int order8[8] = {0, 4, 1, 5, 2, 6, 3, 7};
     static const int order4[4] = {0, 4, 1, 5};      // also the 2-slot horizontal-only plan: {0, 4}
     a.ndirs = paths;
@@ -752,34 +776,48 @@ static void plan_dirs(AggArgs& a, int paths, int lines_per_block) {
         a.dir_code[i] = code;
         a.blk_begin[i] = acc;
         const int nlines = (code & 3) == 0 ? a.H : a.W;
-        acc += (nlines + lines_per_block - 1) / lines_per_block;
+        const int lpb = (code & 3) == 0 ? lines_per_block_x : lines_per_block;
+        acc += (nlines + lpb - 1) / lpb;
     }
     for (int i = paths; i <= 8; i++) a.blk_begin[i] = acc;
     for (int i = paths; i < 8; i++) a.dir_code[i] = 0;
 }
 
-template <int LPP>
+// FSGM_AGG_FINE=0 keeps 16 costs a lane along x too (the round-1 split), for comparison
+static bool agg_fine() {
+    static const bool v = [] { const char* e = getenv("FSGM_AGG_FINE"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+template <int D>
 static void launch_packed(hipStream_t st, AggArgs& a, int paths, int frames, bool wrap) {
-    plan_dirs(a, paths, 4 * (64 / LPP));
+    const bool fine = agg_fine();
+    constexpr int DO = AggSplit<D>::other, DX = AggSplit<D>::along_x;
+    plan_dirs(a, paths, 4 * (64 / (D / (fine ? DX : DO))), 4 * (64 / (D / DO)));
     dim3 grid(a.blk_begin[8], frames);
-    if (wrap) hipLaunchKernelGGL((agg_packed_kernel<LPP, true>), grid, dim3(256), 0, st, a);
-    else      hipLaunchKernelGGL((agg_packed_kernel<LPP, false>), grid, dim3(256), 0, st, a);
+    if (wrap) {
+        if (fine) hipLaunchKernelGGL((agg_packed_kernel<D, true, true>), grid, dim3(256), 0, st, a);
+        else      hipLaunchKernelGGL((agg_packed_kernel<D, true, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (fine) hipLaunchKernelGGL((agg_packed_kernel<D, false, true>), grid, dim3(256), 0, st, a);
+        else      hipLaunchKernelGGL((agg_packed_kernel<D, false, false>), grid, dim3(256), 0, st, a);
+    }
 }
 
 void launch_aggregate(hipStream_t st, AggArgs a, int paths, int frames, int kernel_kind) {
     if (kernel_kind == AGG_GENERIC) {
-        plan_dirs(a, paths, 4);
+        plan_dirs(a, paths, 4, 4);
         dim3 grid(a.blk_begin[8], frames);
         hipLaunchKernelGGL(agg_generic_kernel, grid, dim3(256), 0, st, a);
         return;
     }
     const bool wrap = kernel_kind == AGG_PACKED_WRAP;
-    switch (agg_packed_lpp(a.D)) {
-        case 1: launch_packed<1>(st, a, paths, frames, wrap); break;
-        case 2: launch_packed<2>(st, a, paths, frames, wrap); break;
-        case 4: launch_packed<4>(st, a, paths, frames, wrap); break;
-        case 8: launch_packed<8>(st, a, paths, frames, wrap); break;
+    switch (a.D) {
         case 16: launch_packed<16>(st, a, paths, frames, wrap); break;
+        case 32: launch_packed<32>(st, a, paths, frames, wrap); break;
+        case 64: launch_packed<64>(st, a, paths, frames, wrap); break;
+        case 128: launch_packed<128>(st, a, paths, frames, wrap); break;
+        case 256: launch_packed<256>(st, a, paths, frames, wrap); break;
         default: break;
     }
 }

@@ -94,6 +94,8 @@ constexpr int DPP_QUAD_1032 = 0xB1;        // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_2301 = 0x4E;        // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_SHL1 = 0x101;        // lane i <- lane i+1 (within a row of 16)
 constexpr int DPP_ROW_SHR1 = 0x111;        // lane i <- lane i-1
+constexpr int DPP_WAVE_SHL1 = 0x130;       // lane i <- lane i+1 across the whole wave
+constexpr int DPP_WAVE_SHR1 = 0x138;       // lane i <- lane i-1 across the whole wave
 constexpr int DPP_ROW_MIRROR = 0x140;      // i <-> 15-i
 constexpr int DPP_ROW_HALF_MIRROR = 0x141; // i <-> 7-i within each half row
 
@@ -102,7 +104,7 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
 }
 
-// min over a group of G adjacent lanes (G = 1,2,4,8,16, group aligned), result in every lane.
+// min over a group of G adjacent lanes (G = 1,2,4,8,16,32, group aligned), result in every lane.
 // v_min_u32 with the DPP modifier on its first source: one instruction per butterfly level
 // (the compiler emits mov + mov_dpp + min for the builtin form).  The s_nop covers the
 // VALU-write -> DPP-read hazard (2 wait states), which hipcc does not pad inside asm.
@@ -113,6 +115,11 @@ __device__ __forceinline__ uint32_t group_min_u32(uint32_t x) {
     if (G >= 4)  FSGM_MIN_DPP(x, "quad_perm:[2,3,0,1]");
     if (G >= 8)  FSGM_MIN_DPP(x, "row_half_mirror");
     if (G >= 16) FSGM_MIN_DPP(x, "row_mirror");
+    if (G >= 32) {                                            // rows 0<->1 and 2<->3 (gfx950 v_permlane16_swap)
+        uint32_t y = x;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+        x = min(x, y);
+    }
     return x;
 }
 

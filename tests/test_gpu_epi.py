@@ -67,6 +67,9 @@ AGG_CASES = [
     (64, 48, 16, 100, 200, 255, "packed16/wrap"),
     (37, 23, 128, 90, 120, 255, "packed16/wrap"),
     (45, 31, 64, 6, 64, 255, "packed16/wrap"),
+    (30, 17, 32, 70, 90, 255, "packed16/wrap"),
+    (23, 13, 256, 90, 120, 255, "packed16/wrap"),
+    (131, 9, 128, 6, 64, 24, "packed16/nowrap"),             # along-x lines past two workgroups of the fine split
     (33, 21, 20, 6, 64, 24, "generic"),
     (21, 17, 7, 100, 200, 255, "generic"),
     (9, 5, 1, 6, 64, 24, "generic"),
@@ -463,3 +466,32 @@ def test_sgm_call_shape(gpu_lib, oracle, W, H, D, P1, P2, paths):
     np.testing.assert_array_equal(gS, want[:-1].reshape(H, W, D))
     np.testing.assert_array_equal(gmc, mc)
     np.testing.assert_array_equal(gbd, bd)
+
+
+def _coarse_split_worker(q):
+    """The line kernels with 16 costs a lane along x too (FSGM_AGG_FINE=0, read once per process)."""
+    import os
+    os.environ["FSGM_AGG_FINE"] = "0"
+    from fsgm_amd import sgm, synth as sy
+    out = []
+    for W, H, D, P1, P2, cmax in [(70, 21, 128, 6, 64, 24), (45, 31, 64, 90, 120, 255), (19, 11, 256, 3, 20, 24)]:
+        Cv = sy.cost_volume(W, H, D, seed=W + D, cmax=cmax)
+        out.append(sgm(Cv, P1, P2, paths=8, return_sum=True)[2].copy())
+    q.put(out)
+
+
+def test_line_kernels_coarse_split_matches_the_oracle(gpu_lib, oracle):
+    """Both lane splits of agg_packed_kernel stay checked: the default (4 costs a lane along x) by every line-kernel
+    test above, the 16-costs-a-lane split here, in a process of its own."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_coarse_split_worker, args=(q,))
+    p.start()
+    got = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for (W, H, D, P1, P2, cmax), g in zip([(70, 21, 128, 6, 64, 24), (45, 31, 64, 90, 120, 255), (19, 11, 256, 3, 20, 24)], got):
+        Cv = synth.cost_volume(W, H, D, seed=W + D, cmax=cmax)
+        want = oracle.epi_aggregate(Cv, P1, P2, 8)[:-1].reshape(H, W, D)
+        np.testing.assert_array_equal(g, want, err_msg=f"{W}x{H}x{D}")
