@@ -111,6 +111,26 @@ def pyramid3(args):
     for _ in range(iters):
         pyramidal_sgm(I0, I1, 3)
     host_ms = (time.perf_counter() - t0) / iters * 1e3
+    # throughput form: independent plans (one stream each) started before any is waited for
+    in_flight = {}
+    for n in (2, 4, 8):
+        plans = [PyramidPlan(W, H, 3, 3) for _ in range(n)]
+        try:
+            for f, pl in enumerate(plans):
+                pl.upload(np.roll(I0, 13 * f, axis=2), np.roll(I1, 13 * f, axis=2))
+            rounds = max(3, iters)
+            for timed in (False, True):
+                t0 = time.perf_counter()
+                for _ in range(rounds):
+                    for pl in plans:
+                        pl.run()
+                for pl in plans:
+                    pl.sync()
+                dt = time.perf_counter() - t0
+            in_flight[str(n)] = {"ms_per_pair": dt / (rounds * n) * 1e3, "pairs_per_s": rounds * n / dt, "speedup_vs_sequential": total * rounds * n / (dt * 1e3)}
+        finally:
+            for pl in plans:
+                pl.close()
     levels = []
     for (w, h) in sizes:                                      # coarse to fine, stage by stage
         with PydPlan(w, h, w, h, 5, 5, 2, 1) as lp:
@@ -123,7 +143,7 @@ def pyramid3(args):
     print(json.dumps({"metric": "pyramidal_sgm (3-level calc_pyd_cost_sgm pyramid), device time per image pair", "value": total, "unit": "ms",
                       "higher_is_better": False, "n_gpus": 1, "dtype": "u8", "data": "synthetic",
                       "config": {"workload": "pyramid 1242x375 / 621x188 / 311x94 RGB, 11x11 window (D=121), 8 paths, 2 passes"},
-                      "voxel_paths_per_s": vp / (total * 1e-3), "host_call_ms": host_ms, "levels": levels}), flush=True)
+                      "voxel_paths_per_s": vp / (total * 1e-3), "host_call_ms": host_ms, "plans_in_flight": in_flight, "levels": levels}), flush=True)
 
 
 def pyramid3_ng(args):

@@ -79,11 +79,11 @@ static void select_kernel(fsgm_epi_plan* p) {
     p->kernel_kind = nowrap ? AGG_PACKED_NOWRAP : AGG_PACKED_WRAP;
     // the fused sweeps cover the 8-path no-wrap case; everything else stays on the line kernels
     // (3*P2 <= 255: the excess sum of three paths fits a byte)
-    // Auto mode takes the fused pipelines only for batches: their fixed latency (row blocks of the sweeps,
-    // three passes along 1242-pixel rows for a pair) is ~1.1-1.6 ms whatever the frame count, while the
-    // line kernels scale with it.  Measured crossovers at 1242x375x128 (ms per batch, line vs fused):
-    // 8 paths 4 frames 1.53 / 1.77, 6 frames 2.22 / 1.81; 4 paths 8 frames 1.26 / 1.41, 16 frames 2.47 / 1.85.
-    const int min_batch = p->prm.paths == 8 ? 5 : 10;
+    // Auto mode takes the fused pipelines only for batches: their latency (H rows in sequence for a sweep, down then
+    // up; three passes along 1242-pixel rows for a pair) is 1.0 / 2.0 ms (4 / 8 paths) whatever the frame count,
+    // while the line kernels scale with it.  Measured at 1242x375x128 (ms per batch, line vs fused):
+    // 8 paths 8 frames 1.96 / 2.20, 12 frames 2.89 / 2.29; 4 paths 8 frames 1.18 / 1.19, 12 frames 1.67 / 1.28.
+    const int min_batch = p->prm.paths == 8 ? 10 : 9;
     const bool want = p->agg_mode == 2 || (p->agg_mode == 0 && p->batch >= min_batch);
     // (P1 <= P2: the fused kernels' form of the step clamps path states at P2 first, epi_sweep.hip)
     const bool fusable = nowrap && p->P1 <= p->P2;

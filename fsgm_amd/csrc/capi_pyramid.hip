@@ -165,6 +165,13 @@ fsgm_status fsgm_pyramid_plan_run(fsgm_pyramid_plan* p) {
     return pyramid_enqueue(p);
 }
 
+fsgm_status fsgm_pyramid_plan_sync(fsgm_pyramid_plan* p) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_HIP(hipSetDevice(p->device));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    return FSGM_OK;
+}
+
 fsgm_status fsgm_pyramid_plan_run_images(fsgm_pyramid_plan* p) {
     FSGM_REQUIRE(p, "null plan");
     FSGM_HIP(hipSetDevice(p->device));

@@ -29,6 +29,7 @@ def _bind(lib):
     lib.fsgm_pyramid_plan_upload.argtypes = [vp, vp, vp]
     lib.fsgm_pyramid_plan_run.argtypes = [vp]
     lib.fsgm_pyramid_plan_run_images.argtypes = [vp]
+    lib.fsgm_pyramid_plan_sync.argtypes = [vp]
     lib.fsgm_pyramid_plan_download.argtypes = [vp, i32, vp, vp]
     lib.fsgm_pyramid_plan_download_gray.argtypes = [vp, i32, vp, vp]
     lib.fsgm_pyramid_plan_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
@@ -115,6 +116,10 @@ class PyramidPlan:
 
     def run(self):
         check(self.lib.fsgm_pyramid_plan_run(self._h))
+
+    def sync(self):
+        """Wait for the queued work; plans started with run() before any sync() overlap on the device."""
+        check(self.lib.fsgm_pyramid_plan_sync(self._h))
 
     def run_images(self):
         """Only impyramid / rgb2gray (the level images), no matching."""

@@ -110,8 +110,8 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** plan, int32_t width, int32_t he
                                  int32_t dMax, int32_t batch, const fsgm_epi_params* prm);
 void        fsgm_epi_plan_destroy(fsgm_epi_plan* plan);
 fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t P2, double vMax);
-/* Aggregation strategy: 0 = auto (a fused pipeline when eligible and the plan holds a batch -- 5 frames or
- * more for 8 paths, 10 or more for 4 paths, the measured crossovers: the
+/* Aggregation strategy: 0 = auto (a fused pipeline when eligible and the plan holds a batch -- 10 frames or
+ * more for 8 paths, 9 or more for 4 paths, the measured crossovers at 1242x375x128: the
  * sweeps for 8 paths -- D = 16<<k, no-wrap penalties with 3*P2 <= 255 -- the pair kernels for the
  * shipped 4 paths -- 2*P2 <= 255; else the per-direction line kernels), 1 = line kernels, 2 = the
  * fused pipeline whenever eligible.  Results are identical. */
@@ -284,6 +284,10 @@ void        fsgm_pyramid_plan_destroy(fsgm_pyramid_plan* plan);
 fsgm_status fsgm_pyramid_plan_level_size(fsgm_pyramid_plan* plan, int32_t level, int32_t* width, int32_t* height);
 fsgm_status fsgm_pyramid_plan_upload(fsgm_pyramid_plan* plan, const uint8_t* I0, const uint8_t* I1);
 fsgm_status fsgm_pyramid_plan_run(fsgm_pyramid_plan* plan);              /* asynchronous */
+/* wait for everything queued on the plan.  Plans are independent (own buffers, own stream): several of them
+ * run concurrently when each is started with _run before any is waited for -- the throughput form of the
+ * driver loop (pyramidal_sgm.m:37-75 handles one pair at a time) */
+fsgm_status fsgm_pyramid_plan_sync(fsgm_pyramid_plan* plan);
 /* only the image half of the loop (impyramid, rgb2gray: pyramidal_sgm.m:28-31, 44-45), for callers that run
  * another matcher per level (fsgm_amd.pyramidal_sgm_ng swaps calc_pyd_cost_sgm_ng in); asynchronous */
 fsgm_status fsgm_pyramid_plan_run_images(fsgm_pyramid_plan* plan);

@@ -123,8 +123,9 @@ def test_config4_three_level_pyramid_full_size(gpu_lib, oracle):
 
 # ------------------------------------------------------------------------------------------- config 5
 def test_config5_batch_of_8_kitti_pairs(gpu_lib, oracle):
-    """8 distinct 1242x375x128 pairs through fsgm_calc_cost_sgm_batch_host with 8 paths (the fused sweeps):
-    frames 0 and 7 against the oracle, every frame against a single-frame call (the line kernels)."""
+    """8 distinct 1242x375x128 pairs with 8 paths: fsgm_calc_cost_sgm_batch_host (a batch this small takes the line
+    kernels) with frames 0 and 7 against the oracle and every frame against a single-frame call; then the same 8 pairs
+    resident in a plan through the fused sweeps, every frame against the batch call."""
     W, H, D, B = 1242, 375, 128, 8
     frames = []
     for s in range(B):
@@ -140,6 +141,17 @@ def test_config5_batch_of_8_kitti_pairs(gpu_lib, oracle):
         bd, mc = calc_cost_sgm(*frames[s][:2], D, 0.3, *frames[s][2:], 6, 64, paths=8)
         np.testing.assert_array_equal(res[s][1], mc, err_msg=f"frame {s} minC vs single call")
         np.testing.assert_array_equal(res[s][0], bd, err_msg=f"frame {s} bestD vs single call")
+    with EpiPlan(W, H, D, B, paths=8) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        for s in range(B):
+            plan.upload(s, *frames[s])
+        plan.set_agg_mode(2)
+        plan.run()
+        assert plan.kernel_name == "sweep16/nowrap"
+        for s in range(B):
+            gbd, gmc = plan.download(s)
+            np.testing.assert_array_equal(gmc, res[s][1], err_msg=f"frame {s} minC, fused sweeps")
+            np.testing.assert_array_equal(gbd, res[s][0], err_msg=f"frame {s} bestD, fused sweeps")
 
 
 def test_cost_bound_reset_before_a_fused_run(gpu_lib, oracle):
@@ -155,6 +167,7 @@ def test_cost_bound_reset_before_a_fused_run(gpu_lib, oracle):
         assert plan.kernel_name == "packed16/wrap"
         for f in range(B):
             plan.upload(f, I1, I2, pd0, nd, off)
+        plan.set_agg_mode(2)
         plan.run()
         assert plan.kernel_name == "sweep16/nowrap"
         for f in (0, B - 1):

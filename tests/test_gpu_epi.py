@@ -245,7 +245,7 @@ def test_cost_volume_kitti_shape_general_field(gpu_lib, oracle):
         np.testing.assert_array_equal(plan.download_cost(0), want)
 
 
-@pytest.mark.parametrize("paths,n", [(8, 5), (4, 10)])          # auto mode: fused sweeps from 5 frames, pair kernels from 10
+@pytest.mark.parametrize("paths,n", [(8, 10), (4, 9), (8, 5)])  # auto mode: fused sweeps from 10 frames, pair kernels from 9, line kernels below
 def test_batch_matches_single_frames(gpu_lib, oracle, paths, n):
     W, H, D = 96, 64, 64
     frames = []
@@ -364,6 +364,7 @@ def test_sweep_pipeline_is_deterministic_under_back_to_back_runs(gpu_lib, oracle
         want.append((oracle.epi_vz_to_disp(bd, off, 0.3, D + 1), mc))
     with EpiPlan(W, H, D, B, paths=8) as plan:
         plan.set_penalties(6, 64, 0.3)
+        plan.set_agg_mode(2)
         assert plan.kernel_name == "sweep16/nowrap"
         for f in range(B):
             plan.upload_cost(f, vols[f])

@@ -31,6 +31,31 @@ def test_pyramidal_sgm_bit_exact(gpu_lib, oracle, W, H, ch, numPyd):
     np.testing.assert_array_equal(minC, want_minC)
 
 
+def test_pyramid_plans_in_flight(gpu_lib, oracle):
+    """Several PyramidPlans started before any is waited for (one stream each, the throughput form of the level loop):
+    every plan's flow of every level and minC against the oracle, twice (buffers reused)."""
+    W, H, n = 97, 61, 4
+    pairs = [_pair(W, H, 3, seed=70 + f) for f in range(n)]
+    want = [oracle.pyramidal_sgm(a, b, 3) for a, b in pairs]
+    plans = [PyramidPlan(W, H, 3, 3) for _ in range(n)]
+    try:
+        for pl, (a, b) in zip(plans, pairs):
+            pl.upload(a, b)
+        for rep in range(2):
+            for pl in plans:
+                pl.run()
+            for pl in plans:
+                pl.sync()
+            for f, pl in enumerate(plans):
+                for l in (3, 2, 1):
+                    mv, minC = pl.download(l)
+                    np.testing.assert_array_equal(mv, want[f][2][l - 1], err_msg=f"rep {rep} plan {f} level {l}")
+                np.testing.assert_array_equal(minC, want[f][1], err_msg=f"rep {rep} plan {f}")
+    finally:
+        for pl in plans:
+            pl.close()
+
+
 @pytest.mark.parametrize("over", [dict(verSearchHalfWinSize=3, horSearchHalfWinSize=4), dict(adaptiveP2=1, P2=64),
                                   dict(enableDiagonal=0, totalPass=1), dict(aggHalfWinSize=1, P1=10, P2=40),
                                   dict(verSearchHalfWinSize=6, horSearchHalfWinSize=2)])
