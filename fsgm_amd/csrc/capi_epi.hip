@@ -39,6 +39,9 @@ struct fsgm_epi_plan {
     // (see enqueue(): horizontal kernel on stream_h; the frames split into two lanes that sweep
     // down then up on stream / stream_b)
     uint8_t *dLh = nullptr, *dX = nullptr, *dXup = nullptr, *dState = nullptr, *dCkpt = nullptr, *dCkptV = nullptr;
+    // parallel sweeps (sweep_par): Y_up of every frame and the up sweep's own block-boundary states
+    uint8_t *dXupAll = nullptr, *dStateUp = nullptr;
+    bool sweep_par = false;              // AGG_SWEEP only: down and up sweeps side by side, WTA over the three Y volumes
     // epipolar driver (fsgm_epipolar_sgm_of_host): rotation flow, composed flow, RGB staging
     double *dRflow = nullptr, *dFlow = nullptr;
     uint8_t* dRgb = nullptr;
@@ -70,6 +73,12 @@ struct fsgm_epi_plan {
     uint64_t epoch = 1;
 };
 
+// batch sizes at which auto mode moves from the line kernels to the parallel sweeps and on to the full sweep pipeline
+// (8 paths; measured at 1242x375x128); FSGM_EPI_PAR_MIN / FSGM_EPI_PAR_MAX override them
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+static int par_min_batch() { static const int v = env_int("FSGM_EPI_PAR_MIN", 5); return v; }
+static int par_max_batch() { static const int v = env_int("FSGM_EPI_PAR_MAX", 18); return v; }
+
 static void select_kernel(fsgm_epi_plan* p) {
     p->epoch++;
     p->packed = agg_packed_lpp(p->D) != 0;
@@ -83,11 +92,18 @@ static void select_kernel(fsgm_epi_plan* p) {
     // up; three passes along 1242-pixel rows for a pair) is 1.0 / 2.0 ms (4 / 8 paths) whatever the frame count,
     // while the line kernels scale with it.  Measured at 1242x375x128 (ms per batch, line vs fused):
     // 8 paths 8 frames 1.96 / 2.20, 12 frames 2.89 / 2.29; 4 paths 8 frames 1.18 / 1.19, 12 frames 1.67 / 1.28.
-    const int min_batch = p->prm.paths == 8 ? 10 : 9;
-    const bool want = p->agg_mode == 2 || (p->agg_mode == 0 && p->batch >= min_batch);
+    const int min_batch = p->prm.paths == 8 ? par_min_batch() : 9;
+    const bool want = p->agg_mode == 2 || p->agg_mode == 3 || (p->agg_mode == 0 && p->batch >= min_batch);
     // (P1 <= P2: the fused kernels' form of the step clamps path states at P2 first, epi_sweep.hip)
     const bool fusable = nowrap && p->P1 <= p->P2;
-    if (fusable && 3 * p->P2 <= 255 && p->prm.paths == 8 && want) p->kernel_kind = AGG_SWEEP;
+    p->sweep_par = false;
+    if (fusable && 3 * p->P2 <= 255 && p->prm.paths == 8 && want) {
+        p->kernel_kind = AGG_SWEEP;
+        // Between the line kernels and the full pipeline: the down and the up sweep side by side (H rows in sequence
+        // instead of 2 H) with Y_up written out and a WTA kernel over C, Y_dn, Y_up, Y_h: 3 B per voxel more traffic,
+        // half the latency.  Mode 3 forces it; auto takes it while the batch is too small to hide the longer chain.
+        p->sweep_par = p->agg_mode == 3 || (p->agg_mode == 0 && p->batch < par_max_batch());
+    }
     // the shipped 4-path configuration: both axes as pair kernels, the vertical one final (2*P2 <= 255:
     // the excess sum of a pair fits a byte)
     if (fusable && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
@@ -166,7 +182,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dEdge, p->dTicket, p->dErr};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dXupAll, p->dStateUp, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dEdge, p->dTicket, p->dErr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -366,6 +382,17 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     return FSGM_OK;
 }
 
+static fsgm_status ensure_par_buffers(fsgm_epi_plan* p) {
+    if (p->dXupAll) return FSGM_OK;
+    LazySet ls;
+    uint8_t *xu, *su;
+    ls.alloc(&xu, (size_t)p->batch * p->N);
+    ls.alloc(&su, 2 * (size_t)p->batch * sweep_state_bytes(p->W, p->D));
+    if (ls.err != hipSuccess) return lazy_fail(ls, "parallel sweep buffers");
+    p->dXupAll = xu; p->dStateUp = su;
+    return FSGM_OK;
+}
+
 // What a run of `stages` needs before anything is queued: the cost stage rewrites C with census costs
 // (values <= 24), so the bound of the cost values -- and with it the kernel selection -- is settled first;
 // then the buffer set of the selected pipeline.
@@ -376,7 +403,11 @@ static fsgm_status prepare(fsgm_epi_plan* p, int stages) {
         if (changed) select_kernel(p);
     }
     if (stages & (FSGM_STAGE_AGGREGATE | FSGM_STAGE_WTA)) {
-        if (p->kernel_kind == AGG_SWEEP) return ensure_sweep_buffers(p);
+        if (p->kernel_kind == AGG_SWEEP) {
+            fsgm_status st = ensure_sweep_buffers(p);
+            if (st == FSGM_OK && p->sweep_par) st = ensure_par_buffers(p);
+            return st;
+        }
         if (p->kernel_kind == AGG_PAIRS) return ensure_pairs_buffers(p);
     }
     return FSGM_OK;
@@ -403,7 +434,31 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         if (st != FSGM_OK) return st;
         enqueue_cost(p, 0, p->batch);
     }
-    if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_SWEEP) {
+    if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_SWEEP && p->sweep_par) {
+        // three independent chains: the horizontal pair (stream_h), the down sweep (here), the up sweep (stream_b)
+        FSGM_HIP(hipEventRecord(p->ev_fork, p->stream));
+        FSGM_HIP(hipStreamWaitEvent(p->stream_h, p->ev_fork, 0));
+        FSGM_HIP(hipStreamWaitEvent(p->stream_b, p->ev_fork, 0));
+        const size_t ckb = pair_ckpt_bytes(p->W, p->H, p->D, 0);
+        PairArgs h{};
+        h.C = p->dC; h.c_frame_stride = p->N; h.X = p->dLh; h.x_frame_stride = p->N;
+        h.ckpt = p->dCkpt; h.ckpt_frame_stride = ckb;
+        h.W = p->W; h.H = p->H; h.D = p->D; h.P1 = p->P1; h.P2 = p->P2;
+        launch_pair(p->stream_h, h, p->batch, 0, false);
+        FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
+        SweepArgs w;
+        w.C = p->dC; w.c_frame_stride = p->N;
+        w.X = p->dX; w.x_frame_stride = p->N;
+        w.Lh = nullptr; w.lh_frame_stride = 0; w.rec = nullptr; w.s0 = nullptr;
+        w.state_in = w.state_out = p->dState; w.state_frame_stride = p->state_stride;
+        w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
+        launch_sweep(p->stream, w, p->batch, 0);                      // pass-0 paths from above -> Y_dn
+        w.X = p->dXupAll; w.state_in = w.state_out = p->dStateUp;
+        launch_sweep(p->stream_b, w, p->batch, 1);                    // pass-1 paths -> Y_up
+        FSGM_HIP(hipEventRecord(p->ev_b, p->stream_b));
+        FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_h, 0));
+        FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_b, 0));
+    } else if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_SWEEP) {
         // One sweep launch (strips x frames workgroups) cannot fill 256 CUs, so the work is forked:
         // the horizontal pair runs on stream_h, and the frames split into two lanes, each sweeping
         // down and then up (the final up sweep needs its lane's X_dn and the horizontal pair).
@@ -493,7 +548,18 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
         launch_aggregate(p->stream, a, p->prm.paths, p->batch, p->kernel_kind);
     }
-    if ((stages & FSGM_STAGE_WTA) && (p->kernel_kind == AGG_SWEEP || p->kernel_kind == AGG_PAIRS)) {
+    if ((stages & FSGM_STAGE_WTA) && p->kernel_kind == AGG_SWEEP && p->sweep_par) {
+        WtaArgs a;                                   // S = 8 (C + P2) - (Y_dn + Y_up + Y_h), argmin, parabola, vz -> disp
+        a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
+        a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
+        a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
+        a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp && !p->prm.fb_check;
+        SweepSumArgs q;
+        q.C = p->dC; q.Xdn = p->dX; q.Xup = p->dXupAll; q.v_frame_stride = p->N;
+        q.Lh = p->dLh; q.lh_frame_stride = p->N;
+        q.nC = 8; q.P2 = p->P2; q.Sdbg = nullptr;
+        launch_wta_sweep(p->stream, a, q, p->batch);
+    } else if ((stages & FSGM_STAGE_WTA) && (p->kernel_kind == AGG_SWEEP || p->kernel_kind == AGG_PAIRS)) {
         WtaArgs a;                                   // the argmin happened inside the final sweep / pair pass; finish the records
         a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
         a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
@@ -563,7 +629,7 @@ fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* p, int32_t stages) {
 
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* p, int32_t mode) {
     FSGM_REQUIRE(p, "null plan");
-    FSGM_REQUIRE(mode >= 0 && mode <= 2, "agg mode must be 0 (auto), 1 (per-direction kernels) or 2 (fused sweeps)");
+    FSGM_REQUIRE(mode >= 0 && mode <= 3, "agg mode must be 0 (auto), 1 (per-direction kernels), 2 (fused sweeps) or 3 (parallel sweeps)");
     p->agg_mode = mode;
     select_kernel(p);
     return FSGM_OK;
@@ -727,7 +793,7 @@ const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* p) {
     switch (p->kernel_kind) {
         case AGG_PACKED_NOWRAP: return "packed16/nowrap";
         case AGG_PACKED_WRAP: return "packed16/wrap";
-        case AGG_SWEEP: return "sweep16/nowrap";
+        case AGG_SWEEP: return p->sweep_par ? "sweep16par/nowrap" : "sweep16/nowrap";
         case AGG_PAIRS: return "pairs16/nowrap";
         default: return "generic";
     }

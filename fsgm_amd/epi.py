@@ -138,7 +138,7 @@ class EpiPlan:
         check(self.lib.fsgm_epi_plan_set_penalties(self._h, int(P1), int(P2), float(vMax)))
 
     def set_agg_mode(self, mode):
-        """0 auto, 1 per-direction line kernels, 2 fused sweeps when eligible."""
+        """0 auto, 1 per-direction line kernels, 2 fused pipeline when eligible, 3 parallel sweeps (8 paths) when eligible."""
         check(self.lib.fsgm_epi_plan_set_agg_mode(self._h, int(mode)))
 
     def upload(self, frame, I1, I2, pd0, nd, off):

@@ -110,11 +110,12 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** plan, int32_t width, int32_t he
                                  int32_t dMax, int32_t batch, const fsgm_epi_params* prm);
 void        fsgm_epi_plan_destroy(fsgm_epi_plan* plan);
 fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t P2, double vMax);
-/* Aggregation strategy: 0 = auto (a fused pipeline when eligible and the plan holds a batch -- 10 frames or
- * more for 8 paths, 9 or more for 4 paths, the measured crossovers at 1242x375x128: the
- * sweeps for 8 paths -- D = 16<<k, no-wrap penalties with 3*P2 <= 255 -- the pair kernels for the
- * shipped 4 paths -- 2*P2 <= 255; else the per-direction line kernels), 1 = line kernels, 2 = the
- * fused pipeline whenever eligible.  Results are identical. */
+/* Aggregation strategy: 0 = auto, 1 = the per-direction line kernels, 2 = the fused pipeline whenever eligible
+ * (8 paths: horizontal pair + down sweep + final up sweep with the WTA inside -- D = 16<<k, no-wrap penalties with
+ * P1 <= P2 and 3*P2 <= 255; the shipped 4 paths: the pair kernels -- 2*P2 <= 255), 3 = 8 paths only: the down and the
+ * up sweep side by side and a WTA kernel over the three sums (half the latency of 2, 3 B per voxel more traffic).
+ * Auto, 8 paths: line kernels below 5 frames, 3 below 18, 2 from there; 4 paths: line kernels below 9 frames, then 2
+ * (the measured crossovers at 1242x375x128).  Results are identical. */
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* plan, int32_t mode);
 /* host -> HBM (async on the plan's stream) */
 fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* plan, int32_t frame, const uint8_t* I1,

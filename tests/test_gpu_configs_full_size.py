@@ -123,9 +123,9 @@ def test_config4_three_level_pyramid_full_size(gpu_lib, oracle):
 
 # ------------------------------------------------------------------------------------------- config 5
 def test_config5_batch_of_8_kitti_pairs(gpu_lib, oracle):
-    """8 distinct 1242x375x128 pairs with 8 paths: fsgm_calc_cost_sgm_batch_host (a batch this small takes the line
-    kernels) with frames 0 and 7 against the oracle and every frame against a single-frame call; then the same 8 pairs
-    resident in a plan through the fused sweeps, every frame against the batch call."""
+    """8 distinct 1242x375x128 pairs with 8 paths: fsgm_calc_cost_sgm_batch_host (a batch of 8 takes the parallel sweeps)
+    with frames 0 and 7 against the oracle and every frame against a single-frame call (the line kernels); then the same
+    8 pairs resident in a plan through the full sweep pipeline, every frame against the batch call."""
     W, H, D, B = 1242, 375, 128, 8
     frames = []
     for s in range(B):

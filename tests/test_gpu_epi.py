@@ -245,7 +245,7 @@ def test_cost_volume_kitti_shape_general_field(gpu_lib, oracle):
         np.testing.assert_array_equal(plan.download_cost(0), want)
 
 
-@pytest.mark.parametrize("paths,n", [(8, 10), (4, 9), (8, 5)])  # auto mode: fused sweeps from 10 frames, pair kernels from 9, line kernels below
+@pytest.mark.parametrize("paths,n", [(8, 18), (4, 9), (8, 5), (8, 3)])  # auto mode, 8 paths: line kernels / parallel sweeps from 5 frames / full sweeps from 18; 4 paths: pairs from 9
 def test_batch_matches_single_frames(gpu_lib, oracle, paths, n):
     W, H, D = 96, 64, 64
     frames = []
@@ -406,6 +406,49 @@ def test_strip_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, monkeypatch)
                 gbd, gmc = plan.download(f)
                 np.testing.assert_array_equal(gmc, want[f][1], err_msg=f"rep {rep} frame {f}")
                 np.testing.assert_array_equal(gbd, want[f][0], err_msg=f"rep {rep} frame {f}")
+
+
+@pytest.mark.parametrize("subpixel", [1, 0])
+@pytest.mark.parametrize("W,H,D,B", [(150, 70, 128, 3), (97, 200, 64, 2), (1242, 40, 128, 1), (33, 375, 128, 2), (20, 9, 16, 1), (260, 31, 32, 2),
+                                     (70, 50, 256, 1), (1, 9, 64, 1), (9, 1, 64, 2), (96, 64, 64, 7)])
+def test_parallel_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, subpixel):
+    """Aggregation mode 3 (down and up sweeps side by side, Y_up written out, WTA over C, Y_dn, Y_up, Y_h): bestD / minC of
+    every frame and S of the last frame against the oracle, back-to-back runs on reused buffers; then the same plan in
+    mode 2 (buffers shared between the two forms)."""
+    vols = [synth.cost_volume(W, H, D, seed=W + H + f, cmax=24) for f in range(B)]
+    _, _, off = synth.epi_maps(W, H, "general", seed=3)
+    want, S = [], None
+    for v in vols:
+        S = oracle.epi_aggregate(v, 6, 64, 8)
+        bd, mc = oracle.epi_wta(S, W, H, D, subpixel)
+        want.append((oracle.epi_vz_to_disp(bd, off, 0.3, D + 1), mc))
+    with EpiPlan(W, H, D, B, paths=8, subpixel=subpixel) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        for f in range(B):
+            plan.upload_cost(f, vols[f])
+            plan.upload_offset(f, off)
+        for mode, name in ((3, "sweep16par/nowrap"), (2, "sweep16/nowrap"), (3, "sweep16par/nowrap")):
+            plan.set_agg_mode(mode)
+            assert plan.kernel_name == name
+            for _ in range(3):
+                plan.run(STAGE_AGGREGATE | STAGE_WTA)
+            for f in range(B):
+                gbd, gmc = plan.download(f)
+                np.testing.assert_array_equal(gmc, want[f][1], err_msg=f"mode {mode} frame {f}")
+                np.testing.assert_array_equal(gbd, want[f][0], err_msg=f"mode {mode} frame {f}")
+            np.testing.assert_array_equal(plan.download_sum(B - 1), S[:-1].reshape(H, W, D), err_msg=f"mode {mode}")
+
+
+def test_auto_mode_by_batch_size(gpu_lib):
+    """8 paths, no-wrap penalties: line kernels below 5 frames, parallel sweeps below 18, the full sweep pipeline from there;
+    4 paths: line kernels below 9 frames, then the pair kernels."""
+    for paths, B, name in [(8, 4, "packed16/nowrap"), (8, 5, "sweep16par/nowrap"), (8, 17, "sweep16par/nowrap"), (8, 18, "sweep16/nowrap"),
+                           (4, 8, "packed16/nowrap"), (4, 9, "pairs16/nowrap")]:
+        with EpiPlan(32, 16, 64, B, paths=paths) as plan:
+            plan.set_penalties(6, 64, 0.3)
+            assert plan.kernel_name == name, (paths, B)
+            plan.set_penalties(100, 200, 0.3)
+            assert plan.kernel_name == "packed16/wrap"
 
 
 def _sharded_gpu_worker(rank, world, port, n_frames, q):
