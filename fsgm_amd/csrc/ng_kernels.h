@@ -27,6 +27,10 @@ struct NgAggArgs {
     const uint32_t* unsafe; // the cost kernel's flag (null: take the generic kernel)
     const uint16_t* dd;     // [frames][NP][D] place of a candidate in its pixel's list without repeats, 0xFFFF = a repeat
     const uint8_t* dk;      //                 (launch_ng_dedupe); [frames][NP] length of that list.  Null: every candidate is staged
+    const uint32_t* dbox;   // [frames][NP] packed origin of the bounding box of a pixel's motion vectors, or all ones when it is larger
+                            // than the grid matcher takes (launch_ng_dedupe); null: list matcher only
+    const uint32_t* kstat;  // [256] partial sums of the list lengths of a sample of this launch's pixels (launch_ng_dedupe); with `pick` != 0 a kernel
+    int pick;               // leaves at once unless the mean length is >= NG_GRID_MIN_K (pick = 1) or below it (pick = -1)
     int W, H, D;
     int P1, P2;
     int blk_begin[5];
@@ -66,7 +70,7 @@ struct OtfArgs {
 void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames);
 void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames);
 // repeats among the D <= 128 candidates of every pixel (same motion vector and same cost), see ng_dedupe_kernel
-void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, int W, int H, int D, int frames);
+void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, int W, int H, int D, int frames);   // kstat: 256 words, zeroed here
 void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames);
 void launch_ng_subpixel(hipStream_t st, const NgSubpixArgs& a, int frames);
 void launch_otf(hipStream_t st, const OtfArgs& a, int frames);

@@ -86,6 +86,111 @@ __global__ __launch_bounds__(256) void ng_cost_kernel(NgCostArgs a) {
     if (a.unsafe && !(o.mvx > -0x3FF0 && o.mvx < 0x3FF0 && o.mvy > -0x3FF0 && o.mvy < 0x3FF0)) atomicOr(a.unsafe, 1u);
 }
 
+// The same list for the reference's sizes (3x3 expansion, 3x3 cost window: ng_sgm.m:19-20), one thread = one
+// (pixel, hint).  The sample column depends on offx + ax only and the sample row on offy + ay only (:417-418), so
+// the 9 candidates of a hint read a 5x5 patch of image-2 census codes: 25 + 9 gathered loads and 10 double -> int
+// conversions per 9 candidates instead of 162 and 54 (the per-candidate kernel is bound by its gathered loads).
+// The rounded mean of the taps, (int)(1.0 * sum / 9 + 0.5) (:432), is (2 sum + 9) / 18 in integers: 2 sum + 9 is odd,
+// so the quotient sum / 9 + 0.5 is never closer than 1/18 to an integer and no rounding of the double division can
+// cross one.  The wave's 64 x 27 output dwords go through LDS and leave as contiguous stores.
+__global__ __launch_bounds__(256) void ng_cost_hint_kernel(NgCostArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t sOut[4][64 * 27];
+    const int W = a.W, H = a.H;
+    const int NP = W * H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long total = (long long)NP * 9;
+    const long long wbase = ((long long)blockIdx.x * 4 + wave) * 64;       // first (pixel, hint) of this wave
+    if (wbase >= total) return;                                            // wave-uniform
+    const long long gid = min(wbase + lane, total - 1);                    // lanes past the end redo the last one, nothing of theirs is stored
+    const int p = (int)(gid / 9), h = (int)(gid - (long long)p * 9);
+    const int y = p / W, x = p - y * W;
+    const int dy = (h / 3 - 1) * 8, dx = (h % 3 - 1) * 8;
+    const size_t f = blockIdx.y;
+    const double* mvxp = a.mv + f * 2 * (size_t)a.mvW * a.mvH;
+    const double* mvyp = mvxp + (size_t)a.mvW * a.mvH;
+    const int yn = clampi(y + dy, 0, a.mvH - 1), xn = clampi(x + dx, 0, a.mvW - 1);
+    const double mvx = mvxp[(size_t)a.mvW * yn + xn], mvy = mvyp[(size_t)a.mvW * yn + xn];
+    const uint32_t* __restrict__ cen1 = a.cen1 + f * (size_t)NP;
+    const uint32_t* __restrict__ cen2 = a.cen2 + f * (size_t)NP;
+    int X2[5], Y2[5];
+    uint32_t xin = 0, yin = 0, tin = 0;                                    // which sample columns / rows / image-1 taps exist
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        X2[k] = f64_to_i32_x86(__dadd_rn((double)(x + k - 2), mvx));       // :418 with offx + ax = k - 2
+        Y2[k] = f64_to_i32_x86(__dadd_rn((double)(y + k - 2), mvy));       // :417
+        const bool xo = X2[k] >= 0 && X2[k] <= W - 1, yo = Y2[k] >= 0 && Y2[k] <= H - 1;
+        xin |= (uint32_t)xo << k; yin |= (uint32_t)yo << k;
+        X2[k] = xo ? X2[k] : 0; Y2[k] = yo ? Y2[k] : 0;
+    }
+    uint32_t T[9], P[25];
+#pragma unroll
+    for (int ty = 0; ty < 3; ty++)
+#pragma unroll
+        for (int tx = 0; tx < 3; tx++) {
+            const int y1 = y + ty - 1, x1 = x + tx - 1;
+            const bool in = y1 >= 0 && y1 <= H - 1 && x1 >= 0 && x1 <= W - 1;
+            T[ty * 3 + tx] = cen1[(size_t)W * (in ? y1 : y) + (in ? x1 : x)];
+            tin |= (uint32_t)in << (ty * 3 + tx);
+        }
+#pragma unroll
+    for (int ky = 0; ky < 5; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 5; kx++) P[ky * 5 + kx] = cen2[(size_t)W * Y2[ky] + X2[kx]];
+    uint32_t* out = sOut[wave] + lane * 27;
+    int cmx[3], cmy[3];
+    bool far = false;
+#pragma unroll
+    for (int o = 0; o < 3; o++) {
+        cmx[o] = f64_to_i32_x86(__dadd_rn(mvx, (double)(o - 1)));          // :433
+        cmy[o] = f64_to_i32_x86(__dadd_rn(mvy, (double)(o - 1)));          // :434
+        far |= !(cmx[o] > -0x3FF0 && cmx[o] < 0x3FF0 && cmy[o] > -0x3FF0 && cmy[o] < 0x3FF0);
+    }
+    const bool clean = xin == 31u && yin == 31u && tin == 511u;
+    if (__builtin_amdgcn_ballot_w64(!clean) == 0) {
+#pragma unroll
+        for (int ox = 0; ox < 3; ox++)
+#pragma unroll
+            for (int oy = 0; oy < 3; oy++) {
+                uint32_t sum = 0;
+#pragma unroll
+                for (int ty = 0; ty < 3; ty++)
+#pragma unroll
+                    for (int tx = 0; tx < 3; tx++) sum += __popc(T[ty * 3 + tx] ^ P[(oy + ty) * 5 + ox + tx]);
+                uint32_t* o = out + (ox * 3 + oy) * 3;
+                o[0] = (uint32_t)cmx[ox]; o[1] = (uint32_t)cmy[oy]; o[2] = (2u * sum + 9u) / 18u;
+            }
+    } else {
+#pragma unroll
+        for (int ox = 0; ox < 3; ox++)
+#pragma unroll
+            for (int oy = 0; oy < 3; oy++) {
+                uint32_t sum = 0;
+#pragma unroll
+                for (int ty = 0; ty < 3; ty++)
+#pragma unroll
+                    for (int tx = 0; tx < 3; tx++) {
+                        const uint32_t ok = (tin >> (ty * 3 + tx)) & (xin >> (ox + tx)) & (yin >> (oy + ty)) & 1u;   // :405-421
+                        sum += ok ? (uint32_t)__popc(T[ty * 3 + tx] ^ P[(oy + ty) * 5 + ox + tx]) : 5u;
+                    }
+                uint32_t* o = out + (ox * 3 + oy) * 3;
+                o[0] = (uint32_t)cmx[ox]; o[1] = (uint32_t)cmy[oy]; o[2] = (2u * sum + 9u) / 18u;
+            }
+    }
+    // the fast matcher compares motion vectors as packed 16-bit pairs (ng_pack_mv): tell it when one does not fit
+    if (a.unsafe && far) atomicOr(a.unsafe, 1u);
+    __builtin_amdgcn_wave_barrier();
+    const int ndw = (int)min((long long)64, total - wbase) * 27;           // dwords this wave owns
+    uint32_t* dst = (uint32_t*)(a.C + f * (size_t)NP * 81) + (size_t)wbase * 27;
+    if (((uintptr_t)dst & 15u) == 0) {                                     // wave-uniform
+        for (int i = lane * 4; i < ndw; i += 256) {
+            if (i + 4 <= ndw) *(uint4*)(dst + i) = *(const uint4*)(sOut[wave] + i);
+            else for (int k = i; k < ndw; k++) dst[k] = sOut[wave][k];
+        }
+    } else {
+        for (int i = lane; i < ndw; i += 64) dst[i] = sOut[wave][i];
+    }
+}
+
 // One matcher step shared by both variants (calc_pyd_cost_sgm_ng.cpp:39-78 /
 // calc_cost_sgm_ng.cpp:46-83): the caller's lanes stride over the current candidates; Lpre is in
 // LDS.  Returns the int path cost (C.cost + best - m), not narrowed.
@@ -163,6 +268,31 @@ __global__ __launch_bounds__(256) void ng_agg_kernel(NgAggArgs a) {
 // Same results as ng_agg_kernel (the order-free u32 sums are atomic adds there and here).
 // =============================================================================================
 struct NgPre { const int32_t* x; const int32_t* y; const uint32_t* c8; const uint32_t* cp; };
+
+// grid form of the matcher (ng_agg_grid_kernel): a pixel whose motion vectors fit a box of NG_GB x NG_GB stages
+// its entries in a grid of that box plus 4 cells around it
+constexpr int NG_GB = 12;
+constexpr int NG_GS = NG_GB + 8;
+constexpr int NG_GCELLS = NG_GS * NG_GS;
+constexpr uint32_t NG_BOX_WIDE = 0xFFFFFFFFu;
+constexpr uint32_t NG_GRID_MIN_K = 16;   // mean list length from which the grid form is the faster one (it costs the same at any length)
+
+// adaptive choice between the two aggregation kernels, made on the device: both are launched, each sums the 256 partial
+// list-length sums of the dedupe kernel and the one the mean length does not favour returns (block-uniform)
+__device__ __forceinline__ bool ng_agg_not_mine(const NgAggArgs& a, uint32_t* scratch) {
+    if (a.pick == 0) return false;
+    if (threadIdx.x == 0) *scratch = 0;
+    __syncthreads();
+    uint32_t v = threadIdx.x < 256 ? a.kstat[threadIdx.x] : 0u;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += (uint32_t)__shfl_xor((int)v, s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(scratch, v);
+    __syncthreads();
+    const unsigned long long npix = ((((unsigned long long)a.W * a.H * gridDim.y + 3) / 4 + 15) / 16) * 4;   // the dedupe kernel's sample: every 16th workgroup of 4 pixels
+    const bool high = (unsigned long long)*scratch >= (unsigned long long)NG_GRID_MIN_K * npix;
+    __syncthreads();
+    return a.pick > 0 ? !high : high;
+}
 
 // motion vector as 2 x u16 (valid for |mv| < 0x3FF0: the launch's unsafe flag is raised otherwise)
 constexpr uint32_t NG_PADKEY = 0xC000C000u;   // a staged key no candidate in the packed range is equal or near to
@@ -248,9 +378,20 @@ __device__ __forceinline__ void ng_match4_pair(const NgPre& q, int D, int mvxa, 
 // the LAST is kept ("last exact match wins", :60-62: the kept entries stay in their order).  One wave per pixel:
 // keys (mvx, mvy, C) packed into 31 bits, every lane finds the last index holding its key, kept entries are
 // ranked with two ballots.  A pixel with a vector outside +-4095 keeps its whole list.
+//
+// "The last index holding my key" without comparing all pairs: up to three rounds over a 256-slot table in LDS.
+// In a round every unsettled entry posts its index + 1 to the slot its key hashes to (ds_max), then reads the slot's
+// winner and that entry's key.  Entries with one key share a slot, so either the winner carries their key -- it is
+// then the last of them and the whole group is settled -- or it belongs to another key and the whole group goes on
+// to the next round with another hash.  81 keys in 256 slots leave a few groups for round two and next to none
+// for round three; what is left after that takes the all-pairs scan (wave-uniform branch).
+//
+// Also written per pixel: the bounding box of its motion vectors, as its packed origin (ng_pack_mv) when both
+// sides are <= NG_GB, NG_BOX_WIDE otherwise -- what the grid form of the matcher (ng_agg_grid_kernel) needs.
 __global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__ C, uint16_t* __restrict__ dd, uint8_t* __restrict__ dk,
-                                                        int NPtot, int D) {
+                                                        uint32_t* __restrict__ dbox, uint32_t* __restrict__ kstat, int NPtot, int D) {
     __shared__ __attribute__((aligned(16))) uint32_t sk[4][128];
+    __shared__ __attribute__((aligned(16))) uint32_t stab[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x * 4 + wave;
     if (p >= NPtot) return;                                   // wave-uniform
@@ -263,20 +404,50 @@ __global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__
     };
     bool ok0 = true, ok1 = true;
     const Cand z = {0, 0, 0};
-    const uint32_t k0 = key_of(has0 ? c[d0] : z, ok0), k1 = key_of(has1 ? c[d1] : z, ok1);
+    const Cand e0 = has0 ? c[d0] : z, e1 = has1 ? c[d1] : z;
+    const uint32_t k0 = key_of(e0, ok0), k1 = key_of(e1, ok1);
     sk[wave][d0] = has0 ? k0 : 0xFFFFFFFFu;
     sk[wave][d1] = has1 ? k1 : 0xFFFFFFFFu;
     const bool all_ok = __builtin_amdgcn_ballot_w64(!(ok0 && ok1)) == 0;
     __builtin_amdgcn_wave_barrier();
+    if (dbox) {
+        uint32_t box = NG_BOX_WIDE;
+        if (all_ok) {                                                      // every |mv| < 4096: biased values are small and positive
+            const Cand f0 = has0 ? e0 : c[0], f1 = has1 ? e1 : f0;         // lanes without an entry repeat one that exists
+            const uint32_t xl = wave_min_u32((uint32_t)(min(f0.mvx, f1.mvx) + 0x4000)), xh = 0x8000u - wave_min_u32((uint32_t)(0x4000 - max(f0.mvx, f1.mvx)));
+            const uint32_t yl = wave_min_u32((uint32_t)(min(f0.mvy, f1.mvy) + 0x4000)), yh = 0x8000u - wave_min_u32((uint32_t)(0x4000 - max(f0.mvy, f1.mvy)));
+            if (xh - xl < (uint32_t)NG_GB && yh - yl < (uint32_t)NG_GB) box = (xl << 16) | yl;
+        }
+        if (lane == 0) dbox[p] = box;
+    }
     int last0 = d0, last1 = d1;
     if (all_ok) {
-        for (int e = 0; e < D; e += 4) {
-            const uint4 k4 = *(const uint4*)(&sk[wave][e]);
-            const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w};
+        bool open0 = has0, open1 = has1;
+        uint32_t* tab = stab[wave];
+#pragma unroll 1
+        for (int round = 0; round < 3; round++) {
+            if (__builtin_amdgcn_ballot_w64(open0 || open1) == 0) break;
+            *(uint4*)(tab + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t mul = round == 0 ? 0x9E3779B1u : round == 1 ? 0x85EBCA77u : 0xC2B2AE3Du;
+            const uint32_t s0 = (k0 * mul) >> 24, s1 = (k1 * mul) >> 24;
+            if (open0) atomicMax(&tab[s0], (uint32_t)d0 + 1u);
+            if (open1) atomicMax(&tab[s1], (uint32_t)d1 + 1u);
+            __builtin_amdgcn_wave_barrier();
+            if (open0) { const int w = (int)tab[s0] - 1; if (sk[wave][w] == k0) { last0 = w; open0 = false; } }
+            if (open1) { const int w = (int)tab[s1] - 1; if (sk[wave][w] == k1) { last1 = w; open1 = false; } }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (__builtin_amdgcn_ballot_w64(open0 || open1) != 0) {
+            last0 = d0; last1 = d1;
+            for (int e = 0; e < D; e += 4) {
+                const uint4 k4 = *(const uint4*)(&sk[wave][e]);
+                const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                last0 = ka[i] == k0 ? e + i : last0;
-                last1 = ka[i] == k1 ? e + i : last1;
+                for (int i = 0; i < 4; i++) {
+                    last0 = ka[i] == k0 ? e + i : last0;
+                    last1 = ka[i] == k1 ? e + i : last1;
+                }
             }
         }
     }
@@ -286,7 +457,10 @@ __global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__
     const int n0 = __popcll(b0);
     if (has0) dd[(size_t)p * D + d0] = keep0 ? (uint16_t)__popcll(b0 & below) : (uint16_t)0xFFFF;
     if (has1) dd[(size_t)p * D + d1] = keep1 ? (uint16_t)(n0 + __popcll(b1 & below)) : (uint16_t)0xFFFF;
-    if (lane == 0) dk[p] = (uint8_t)(n0 + __popcll(b1));
+    if (lane == 0) {
+        dk[p] = (uint8_t)(n0 + __popcll(b1));
+        if (kstat && (blockIdx.x & 15) == 0) atomicAdd(&kstat[(blockIdx.x >> 4) & 255], (uint32_t)(n0 + __popcll(b1)));   // a 1-in-16 sample of the pixels
+    }
 }
 
 // One THREAD per (line, candidate): a 256-thread workgroup advances 256/D lines (3 at D = 81, 95 % of the
@@ -295,6 +469,7 @@ __global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__
 // one barrier per step.
 __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sNg[];   // [line][2 buffers][4 arrays][Dp], then [line][8]: 3 minima, the staged lists' lengths at [4 + step parity]
+    if (ng_agg_not_mine(a, sNg)) return;
     int slot = 0;
 #pragma unroll
     for (int i = 1; i < 4; i++)
@@ -377,6 +552,157 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
         }
         __syncthreads();
         uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
+      }
+    }
+}
+
+// ng_agg_lines_kernel with a second form of the matcher.  What a candidate needs from the predecessor's list is the
+// cost of the last entry with its own motion vector and the smallest cost + P1 among the entries within 2 on both
+// axes (:39-78) -- a 5x5 neighbourhood in motion-vector space.  A pixel whose motion vectors fit a NG_GB x NG_GB box
+// (launch_ng_dedupe writes the box; smooth hint maps always do) also stages its kept entries in a grid over that box
+// plus 4 cells around it: per cell the smallest cost + P1 (ds_min) and (place + 1) << 8 | cost of the last entry
+// (ds_max, places grow with the candidate index).  A candidate of the next pixel then reads 25 cells instead of
+// walking the list -- ~60 instructions against 8 per entry -- and one farther than 2 from the box matches nothing.
+// Three grids per line rotate (read the one staged a step ago, stage, clear the third), so a step still has one
+// barrier.  The lists are staged as before, and a step whose predecessors (of any of the workgroup's lines) did not
+// fit a box takes the list matcher: same results either way.
+__global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sNg[];   // lists [line][2][4][Dp]; grids [line][3][2][NG_GCELLS]; [line][8] minima ring + lengths; [2][line] box flags
+    if (ng_agg_not_mine(a, sNg)) return;
+    int slot = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if ((int)blockIdx.x >= a.blk_begin[i]) slot = i;
+    slot = a.slot_of[slot];
+    const int base = slot & 1;                               // 0: along x, 1: along y
+    const bool mirror = slot >= 2;
+    const int W = a.W, H = a.H, D = a.D, Dp = (D + 3) & ~3;
+    const int LPB = 256 / D;                                  // lines per workgroup
+    const int NP = W * H;
+    const int nlines = base == 0 ? H : W;
+    const int len = base == 0 ? W : H;
+    const int g = threadIdx.x;
+    const int ll = min(g / D, LPB - 1), cand = g - (g / D) * D;
+    const bool tact = g < LPB * D;                            // this thread holds a candidate
+    int bb = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if ((int)blockIdx.x >= a.blk_begin[i]) bb = i;
+    const int line = ((int)blockIdx.x - a.blk_begin[bb]) * LPB + ll;
+    const bool lact = tact && line < nlines;
+    const int linec = min(line, nlines - 1);
+    const size_t f = blockIdx.y;
+    const Cand* __restrict__ Cf = a.C + f * (size_t)NP * D;
+    uint32_t* __restrict__ Sf = a.S + f * (size_t)NP * D;
+    uint32_t* buf0 = sNg + (size_t)ll * 8 * Dp;
+    uint32_t* buf1 = buf0 + 4 * Dp;
+    uint32_t* const grids = sNg + (size_t)LPB * 8 * Dp + (size_t)ll * 6 * NG_GCELLS;
+    uint32_t* gpre = grids;                                   // staged by the previous step: [0..CELLS) smallest cost + P1, [CELLS..2 CELLS) last entry
+    uint32_t* gcur = grids + 2 * NG_GCELLS;
+    uint32_t* gnxt = grids + 4 * NG_GCELLS;
+    uint32_t* const tailw = sNg + (size_t)LPB * 8 * Dp + (size_t)LPB * 6 * NG_GCELLS;
+    uint32_t* smin = tailw + ll * 8;                          // [0..2] minima ring, [4 + (t & 1)] entries staged by step t
+    uint32_t* const sflag = tailw + LPB * 8;                  // [t & 1][line]: the pixel of step t fits a box
+    if (cand < 3 && tact) smin[cand] = 255u;
+    if (tact)
+        for (int i = cand; i < 3 * NG_GCELLS / 2; i += D) {   // uint2 units; near halves all ones, last halves zero
+            const int b = i / (NG_GCELLS / 2), r = i - b * (NG_GCELLS / 2);
+            *(uint2*)(grids + b * 2 * NG_GCELLS + 2 * r) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            *(uint2*)(grids + b * 2 * NG_GCELLS + NG_GCELLS + 2 * r) = make_uint2(0u, 0u);
+        }
+    const bool safe = *a.unsafe == 0;                         // no motion vector of this launch near the int range
+    auto pix_of = [&](int t) {
+        int x = base == 0 ? t : linec, y = base == 0 ? linec : t;
+        if (mirror) { x = W - 1 - x; y = H - 1 - y; }
+        return (size_t)y * W + x;
+    };
+    const uint16_t* __restrict__ ddf = a.dd + f * (size_t)NP * D;
+    const uint8_t* __restrict__ dkf = a.dk + f * (size_t)NP;
+    const uint32_t* __restrict__ dbf = a.dbox + f * (size_t)NP;
+    constexpr int PF = 4;
+    Cand ring[PF];
+    uint32_t rpl[PF], rlen[PF], rbox[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        const size_t px = pix_of(min(k, len - 1));
+        ring[k] = Cf[px * D + cand];
+        rpl[k] = ddf[px * D + cand];
+        rlen[k] = dkf[px];
+        rbox[k] = dbf[px];
+    }
+    uint32_t pbox = NG_BOX_WIDE;                              // box of the previous step's pixel
+    __syncthreads();
+    for (int t0 = 0; t0 < len; t0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int t = t0 + u;
+        if (t >= len) break;                                  // block-uniform
+        const Cand c = ring[u];
+        const uint32_t place = rpl[u], K = rlen[u], box = rbox[u];
+        {
+            const size_t px = pix_of(min(t + PF, len - 1));
+            ring[u] = Cf[px * D + cand];
+            rpl[u] = ddf[px * D + cand];
+            rlen[u] = dkf[px];
+            rbox[u] = dbf[px];
+        }
+        const size_t off = pix_of(t) * D;
+        const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
+        const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
+        int o = c.cost;
+        if (t > 0) {
+            bool grid = true;
+            for (int i = 0; i < LPB; i++) grid = grid && sflag[((t - 1) & 1) * LPB + i] != 0;   // block-uniform
+            if (grid) {
+                // cell of this candidate in the predecessor's grid (mod 2^32: exact, the box origin is small)
+                const uint32_t gx = (uint32_t)c.mvx + 0x4000u - (pbox >> 16) + 4u, gy = (uint32_t)c.mvy + 0x4000u - (pbox & 0xFFFFu) + 4u;
+                uint32_t best = jump;
+                if (gx - 2u < (uint32_t)(NG_GS - 4) && gy - 2u < (uint32_t)(NG_GS - 4)) {
+                    const uint32_t* q = gpre + (gy - 2u) * NG_GS + (gx - 2u);
+                    uint32_t nr = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int r = 0; r < 5; r++)
+#pragma unroll
+                        for (int k = 0; k < 5; k++)
+                            if (r != 2 || k != 2) nr = min(nr, q[r * NG_GS + k]);
+                    const uint32_t last = q[NG_GCELLS + 2 * NG_GS + 2];
+                    best = min(best, nr);
+                    if (last) best = min(best, last & 0xFFu);                    // (a later entry replaces an earlier one: :60-62)
+                }
+                o = (c.cost + (int)best) - (int)m;
+            } else {
+                const NgPre q{(const int32_t*)buf0, (const int32_t*)buf0 + Dp, buf0 + 2 * Dp, buf0 + 3 * Dp};
+                const int Kpre = (int)smin[4 + ((t - 1) & 1)];
+                o = ng_match4(q, safe ? (Kpre + 3) & ~3 : Kpre, c.mvx, c.mvy, c.cost, m, jump, safe);
+            }
+            if (tact) atomicMin(&smin[t % 3], (uint32_t)o & 0xFF);                // :74 narrowed
+        }
+        if (tact) {
+            if (place != 0xFFFFu) {
+                const uint32_t c8 = (uint32_t)o & 0xFF, cp = (uint32_t)(o + a.P1) & 0xFF;
+                buf1[place] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + place] = (uint32_t)c.mvy;
+                buf1[2 * Dp + place] = c8; buf1[3 * Dp + place] = cp;
+                if (box != NG_BOX_WIDE) {
+                    const uint32_t cell = ((uint32_t)c.mvy + 0x4000u - (box & 0xFFFFu) + 4u) * NG_GS + ((uint32_t)c.mvx + 0x4000u - (box >> 16) + 4u);
+                    atomicMin(&gcur[cell], cp);
+                    atomicMax(&gcur[NG_GCELLS + cell], ((place + 1u) << 8) | c8);
+                }
+            }
+            if (cand < 3 && K + cand < (uint32_t)Dp) {         // neutral entries up to the next multiple of 4
+                buf1[K + cand] = NG_PADKEY; buf1[Dp + K + cand] = 0x7FFFFFFFu;
+                buf1[2 * Dp + K + cand] = 0xFFFFu; buf1[3 * Dp + K + cand] = 0xFFFFu;
+            }
+            if (lact) atomicAdd(&Sf[off + cand], (uint32_t)o);                    // :249
+            if (cand == 0) { smin[(t + 1) % 3] = 255u; smin[4 + (t & 1)] = K; sflag[(t & 1) * LPB + ll] = box != NG_BOX_WIDE; }
+            for (int i = cand; i < NG_GCELLS / 2; i += D) {                       // the grid staged two steps ago is free
+                *(uint2*)(gnxt + 2 * i) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                *(uint2*)(gnxt + NG_GCELLS + 2 * i) = make_uint2(0u, 0u);
+            }
+        }
+        pbox = box;
+        __syncthreads();
+        uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
+        tmp = gpre; gpre = gcur; gcur = gnxt; gnxt = tmp;
       }
     }
 }
@@ -1058,6 +1384,12 @@ __global__ __launch_bounds__(896) void otf_pipe_kernel(OtfArgs a) {
 // launchers
 // =============================================================================================
 void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames) {
+    static const bool by_hint = [] { const char* e = getenv("FSGM_NG_COST_HINT"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (by_hint && a.rX == 1 && a.rY == 1 && a.rAgg == 1) {
+        const long long n = (long long)a.W * a.H * 9;
+        hipLaunchKernelGGL(ng_cost_hint_kernel, dim3((unsigned)((n + 255) / 256), frames), dim3(256), 0, st, a);
+        return;
+    }
     const long long n = (long long)a.W * a.H * 9 * (2 * a.rX + 1) * (2 * a.rY + 1);
     dim3 grid((unsigned)((n + 255) / 256), frames);
     hipLaunchKernelGGL(ng_cost_kernel, grid, dim3(256), 0, st, a);
@@ -1071,7 +1403,8 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         acc += (((i & 1) == 0 ? a.H : a.W) + 3) / 4;
     }
     a.blk_begin[4] = acc;
-    { const char* e = getenv("FSGM_NG_DEDUPE"); if (e && atoi(e) == 0) { a.dd = nullptr; a.dk = nullptr; } }   // A/B switch: stage every candidate
+    a.pick = 0;
+    { const char* e = getenv("FSGM_NG_DEDUPE"); if (e && atoi(e) == 0) { a.dd = nullptr; a.dk = nullptr; a.dbox = nullptr; } }   // A/B switch: stage every candidate
     if (a.D <= 128 && a.unsafe) {
         const int lpb = 256 / a.D, Dp = (a.D + 3) & ~3;
         // long lines first: with few frames their blocks decide when the launch ends
@@ -1087,6 +1420,21 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
             acc += (((sl & 1) == 0 ? a.H : a.W) + lpb - 1) / lpb;
         }
         a.blk_begin[4] = acc;
+        // The grid form of the matcher costs the same at any list length, the list form grows with it: lists of a few
+        // entries (nearly constant hint maps) are faster walked, anything richer is faster looked up.  FSGM_NG_GRID: 0 list
+        // form only, 1 grid form only (also for one or two frames, where the split list matcher is the default), unset:
+        // both launched, the device picks by the mean list length of this launch (ng_agg_not_mine).
+        const char* genv = getenv("FSGM_NG_GRID");
+        const int grid_env = genv && *genv ? atoi(genv) : -1;
+        const bool can_grid = a.dd && a.dk && a.dbox && a.kstat;
+        a.pick = 0;
+        if (can_grid && grid_env != 0 && (grid_env == 1 || !split)) {
+            const size_t lds = ((size_t)lpb * 8 * Dp + (size_t)lpb * 6 * NG_GCELLS + lpb * 8 + 2 * lpb) * sizeof(uint32_t);
+            a.pick = grid_env == 1 ? 0 : 1;
+            hipLaunchKernelGGL(ng_agg_grid_kernel, dim3(acc, frames), dim3(256), lds, st, a);
+            if (grid_env == 1) return;
+            a.pick = -1;
+        }
         if (split) {
             const size_t lds = ((size_t)lpb * (10 * Dp + 8) + (size_t)(nparts - 1) * lpb * Dp * 2) * sizeof(uint32_t);
             if (nparts == 2)      hipLaunchKernelGGL(ng_agg_split_kernel<2>, dim3(acc, frames), dim3(512), lds, st, a);
@@ -1101,9 +1449,10 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
     hipLaunchKernelGGL(ng_agg_kernel, dim3(acc, frames), dim3(256), 0, st, a);
 }
 
-void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, int W, int H, int D, int frames) {
-    const int n = W * H * frames;                            // frames are contiguous in all three arrays
-    hipLaunchKernelGGL(ng_dedupe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, dd, dk, n, D);
+void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, int W, int H, int D, int frames) {
+    const int n = W * H * frames;                            // frames are contiguous in all arrays
+    if (kstat) (void)hipMemsetAsync(kstat, 0, 256 * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(ng_dedupe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, dd, dk, dbox, kstat, n, D);
 }
 
 void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames) {

@@ -121,6 +121,48 @@ def test_calc_pyd_cost_sgm_ng_repeated_candidates(gpu_lib, oracle, monkeypatch, 
         np.testing.assert_array_equal(gfl, fl)
 
 
+@pytest.mark.parametrize("kind,amp,sub,P1,P2", [
+    ("zero", 1.0, 0, 6, 32),               # one cell cluster: every pixel's vectors in a 3x3 box
+    ("int", 1.0, 1, 6, 32),                # boxes of up to 5x5
+    ("int", 4.0, 0, 6, 32),                # boxes of up to 11x11: the largest the grid takes, next to pixels that fall back
+    ("int", 5.0, 1, 6, 32),                # mostly around the limit (12): box and list steps mixed inside a line
+    ("int", 9.0, 0, 6, 32),                # mostly too wide: list steps
+    ("general", 3.0, 1, 6, 32),            # fractional hints: one vector at several costs in a cell (the last one counts)
+    ("general", 2.0, 0, 90, 120),          # wrapping penalties
+])
+def test_calc_pyd_cost_sgm_ng_grid_matcher(gpu_lib, oracle, monkeypatch, kind, amp, sub, P1, P2):
+    """The grid form of the matcher (ng_agg_grid_kernel: a pixel whose vectors fit a 12x12 box stages its list as a grid,
+    the next pixel's candidates read 25 cells) against the oracle, forced on for a single frame, where auto mode would
+    take the split list matcher; hint spreads from one cell to far beyond the box."""
+    monkeypatch.setenv("FSGM_NG_GRID", "1")
+    for W, H in ((83, 58), (17, 40), (200, 9)):
+        I1, I2 = synth.image_pair(W, H, 16, seed=W)
+        mv = synth.hint_map(W, H, kind, seed=H + 3, amp=amp)
+        mc, fl, _, S = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, sub, P1, P2, want_volumes=True)
+        gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, sub, P1, P2, return_sum=True)
+        np.testing.assert_array_equal(gS, S, err_msg=f"{W}x{H}")
+        np.testing.assert_array_equal(gmc, mc, err_msg=f"{W}x{H}")
+        np.testing.assert_array_equal(gfl, fl, err_msg=f"{W}x{H}")
+
+
+@pytest.mark.parametrize("kind,amp", [("zero", 1.0), ("int", 3.0), ("general", 1.0)])
+def test_calc_pyd_cost_sgm_ng_batch_picks_a_matcher_on_the_device(gpu_lib, oracle, kind, amp):
+    """Three frames or more: the list and the grid form of the aggregation are both launched and the mean list length of
+    the launch decides on the device which of them runs (short lists: 'zero'; long ones: 'int' with a spread of 7)."""
+    from fsgm_amd import calc_pyd_cost_sgm_ng_batch
+    W, H = 61, 37
+    frames, want = [], []
+    for i in range(3):
+        I1, I2 = synth.image_pair(W, H, 16, seed=50 + i)
+        mv = synth.hint_map(W, H, kind, seed=60 + i, amp=amp)
+        frames.append((I1, I2, mv))
+        want.append(oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 1, 6, 32))
+    for rep in range(2):
+        for i, ((gmc, gfl), (mc, fl)) in enumerate(zip(calc_pyd_cost_sgm_ng_batch(frames, 1, 2, 1, 6, 32), want)):
+            np.testing.assert_array_equal(gmc, mc, err_msg=f"rep {rep} frame {i}")
+            np.testing.assert_array_equal(gfl, fl, err_msg=f"rep {rep} frame {i}")
+
+
 def test_ng_batches_match_single_calls(gpu_lib, oracle):
     """Frames of a batch share one launch sequence (three or more frames: one thread per (line, candidate), no
     matcher split; the on-the-fly variant: one workgroup per frame): same results as the oracle frame by frame."""
