@@ -495,11 +495,13 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
     uint32_t* smin = sNg + (size_t)LPB * 8 * Dp + ll * 8;     // [0..2] minima ring, [4 + (t & 1)] entries staged by step t
     if (cand < 3 && tact) smin[cand] = 255u;
     const bool safe = *a.unsafe == 0;                         // no motion vector of this launch near the int range
-    auto pix_of = [&](int t) {
-        int x = base == 0 ? t : linec, y = base == 0 ? linec : t;
-        if (mirror) { x = W - 1 - x; y = H - 1 - y; }
-        return (size_t)y * W + x;
-    };
+    // the line as a walk over entry indices (pixel * D + candidate < 2^31, checked by the host entry points): step t
+    // sits at e_cur, the fetch cursor PF steps ahead (it stops at the last pixel)
+    int pix0 = base == 0 ? linec * W : linec;
+    if (mirror) pix0 = NP - 1 - pix0;
+    const int dpix = (mirror ? -1 : 1) * (base == 0 ? 1 : W);
+    const uint32_t dent = (uint32_t)(dpix * D);              // mod 2^32: the indices themselves stay in range
+    uint32_t e_cur = (uint32_t)(pix0 * D + cand), p_fet = (uint32_t)pix0, e_fet = e_cur;
     const uint16_t* __restrict__ ddf = a.dd ? a.dd + f * (size_t)NP * D : nullptr;
     const uint8_t* __restrict__ dkf = a.dk ? a.dk + f * (size_t)NP : nullptr;
     // the candidates of step t+PF are requested while step t computes (a gathered 12-byte load takes
@@ -509,10 +511,10 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
     uint32_t rpl[PF], rlen[PF];                               // the candidate's place in its pixel's list without repeats, that list's length
 #pragma unroll
     for (int k = 0; k < PF; k++) {
-        const size_t px = pix_of(min(k, len - 1));
-        ring[k] = Cf[px * D + cand];
-        rpl[k] = ddf ? ddf[px * D + cand] : (uint32_t)cand;
-        rlen[k] = dkf ? dkf[px] : (uint32_t)D;
+        ring[k] = Cf[e_fet];
+        rpl[k] = ddf ? ddf[e_fet] : (uint32_t)cand;
+        rlen[k] = dkf ? dkf[p_fet] : (uint32_t)D;
+        if (k + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
     }
     __syncthreads();
     for (int t0 = 0; t0 < len; t0 += PF) {
@@ -522,13 +524,10 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
         if (t >= len) break;                                  // block-uniform
         const Cand c = ring[u];
         const uint32_t place = rpl[u], K = rlen[u];
-        {
-            const size_t px = pix_of(min(t + PF, len - 1));
-            ring[u] = Cf[px * D + cand];
-            rpl[u] = ddf ? ddf[px * D + cand] : (uint32_t)cand;
-            rlen[u] = dkf ? dkf[px] : (uint32_t)D;
-        }
-        const size_t off = pix_of(t) * D;
+        ring[u] = Cf[e_fet];
+        rpl[u] = ddf ? ddf[e_fet] : (uint32_t)cand;
+        rlen[u] = dkf ? dkf[p_fet] : (uint32_t)D;
+        if (t + PF + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
         const NgPre q{(const int32_t*)buf0, (const int32_t*)buf0 + Dp, buf0 + 2 * Dp, buf0 + 3 * Dp};
         const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
         const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
@@ -547,9 +546,10 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
                 buf1[K + cand] = NG_PADKEY; buf1[Dp + K + cand] = 0x7FFFFFFFu;
                 buf1[2 * Dp + K + cand] = 0xFFFFu; buf1[3 * Dp + K + cand] = 0xFFFFu;
             }
-            if (lact) atomicAdd(&Sf[off + cand], (uint32_t)o);                    // :249
+            if (lact) atomicAdd(&Sf[e_cur], (uint32_t)o);                         // :249
             if (cand == 0) { smin[(t + 1) % 3] = 255u; smin[4 + (t & 1)] = K; }
         }
+        e_cur += dent;
         __syncthreads();
         uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
       }
@@ -611,11 +611,13 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
             *(uint2*)(grids + b * 2 * NG_GCELLS + NG_GCELLS + 2 * r) = make_uint2(0u, 0u);
         }
     const bool safe = *a.unsafe == 0;                         // no motion vector of this launch near the int range
-    auto pix_of = [&](int t) {
-        int x = base == 0 ? t : linec, y = base == 0 ? linec : t;
-        if (mirror) { x = W - 1 - x; y = H - 1 - y; }
-        return (size_t)y * W + x;
-    };
+    // the line as a walk over entry indices (pixel * D + candidate < 2^31, checked by the host entry points): step t
+    // sits at e_cur, the fetch cursor PF steps ahead (it stops at the last pixel)
+    int pix0 = base == 0 ? linec * W : linec;
+    if (mirror) pix0 = NP - 1 - pix0;
+    const int dpix = (mirror ? -1 : 1) * (base == 0 ? 1 : W);
+    const uint32_t dent = (uint32_t)(dpix * D);              // mod 2^32: the indices themselves stay in range
+    uint32_t e_cur = (uint32_t)(pix0 * D + cand), p_fet = (uint32_t)pix0, e_fet = e_cur;
     const uint16_t* __restrict__ ddf = a.dd + f * (size_t)NP * D;
     const uint8_t* __restrict__ dkf = a.dk + f * (size_t)NP;
     const uint32_t* __restrict__ dbf = a.dbox + f * (size_t)NP;
@@ -624,11 +626,11 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
     uint32_t rpl[PF], rlen[PF], rbox[PF];
 #pragma unroll
     for (int k = 0; k < PF; k++) {
-        const size_t px = pix_of(min(k, len - 1));
-        ring[k] = Cf[px * D + cand];
-        rpl[k] = ddf[px * D + cand];
-        rlen[k] = dkf[px];
-        rbox[k] = dbf[px];
+        ring[k] = Cf[e_fet];
+        rpl[k] = ddf[e_fet];
+        rlen[k] = dkf[p_fet];
+        rbox[k] = dbf[p_fet];
+        if (k + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
     }
     uint32_t pbox = NG_BOX_WIDE;                              // box of the previous step's pixel
     __syncthreads();
@@ -639,14 +641,11 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
         if (t >= len) break;                                  // block-uniform
         const Cand c = ring[u];
         const uint32_t place = rpl[u], K = rlen[u], box = rbox[u];
-        {
-            const size_t px = pix_of(min(t + PF, len - 1));
-            ring[u] = Cf[px * D + cand];
-            rpl[u] = ddf[px * D + cand];
-            rlen[u] = dkf[px];
-            rbox[u] = dbf[px];
-        }
-        const size_t off = pix_of(t) * D;
+        ring[u] = Cf[e_fet];
+        rpl[u] = ddf[e_fet];
+        rlen[u] = dkf[p_fet];
+        rbox[u] = dbf[p_fet];
+        if (t + PF + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
         const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
         const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
         int o = c.cost;
@@ -692,7 +691,7 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
                 buf1[K + cand] = NG_PADKEY; buf1[Dp + K + cand] = 0x7FFFFFFFu;
                 buf1[2 * Dp + K + cand] = 0xFFFFu; buf1[3 * Dp + K + cand] = 0xFFFFu;
             }
-            if (lact) atomicAdd(&Sf[off + cand], (uint32_t)o);                    // :249
+            if (lact) atomicAdd(&Sf[e_cur], (uint32_t)o);                         // :249
             if (cand == 0) { smin[(t + 1) % 3] = 255u; smin[4 + (t & 1)] = K; sflag[(t & 1) * LPB + ll] = box != NG_BOX_WIDE; }
             for (int i = cand; i < NG_GCELLS / 2; i += D) {                       // the grid staged two steps ago is free
                 *(uint2*)(gnxt + 2 * i) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -700,6 +699,7 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
             }
         }
         pbox = box;
+        e_cur += dent;
         __syncthreads();
         uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
         tmp = gpre; gpre = gcur; gcur = gnxt; gnxt = tmp;
