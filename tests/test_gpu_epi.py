@@ -342,12 +342,17 @@ def test_forward_backward_check(gpu_lib, oracle, W, H, D, kind, paths):
     np.testing.assert_array_equal(gd2, d2)
     np.testing.assert_array_equal(gconf, conf)
     assert 0 < int(gconf.sum()) < W * H                      # both outcomes occur
-    # a batch of 5 goes through the fused sweeps: same answer
-    res = calc_cost_sgm_batch([(I1, I2, pd0, nd, off)] * 5, D, 0.3, 6, 64, paths=paths, fb_check=1)
-    for r in res:
-        np.testing.assert_array_equal(r[0], bd)
-        np.testing.assert_array_equal(r[2], conf)
-        np.testing.assert_array_equal(r[3], d2)
+    # batches of 5 and 18 go through the parallel sweeps and the full sweep pipeline (8 paths; the line and the pair kernels
+    # for 4), with the volumes read back through the debug taps: same answer
+    for n in (5, 18):
+        res = calc_cost_sgm_batch([(I1, I2, pd0, nd, off)] * n, D, 0.3, 6, 64, paths=paths, fb_check=1, return_volumes=(n == 5))
+        for r in res:
+            np.testing.assert_array_equal(r[0], bd)
+            np.testing.assert_array_equal(r[-2], conf)
+            np.testing.assert_array_equal(r[-1], d2)
+            if n == 5:
+                np.testing.assert_array_equal(r[2], Cv)
+                np.testing.assert_array_equal(r[3], S[:-1].reshape(H, W, D))
 
 
 def test_sweep_pipeline_is_deterministic_under_back_to_back_runs(gpu_lib, oracle):
