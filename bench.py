@@ -333,7 +333,15 @@ def main():
         voxel_paths_step = total_frames * W * H * D * PATHS
         value = voxel_paths_step * args.steps / dt
         alg_bytes_launch = B * W * H * D * PATHS            # 1 byte of C per voxel-path
-        achieved = alg_bytes_launch / (agg_ms * 1e-3) / 1e9
+        # which kernels the stage is made of depends on the pipeline the plan picked for this batch size;
+        # where the argmin is a kernel of its own (parallel sweeps, line kernels) it belongs to the timed stage
+        stage_kernels = {
+            "sweep16/nowrap": ("sweep_kernel<8,0> + sweep_kernel<8,2> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>", False),
+            "sweep16par/nowrap": ("sweep_kernel<8,0> + sweep_kernel<8,1> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + wta_sweep_kernel<8>", True),
+            "pairs16/nowrap": ("pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + pair_ckpt_kernel<8,1> + pair_sum_kernel<8,1,true>", False),
+        }.get(plan.kernel_name, ("agg_packed_kernel<128,false,true> + wta_packed_kernel<8>", True))
+        stage_time_ms = agg_ms + (wta_ms if stage_kernels[1] else 0.0)
+        achieved = alg_bytes_launch / (stage_time_ms * 1e-3) / 1e9
         bpv, traffic_src = measured_traffic(plan.kernel_name, PATHS)
         out = {
             "metric": f"aggregated cost-volume voxel-paths/s (HxWxDx{PATHS} paths), KITTI 1242x375 D=128",
@@ -347,8 +355,7 @@ def main():
             # (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane; pair_ckpt_kernel<8,0> +
             # pair_sum_kernel<8,0,false> for the horizontal pair): the roofline is taken over the stage, HIP
             # events fork->join
-            "roofline": {"bound": "hbm", "kernel": ("aggregation stage: sweep_kernel<8,0> + sweep_kernel<8,2> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>"
-                                                     if PATHS == 8 else "aggregation stage: pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + pair_ckpt_kernel<8,1> + pair_sum_kernel<8,1,true>"),
+            "roofline": {"bound": "hbm", "kernel": "aggregation stage: " + stage_kernels[0],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": bpv * B * W * H * D if bpv else None, "traffic_source": traffic_src,
                          "algorithmic_bytes": alg_bytes_launch, "stage_ms": agg_ms, "finish_ms": wta_ms},
