@@ -75,19 +75,26 @@ def _smooth_hints(W, H, seed, big=False):
 
 def test_config4_single_level_full_size(gpu_lib, oracle):
     """One calc_pyd_cost_sgm_ng call at 1242x375, 81 candidates, with every variant of the aggregation kernels the
-    library can select for it (FSGM_NG_SPLIT parts, repeat removal on/off): S, minC and the flow, all pixels."""
+    library can select for it (FSGM_NG_SPLIT parts, repeat removal on/off, list / grid form of the matcher): S, minC and the
+    flow, all pixels."""
     W, H = 1242, 375
     I1, I2 = synth.image_pair(W, H, 16, seed=41)
     mv = _smooth_hints(W, H, 1, big=True)
     mc, fl, _, S = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 1, 6, 32, want_volumes=True)
-    saved = {k: os.environ.get(k) for k in ("FSGM_NG_SPLIT", "FSGM_NG_DEDUPE")}
+    saved = {k: os.environ.get(k) for k in ("FSGM_NG_SPLIT", "FSGM_NG_DEDUPE", "FSGM_NG_GRID")}
     try:
-        for split, dedupe in [("2", "1"), ("1", "1"), ("2", "0"), ("1", "0"), ("3", "1")]:
+        # (matcher parts, repeat removal, grid form: "" = the device picks between the list and the grid kernel when the
+        # matcher is not split, "1" / "0" = grid / list kernel whatever the lists look like)
+        for split, dedupe, grid in [("2", "1", ""), ("1", "1", ""), ("2", "0", ""), ("1", "0", ""), ("3", "1", ""), ("2", "1", "1"), ("1", "1", "0")]:
             os.environ["FSGM_NG_SPLIT"], os.environ["FSGM_NG_DEDUPE"] = split, dedupe
+            if grid:
+                os.environ["FSGM_NG_GRID"] = grid
+            else:
+                os.environ.pop("FSGM_NG_GRID", None)
             gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 1, 6, 32, return_sum=True)
-            np.testing.assert_array_equal(gS, S, err_msg=f"split {split} dedupe {dedupe}")
-            np.testing.assert_array_equal(gmc, mc, err_msg=f"split {split} dedupe {dedupe}")
-            np.testing.assert_array_equal(gfl, fl, err_msg=f"split {split} dedupe {dedupe}")
+            np.testing.assert_array_equal(gS, S, err_msg=f"split {split} dedupe {dedupe} grid {grid!r}")
+            np.testing.assert_array_equal(gmc, mc, err_msg=f"split {split} dedupe {dedupe} grid {grid!r}")
+            np.testing.assert_array_equal(gfl, fl, err_msg=f"split {split} dedupe {dedupe} grid {grid!r}")
     finally:
         for k, v in saved.items():
             if v is None:
