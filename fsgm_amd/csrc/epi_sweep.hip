@@ -930,6 +930,14 @@ size_t pair_ckpt_bytes(int W, int H, int D, int axis) {
     return (size_t)nl * (size_t)(NT > 1 ? NT - 1 : 1) * D;
 }
 
+// LDS the along-y checkpoint pass asks for without using it: a cap of two resident workgroups per CU.  In the 4-path
+// pipeline that pass (many waves, short lines) runs beside the along-x pair (few waves, the 2 W-step chain everything waits
+// for) and crowds its waves out of the issue slots: capped, 40 frames take 3.47 instead of 3.62 ms.  FSGM_PAIR_VLDS (KB): A/B knob.
+static size_t pair_vckpt_lds() {
+    static const size_t v = [] { const char* e = getenv("FSGM_PAIR_VLDS"); const int x = (e && *e) ? atoi(e) : 64; return (size_t)(x < 0 ? 0 : (x > 160 ? 160 : x)) * 1024; }();
+    return v;
+}
+
 template <int LPP>
 static void launch_pair_t(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase) {
     constexpr int PXW = 64 / LPP;
@@ -937,7 +945,7 @@ static void launch_pair_t(hipStream_t st, const PairArgs& a, int frames, int axi
     dim3 grid((nl + 4 * PXW - 1) / (4 * PXW), frames);
     if (phase != 2) {
         if (axis == 0) hipLaunchKernelGGL((pair_ckpt_kernel<LPP, 0>), grid, dim3(256), 0, st, a);
-        else           hipLaunchKernelGGL((pair_ckpt_kernel<LPP, 1>), grid, dim3(256), 0, st, a);
+        else           hipLaunchKernelGGL((pair_ckpt_kernel<LPP, 1>), grid, dim3(256), pair_vckpt_lds(), st, a);
     }
     if (phase != 1) {
         if (axis == 0 && !final_pass)      hipLaunchKernelGGL((pair_sum_kernel<LPP, 0, false>), grid, dim3(256), 0, st, a);
