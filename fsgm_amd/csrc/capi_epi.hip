@@ -323,6 +323,16 @@ fsgm_status fsgm_epi_plan_upload_offset(fsgm_epi_plan* p, int32_t f, const doubl
     return FSGM_OK;
 }
 
+// 4-path pipeline: the along-x pair as pairx_* kernels (8 costs a lane).  Small batches wait for that pair's serial chain,
+// which the finer split shortens (2 / 9 frames at 1242x375x128: 0.96 -> 0.82 / 1.24 -> 1.12 ms); from 16 frames the
+// pipeline is bound by its HBM traffic (7.5 B per voxel at ~5 TB/s) and the coarser kernels' fewer instructions win
+// (40 frames: 3.47 against 3.68 ms).  FSGM_PAIR_XFINE=0 / 1: never / always (A/B switch).
+static int pairs_x_fine(const fsgm_epi_plan* p) {
+    static const int env = [] { const char* e = getenv("FSGM_PAIR_XFINE"); return (e && *e) ? atoi(e) : -1; }();
+    if (!pair_x_fine_ok(p->D) || env == 0) return 0;
+    return env == 1 || p->batch < 16 ? 1 : 0;
+}
+
 static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
     if (p->dCkptV) return FSGM_OK;
     const size_t B = p->batch;
@@ -531,9 +541,12 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         h.C = p->dC; h.c_frame_stride = p->N; h.X = p->dLh; h.x_frame_stride = p->N;
         h.ckpt = p->dCkpt; h.ckpt_frame_stride = pair_ckpt_bytes(p->W, p->H, p->D, 0);
         h.W = p->W; h.H = p->H; h.D = p->D; h.P1 = p->P1; h.P2 = p->P2;
-        launch_pair(p->stream_h, h, p->batch, 0, false);
+        const int fine = pairs_x_fine(p);                       // the along-x pair with 8 costs a lane: its chain is what this pipeline waits for
+        if (fine) launch_pair_x_fine(p->stream_h, h, p->batch);
+        else      launch_pair(p->stream_h, h, p->batch, 0, false);
         FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
         PairArgs v = h;
+        v.xo_natural = fine;
         v.X = nullptr; v.x_frame_stride = 0;
         v.ckpt = p->dCkptV; v.ckpt_frame_stride = pair_ckpt_bytes(p->W, p->H, p->D, 1);
         v.Xother = p->dLh; v.xo_frame_stride = p->N; v.rec = p->dRec; v.s0 = p->dS0; v.nC = 4;
@@ -556,7 +569,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp && !p->prm.fb_check;
         SweepSumArgs q;
         q.C = p->dC; q.Xdn = p->dX; q.Xup = p->dXupAll; q.v_frame_stride = p->N;
-        q.Lh = p->dLh; q.lh_frame_stride = p->N;
+        q.Lh = p->dLh; q.lh_frame_stride = p->N; q.lh_natural = 0;
         q.nC = 8; q.P2 = p->P2; q.Sdbg = nullptr;
         launch_wta_sweep(p->stream, a, q, p->batch);
     } else if ((stages & FSGM_STAGE_WTA) && (p->kernel_kind == AGG_SWEEP || p->kernel_kind == AGG_PAIRS)) {
@@ -720,7 +733,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
         SweepSumArgs q;
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX + (size_t)f * p->N; q.Xup = p->dXup; q.v_frame_stride = p->N;
-        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N;
+        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_natural = 0;
         q.nC = 8; q.P2 = p->P2; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
@@ -748,7 +761,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
         SweepSumArgs q;
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX; q.Xup = nullptr; q.v_frame_stride = p->N;
-        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N;
+        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_natural = pairs_x_fine(p);
         q.nC = 4; q.P2 = p->P2; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());

@@ -90,6 +90,7 @@ struct SweepSumArgs {          // what wta_sweep_kernel adds up (u8 volumes; the
     size_t v_frame_stride;
     const uint8_t* Lh;        // [frames] Y_h of the horizontal pair
     size_t lh_frame_stride;
+    int lh_natural;           // Lh is in natural d order (pairx_* kernels), not the private one
     int nC;                   // S = nC*(C + P2) - (Xdn + Xup + Lh)
     int P2;
     uint32_t* Sdbg;           // optional natural-order u32 dump of S [frames][NP][D]
@@ -108,6 +109,7 @@ struct PairArgs {              // an opposite pair of paths as one excess sum (e
     uint16_t* s0;             // final pass: [frames][NP] S[0] of every pixel
     int nC;                   // final pass: S = nC * (C + P2) - (Y + Yother)
     int prio;                 // s_setprio level of the pair kernels' waves (0-3)
+    int xo_natural;           // final pass: Xother is in natural d order (written by the pairx_* kernels), not the private one
     int W, H, D;
     int P1, P2;
 };
@@ -139,6 +141,8 @@ size_t strip_edge_uint4s(int W, int H, int D);              // hand-off buffer p
 void launch_strips(hipStream_t st, const StripArgs& a, int mode);               // same modes, one launch per sweep
 size_t pair_ckpt_bytes(int W, int H, int D, int axis);      // per frame; axis 0 horizontal, 1 vertical
 void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase = 0);
+bool pair_x_fine_ok(int D);                                                        // the along-x pair with 8 costs a lane exists for this D
+void launch_pair_x_fine(hipStream_t st, const PairArgs& a, int frames);            // checkpoint + sum pass, Y in natural d order
 void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames);
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);
 void launch_fb_check(hipStream_t st, const FbArgs& a, int frames);

@@ -721,7 +721,8 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
 #pragma unroll
         for (int k = 0; k < 8; k++) YT[k] += E2[k];
     }
-    unpack_p(*(const uint4*)(q.Lh + f * q.lh_frame_stride + bo), E2);
+    if (q.lh_natural) unpack_c(*(const uint4*)(q.Lh + f * q.lh_frame_stride + bo), E2, 0u);
+    else unpack_p(*(const uint4*)(q.Lh + f * q.lh_frame_stride + bo), E2);
 #pragma unroll
     for (int k = 0; k < 8; k++) ST[k] = pk_sub(pk_mad16(CP[k], nC * 0x10001u, 0u), pk_add(YT[k], E2[k]));
 
@@ -775,6 +776,9 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
 //         the 4-path pipeline (the reference's shipped configuration): horizontal pair -> Y_h, vertical
 //         pair final: S = 4*(C + P2) - (Y_v + Y_h), 7.5 B per voxel for 4 voxel-paths, S never in HBM.
 // =============================================================================================
+#ifndef FSGM_PAIR_PF
+#define FSGM_PAIR_PF 4          // steps of C the checkpoint passes request ahead (A/B knob)
+#endif
 #ifndef FSGM_HP_TC
 #define FSGM_HP_TC 8            // tile width = checkpoint spacing in positions (A/B knob)
 #endif
@@ -782,7 +786,7 @@ constexpr int HP_TC = FSGM_HP_TC;
 
 template <int LPP, int AXIS>
 __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
-    constexpr int PXW = 64 / LPP, D = LPP * 16, PF = 4;
+    constexpr int PXW = 64 / LPP, D = LPP * 16, PF = FSGM_PAIR_PF;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / LPP, j = lane % LPP;
     const int nl = AXIS ? a.W : a.H, len = AXIS ? a.H : a.W;
@@ -900,7 +904,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
                 // S = nC*(C + P2) - (this pair + the other pair) (calc_cost_sgm.cpp:227-232), WTA on the spot
                 uint32_t ST[8], E2[8], E3[8];
                 unpack_p(exR[c], E2);
-                unpack_p(xo[c], E3);
+                if (a.xo_natural) unpack_c(xo[c], E3, 0u); else unpack_p(xo[c], E3);    // (block-uniform)
                 const uint32_t nC = (uint32_t)a.nC * 0x10001u;
 #pragma unroll
                 for (int q = 0; q < 8; q++) ST[q] = pk_sub(pk_mad16(CP[q], nC, 0u), pk_add(pk_add(Y[q], E2[q]), E3[q]));
@@ -916,6 +920,164 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
         tile(0, std::true_type{});
     } else {
         tile(0, std::true_type{});                                // holds position 0 (and, for len <= TC + 1, the end too)
+        for (int t = 1; t < NT - 1; t++) {
+            if ((t + 1) * TC <= len - 1) tile(t, std::false_type{});
+            else tile(t, std::true_type{});
+        }
+        tile(NT - 1, std::true_type{});
+    }
+}
+
+// =============================================================================================
+// The along-x pair with 8 costs a lane (half the registers of the kernels above: 4 packed registers, register i =
+// (d = 8j + i, d = 8j + 4 + i), D / 8 lanes a pixel, 64 / (D / 8) rows a wave).  The along-x lines are few and long:
+// where nothing else runs beside them (the 4-path pipeline) their serial length is what everything waits for, and
+// a step of a lane with half the costs is ≈0.6 of the instructions while twice the waves share the SIMDs.
+// Same passes, same checkpoint spacing; the checkpoint bytes and the Y of the tile stay in a private order of this
+// pair of kernels, the stored sum Y is in natural d order (PairArgs.xo_natural / SweepSumArgs.lh_natural tell its readers).
+// =============================================================================================
+__device__ __forceinline__ void unpack_c4(const uint2 w, uint32_t (&CP)[4], const uint32_t P2pk) {
+    CP[0] = pk_add(__builtin_amdgcn_perm(w.y, w.x, 0x0C040C00u), P2pk);
+    CP[1] = pk_add(__builtin_amdgcn_perm(w.y, w.x, 0x0C050C01u), P2pk);
+    CP[2] = pk_add(__builtin_amdgcn_perm(w.y, w.x, 0x0C060C02u), P2pk);
+    CP[3] = pk_add(__builtin_amdgcn_perm(w.y, w.x, 0x0C070C03u), P2pk);
+}
+// private byte order of 4 registers: (R0.lo, R1.lo, R0.hi, R1.hi), (R2.lo, R3.lo, R2.hi, R3.hi)
+__device__ __forceinline__ uint2 pack_q(const uint32_t (&R)[4]) {
+    return make_uint2(__builtin_amdgcn_perm(R[1], R[0], SEL_PACK), __builtin_amdgcn_perm(R[3], R[2], SEL_PACK));
+}
+__device__ __forceinline__ void unpack_q(const uint2 v, uint32_t (&R)[4]) {
+    R[0] = v.x & 0x00FF00FFu; R[1] = __builtin_amdgcn_perm(0u, v.x, SEL_ODD);
+    R[2] = v.y & 0x00FF00FFu; R[3] = __builtin_amdgcn_perm(0u, v.y, SEL_ODD);
+}
+// private order -> natural d order: (d0 d1 d4 d5), (d2 d3 d6 d7) -> (d0 d1 d2 d3), (d4 d5 d6 d7)
+__device__ __forceinline__ uint2 natural_q(const uint2 v) {
+    return make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x05040100u), __builtin_amdgcn_perm(v.y, v.x, 0x07060302u));
+}
+
+// step_s for 4 registers a lane, G lanes a pixel (G <= 16: one DPP row)
+template <int G, bool MASKED = true>
+__device__ __forceinline__ void step_q(uint32_t (&S)[4], const uint32_t (&CP)[4], uint32_t (&Y)[4], const uint32_t P1pk,
+                                       const uint32_t P2, const LaneSel sel, const uint32_t mmask) {
+    uint32_t T[4], N[4];
+    T[3] = pk_subs(S[3], P1pk);
+    T[0] = pk_subs(S[0], P1pk);
+    T[1] = pk_subs(S[1], P1pk);
+    T[2] = pk_subs(S[2], P1pk);
+    const uint32_t LT = __builtin_amdgcn_perm(T[3], (uint32_t)__builtin_amdgcn_mov_dpp((int)T[3], DPP_ROW_SHR1, 0xF, 0xF, true), sel.lo);
+    const uint32_t RT = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_mov_dpp((int)T[0], DPP_ROW_SHL1, 0xF, 0xF, true), T[0], sel.hi);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        Y[i] = pk_max3(S[i], i ? T[i - 1] : LT, i < 3 ? T[i + 1] : RT);
+        N[i] = pk_sub(CP[i], Y[i]);
+    }
+    const uint32_t mm = pk_min(N[0], pk_min3(N[1], N[2], N[3]));
+    uint32_t mx = group_min_u32<G>(min_halves(mm));
+    if (MASKED) mx &= mmask;
+    const uint32_t p2m = __umul24(mx, 0x10001u) + P2 * 0x10001u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) S[i] = pk_subs(p2m, N[i]);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void pairx_ckpt_kernel(PairArgs a) {
+    constexpr int G = D / 8, PXW = 64 / G, PF = FSGM_PAIR_PF;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / G, j = lane % G;
+    const int nl = a.H, len = a.W;
+    const int lg = (int)blockIdx.x * 4 + wave;
+    if (lg * PXW >= nl) return;                                 // wave-uniform
+    const int l = min(lg * PXW + g, nl - 1);                    // lines past the last redo the last (same bytes, same addresses)
+    const int NT = (len + HP_TC - 1) / HP_TC;
+    if (NT < 2) return;
+    const size_t f = blockIdx.y;
+    const uint8_t* __restrict__ Cl = a.C + f * a.c_frame_stride + (size_t)l * a.W * D + (size_t)j * 8;
+    uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * (NT - 1)) * D + (size_t)j * 8;
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const LaneSel sel = lane_sel<G>(j);
+    uint32_t S[4] = {P2pk, P2pk, P2pk, P2pk};                   // the path starts at the line's last position
+    auto load_c = [&](int t) -> uint2 { return *(const uint2*)(Cl + (size_t)max(t, 0) * D); };
+    uint2 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) ring[i] = load_c(len - 1 - i);
+    const int last = HP_TC;
+    for (int t0 = len - 1; t0 >= last; t0 -= PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const int t = t0 - i;
+            const uint2 cw = ring[i];
+            ring[i] = load_c(t - PF);
+            uint32_t CP[4], Y[4];
+            unpack_c4(cw, CP, P2pk);
+            step_q<G>(S, CP, Y, P1pk, P2, sel, t == len - 1 ? 0u : 0xFFFFu);
+            if (t >= last && (t % HP_TC) == 0) *(uint2*)(Kl + (size_t)(t / HP_TC - 1) * D) = pack_q(S);
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void pairx_sum_kernel(PairArgs a) {
+    constexpr int G = D / 8, PXW = 64 / G, TC = HP_TC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / G, j = lane % G;
+    const int nl = a.H, len = a.W;
+    const int lg = (int)blockIdx.x * 4 + wave;
+    if (lg * PXW >= nl) return;
+    const int l = min(lg * PXW + g, nl - 1);
+    const int NT = (len + TC - 1) / TC;
+    const size_t f = blockIdx.y;
+    const size_t lbase = (size_t)l * a.W * D + (size_t)j * 8;
+    const uint8_t* __restrict__ Cl = a.C + f * a.c_frame_stride + lbase;
+    uint8_t* __restrict__ Xl = a.X + f * a.x_frame_stride + lbase;
+    const uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * max(NT - 1, 1)) * D + (size_t)j * 8;
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const LaneSel sel = lane_sel<G>(j);
+    uint32_t FS[4] = {P2pk, P2pk, P2pk, P2pk};                  // position 0 starts the forward path
+    auto load_c = [&](int t) -> uint2 { return *(const uint2*)(Cl + (size_t)min(t, len - 1) * D); };
+    auto load_k = [&](int t) -> uint2 { return *(const uint2*)(Kl + (size_t)min(t, max(NT - 2, 0)) * D); };
+    uint2 cT[TC], cN[TC], kT = load_k(0), kN;
+#pragma unroll
+    for (int c = 0; c < TC; c++) cT[c] = load_c(c);
+    auto tile = [&](const int t, auto edge) {
+        constexpr bool EDGE = decltype(edge)::value;
+        const int tb = t * TC;
+#pragma unroll
+        for (int c = 0; c < TC; c++) cN[c] = load_c(tb + TC + c);
+        kN = load_k(t + 1);
+        uint32_t RS[4];
+        unpack_q(kT, RS);
+        uint2 exR[TC];
+#pragma unroll
+        for (int c = TC - 1; c >= 0; c--) {
+            const int x = tb + c;
+            uint32_t CP[4], Y[4];
+            unpack_c4(cT[c], CP, P2pk);
+            uint32_t mmask = 0xFFFFu;
+            if (EDGE && x >= len - 1) {                           // wave-uniform: the backward path starts here
+                RS[0] = RS[1] = RS[2] = RS[3] = P2pk;
+                mmask = 0u;
+            }
+            step_q<G>(RS, CP, Y, P1pk, P2, sel, mmask);
+            exR[c] = pack_q(Y);
+        }
+#pragma unroll
+        for (int c = 0; c < TC; c++) {
+            const int x = tb + c;
+            uint32_t CP[4], Y[4];
+            unpack_c4(cT[c], CP, P2pk);
+            step_q<G>(FS, CP, Y, P1pk, P2, sel, (EDGE && x == 0) ? 0u : 0xFFFFu);
+            const uint2 yf = pack_q(Y);
+            // both y are <= P2 per byte and 2*P2 <= 255: the packed bytes add as plain words
+            if (!EDGE || x < len) *(uint2*)(Xl + (size_t)x * D) = natural_q(make_uint2(yf.x + exR[c].x, yf.y + exR[c].y));
+        }
+#pragma unroll
+        for (int c = 0; c < TC; c++) cT[c] = cN[c];
+        kT = kN;
+    };
+    if (NT == 1) {
+        tile(0, std::true_type{});
+    } else {
+        tile(0, std::true_type{});
         for (int t = 1; t < NT - 1; t++) {
             if ((t + 1) * TC <= len - 1) tile(t, std::false_type{});
             else tile(t, std::true_type{});
@@ -953,6 +1115,22 @@ static void launch_pair_t(hipStream_t st, const PairArgs& a, int frames, int axi
         else if (!final_pass)              hipLaunchKernelGGL((pair_sum_kernel<LPP, 1, false>), grid, dim3(256), 0, st, a);
         else                               hipLaunchKernelGGL((pair_sum_kernel<LPP, 1, true>), grid, dim3(256), 0, st, a);
     }
+}
+
+// the along-x pair as pairx_* (8 costs a lane): D = 16 .. 128; Y comes out in natural d order
+bool pair_x_fine_ok(int D) { return D == 16 || D == 32 || D == 64 || D == 128; }
+void launch_pair_x_fine(hipStream_t st, const PairArgs& a, int frames) {
+#define FSGM_PX(DD) do { constexpr int PXW = 64 / (DD / 8); dim3 grid((a.H + 4 * PXW - 1) / (4 * PXW), frames); \
+        hipLaunchKernelGGL((pairx_ckpt_kernel<DD>), grid, dim3(256), 0, st, a); \
+        hipLaunchKernelGGL((pairx_sum_kernel<DD>), grid, dim3(256), 0, st, a); } while (0)
+    switch (a.D) {
+        case 16: FSGM_PX(16); break;
+        case 32: FSGM_PX(32); break;
+        case 64: FSGM_PX(64); break;
+        case 128: FSGM_PX(128); break;
+        default: break;
+    }
+#undef FSGM_PX
 }
 
 // One axis (0 horizontal, 1 vertical).  phase 0: checkpoint pass + sum pass; 1: checkpoint pass only;

@@ -103,7 +103,9 @@ def test_aggregate_sum_bit_exact(gpu_lib, oracle, W, H, D, P1, P2, cmax, kernel,
 @pytest.mark.parametrize("W,H,D,B", [(70, 40, 128, 2), (200, 53, 64, 1), (33, 100, 128, 3), (50, 20, 256, 1), (257, 19, 16, 2), (40, 300, 32, 1),
                                      # sizes around the 8-position tiles of either axis (no / one / partial checkpoint)
                                      (1, 9, 64, 1), (9, 1, 64, 1), (5, 20, 128, 2), (8, 8, 128, 1), (9, 17, 32, 1), (16, 7, 128, 1),
-                                     (17, 16, 64, 2), (1242, 9, 128, 1), (12, 375, 128, 1)])
+                                     (17, 16, 64, 2), (1242, 9, 128, 1), (12, 375, 128, 1),
+                                     # 16 frames and more: the along-x pair with 16 costs a lane (8 a lane below)
+                                     (33, 21, 64, 16), (40, 12, 128, 17)])
 def test_pairs_pipeline_4_paths(gpu_lib, oracle, W, H, D, B):
     """The 4-path pair pipeline (horizontal pair -> X_h, vertical pair final with the WTA): S through the
     debug tap, bestD / minC through the records, against the oracle and the line kernels."""
