@@ -21,8 +21,12 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
+# micro-benchmarks behind DESIGN.md's rates (run on the GPU box; binaries are not tracked)
+ubench:
+	for f in tools/ubench/*.hip; do $(HIPCC) -O3 --offload-arch=$(ARCH) -Wno-unused-value -o $${f%.hip} $$f; done
+
 clean:
 	rm -f $(OBJS) $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean ubench

@@ -23,3 +23,4 @@ done
 timeout -k 10 120 tools/ubench/pk_rates > gpurun_out/r02_ubench_pk_rates.txt 2>&1 || true
 timeout -k 10 120 tools/ubench/copy_rates > gpurun_out/r02_ubench_copy_rates.txt 2>&1 || true
 timeout -k 10 120 tools/ubench/h2d_rates > gpurun_out/r02_ubench_h2d_rates.txt 2>&1 || true
+timeout -k 10 120 tools/ubench/pattern_rates > gpurun_out/r02_ubench_pattern_rates.txt 2>&1 || true
