@@ -358,6 +358,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "aggregation stage: " + stage_kernels[0],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": bpv * B * W * H * D if bpv else None, "traffic_source": traffic_src,
+                         # the rate at which that traffic moved; the same access patterns without arithmetic reach 5.1-5.6 TB/s
+                         # (tools/ubench/pattern_rates.hip, profiles/r02_ubench_pattern_rates.txt)
+                         "traffic_GBps": (bpv * B * W * H * D / (stage_time_ms * 1e-3) / 1e9) if bpv else None,
                          "algorithmic_bytes": alg_bytes_launch, "stage_ms": agg_ms, "finish_ms": wta_ms},
             "checked": bool(checked),
             "check": f"frames {check_frames} of the timed plan == line kernels ({ref_kernel}) on the same volumes, bestD and minC, all pixels",
