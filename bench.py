@@ -411,9 +411,20 @@ def main():
                 calc_cost_sgm_batch(frames8, D, VMAX, P1, P2, paths=PATHS)
             eight = (time.perf_counter() - t0) / 3 * 1e3
             bytes_frame = 2 * W * H + 5 * 8 * W * H + 2 * 4 * W * H
+            # the driver one level up (epipolar_sgm_of.m:33-51) with the three fp64 maps made on the device from F, H, the
+            # epipole: 2 images up, flow (3 fp64 planes) and minC down
+            from fsgm_amd import epipolar_sgm_of
+            Fm, Hm, epi, direction = synth.epi_geometry(W, H, "forward")
+            epipolar_sgm_of(I1, I2, Fm, Hm, epi, direction, D, VMAX, paths=PATHS)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                epipolar_sgm_of(I1, I2, Fm, Hm, epi, direction, D, VMAX, paths=PATHS)
+            driver = (time.perf_counter() - t0) / 10 * 1e3
             out["host_call_ms"] = {"one_frame": one, "eight_frames": eight, "ms_per_frame_in_batch": eight / 8,
                                    "pcie_bytes_per_frame": bytes_frame,
-                                   "note": "fsgm_calc_cost_sgm(_batch)_host from pageable numpy buffers, whole call incl. H2D of 2 images + 5 fp64 map planes and D2H of bestD/minC"}
+                                   "epipolar_driver_one_frame": driver, "epipolar_driver_pcie_bytes": 2 * W * H + 3 * 8 * W * H + 4 * W * H,
+                                   "note": "fsgm_calc_cost_sgm(_batch)_host from pageable numpy buffers, whole call incl. H2D of 2 images + 5 fp64 map planes and D2H of bestD/minC; "
+                                           "epipolar_driver: fsgm_epipolar_sgm_of_host, maps made on the device (2 images up, flow + minC down)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(PATHS=PATHS)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(PATHS=PATHS)
