@@ -94,7 +94,7 @@ fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in
     if (st != FSGM_OK) return st;
     const size_t NP = (size_t)W * H, MV = (size_t)a.mvWidth * a.mvHeight, N = NP * D, B = n;
     DevBufs d;
-    uint8_t *dI1, *dI2, *dDk; uint16_t* dDd; uint32_t *dCen1, *dCen2, *dS, *dMinC, *dUnsafe, *dBox, *dKstat; double *dMv, *dFlow; Cand* dC;
+    uint8_t *dI1, *dI2, *dDk; uint16_t *dDd, *dCm; uint32_t* dCk; uint32_t *dCen1, *dCen2, *dS, *dMinC, *dUnsafe, *dBox, *dKstat; double *dMv, *dFlow; Cand* dC;
     d.want((void**)&dUnsafe, 4);
     d.want((void**)&dI1, B * NP);
     d.want((void**)&dI2, B * NP);
@@ -108,7 +108,9 @@ fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in
     d.want((void**)&dDd, B * N * 2);
     d.want((void**)&dDk, B * NP);
     d.want((void**)&dBox, B * NP * 4);
-    d.want((void**)&dKstat, 256 * 4);
+    d.want((void**)&dKstat, NG_KSTAT_WORDS * 4);
+    d.want((void**)&dCk, B * N * 4);
+    d.want((void**)&dCm, B * N * 2);
     { const hipError_t e = d.commit(device); if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP, "fsgm_calc_pyd_cost_sgm_ng: %s", hipGetErrorString(e)); }
     for (int i = 0; i < n; i++) {
         FSGM_HIP(hipMemcpyAsync(dI1 + i * NP, in[i].I1, NP, hipMemcpyHostToDevice, d.stream));
@@ -125,15 +127,19 @@ fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in
     launch_ng_cost(d.stream, ca, n);
     NgAggArgs ga;
     ga.C = dC; ga.S = dS; ga.unsafe = dUnsafe; ga.W = W; ga.H = H; ga.D = (int)D; ga.P1 = a.P1; ga.P2 = a.P2;
-    ga.dd = nullptr; ga.dk = nullptr; ga.dbox = nullptr; ga.kstat = nullptr; ga.pick = 0;
+    ga.dd = nullptr; ga.dk = nullptr; ga.dbox = nullptr; ga.kstat = nullptr; ga.ck = nullptr; ga.cm = nullptr;
     if (D <= 128) {                                  // repeats in the candidate lists: the matchers scan each distinct entry once
-        launch_ng_dedupe(d.stream, dC, dDd, dDk, dBox, dKstat, W, H, (int)D, n);
-        ga.dd = dDd; ga.dk = dDk; ga.dbox = dBox; ga.kstat = dKstat;
+        launch_ng_dedupe(d.stream, dC, dDd, dDk, dBox, dKstat, dCk, dCm, W, H, (int)D, n);
+        ga.dd = dDd; ga.dk = dDk; ga.dbox = dBox; ga.kstat = dKstat; ga.ck = dCk; ga.cm = dCm;
     }
     launch_ng_aggregate(d.stream, ga, n);
     NgWtaArgs wa;
     wa.C = dC; wa.S = dS; wa.minC = dMinC; wa.flow = dFlow; wa.W = W; wa.H = H; wa.D = (int)D;
+    wa.cm = ga.dd ? dCm : nullptr; wa.dk = ga.dd ? dDk : nullptr;
     launch_ng_wta(d.stream, wa, n);
+    bool want_S = false;
+    for (int i = 0; i < n; i++) want_S = want_S || out[i].S;
+    if (want_S && ga.dd) launch_ng_fill_repeats(d.stream, dS, dDd, dCm, W, H, (int)D, n);      // the compact kernel adds to kept entries only
     if (a.subPixelRefine) {                                                     // :516-517
         NgSubpixArgs sa;
         sa.cen1 = dCen1; sa.cen2 = dCen2; sa.flow = dFlow; sa.W = W; sa.H = H;

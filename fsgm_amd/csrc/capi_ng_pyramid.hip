@@ -29,6 +29,8 @@ struct fsgm_ng_pyramid_plan {
     uint8_t* dDk = nullptr;
     uint32_t* dBox = nullptr;                        // bounding boxes of the lists' motion vectors (grid matcher)
     uint32_t* dKstat = nullptr;                      // partial sums of the list lengths (choice of the matcher form)
+    uint32_t* dCk = nullptr;                         // the kept entries in place order (compact aggregation kernel)
+    uint16_t* dCm = nullptr;
     Cand* dC = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -52,7 +54,7 @@ void fsgm_ng_pyramid_plan_destroy(fsgm_ng_pyramid_plan* p) {
     (void)hipSetDevice(p->device);
     auto drop = [](auto& v) { for (auto* b : v) if (b) (void)hipFree(b); };
     drop(p->dP0); drop(p->dP1); drop(p->dG0); drop(p->dG1); drop(p->dMv); drop(p->dFlow); drop(p->dMinC);
-    void* one[] = {p->dCen1, p->dCen2, p->dS, p->dUnsafe, p->dC, p->dDd, p->dDk, p->dBox, p->dKstat};
+    void* one[] = {p->dCen1, p->dCen2, p->dS, p->dUnsafe, p->dC, p->dDd, p->dDk, p->dBox, p->dKstat, p->dCk, p->dCm};
     for (void* b : one) if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -120,7 +122,9 @@ fsgm_status fsgm_ng_pyramid_plan_create_batch(fsgm_ng_pyramid_plan** out, int32_
     if (e == hipSuccess) e = hipMalloc((void**)&p->dDd, B * N * 2);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dDk, B * NP);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dBox, B * NP * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->dKstat, 256 * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dKstat, NG_KSTAT_WORDS * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dCk, B * N * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dCm, B * N * 2);
     if (e == hipSuccess) e = hipMemset(p->dMv[n - 1], 0, B * 2 * (size_t)p->mvW[n - 1] * p->mvH[n - 1] * sizeof(double));   // :34
     if (e != hipSuccess) {
         fsgm_ng_pyramid_plan_destroy(p);
@@ -182,14 +186,15 @@ static fsgm_status ng_pyramid_enqueue(fsgm_ng_pyramid_plan* p) {
         launch_ng_cost(s, ca, B);
         NgAggArgs ga;
         ga.C = p->dC; ga.S = p->dS; ga.unsafe = p->dUnsafe; ga.W = w; ga.H = h; ga.D = D; ga.P1 = p->prm.P1; ga.P2 = p->prm.P2;
-        ga.dd = nullptr; ga.dk = nullptr; ga.dbox = nullptr; ga.kstat = nullptr; ga.pick = 0;
+        ga.dd = nullptr; ga.dk = nullptr; ga.dbox = nullptr; ga.kstat = nullptr; ga.ck = nullptr; ga.cm = nullptr;
         if (D <= 128) {
-            launch_ng_dedupe(s, p->dC, p->dDd, p->dDk, p->dBox, p->dKstat, w, h, D, B);
-            ga.dd = p->dDd; ga.dk = p->dDk; ga.dbox = p->dBox; ga.kstat = p->dKstat;
+            launch_ng_dedupe(s, p->dC, p->dDd, p->dDk, p->dBox, p->dKstat, p->dCk, p->dCm, w, h, D, B);
+            ga.dd = p->dDd; ga.dk = p->dDk; ga.dbox = p->dBox; ga.kstat = p->dKstat; ga.ck = p->dCk; ga.cm = p->dCm;
         }
         launch_ng_aggregate(s, ga, B);
         NgWtaArgs wa;
         wa.C = p->dC; wa.S = p->dS; wa.minC = p->dMinC[l]; wa.flow = p->dFlow[l]; wa.W = w; wa.H = h; wa.D = D;
+        wa.cm = ga.dd ? p->dCm : nullptr; wa.dk = ga.dd ? p->dDk : nullptr;
         launch_ng_wta(s, wa, B);
         if (p->prm.subPixelRefine) {                                             // :516-517
             NgSubpixArgs sa;

@@ -29,8 +29,14 @@ struct NgAggArgs {
     const uint8_t* dk;      //                 (launch_ng_dedupe); [frames][NP] length of that list.  Null: every candidate is staged
     const uint32_t* dbox;   // [frames][NP] packed origin of the bounding box of a pixel's motion vectors, or all ones when it is larger
                             // than the grid matcher takes (launch_ng_dedupe); null: list matcher only
-    const uint32_t* kstat;  // [256] partial sums of the list lengths of a sample of this launch's pixels (launch_ng_dedupe); with `pick` != 0 a kernel
-    int pick;               // leaves at once unless the mean length is >= NG_GRID_MIN_K (pick = 1) or below it (pick = -1)
+    const uint32_t* ck;     // [frames][NP][D] packed motion vector (ng_pack_mv) of the kept entry at each place   } launch_ng_dedupe; the
+    const uint16_t* cm;     // [frames][NP][D] (index of the group's first member << 8) | cost of the kept entry     } compact kernel's input
+    int role;               // which of the launch's aggregation kernels this is (NG_ROLE_*): each decides on the device whether it runs
+    int with_compact;       // the compact kernel is part of this launch set
+    int blk_begin_c[5];     // compact kernel: first block of each range (4 lines a workgroup)
+    int slot_of_c[4];
+    const uint32_t* kstat;  // [256] partial sums of the list lengths of a sample of this launch's pixels, [256] flags: bit 0 a list longer
+                            // than 64 entries, bit 1 a pixel whose entries do not fit the packed key (launch_ng_dedupe)
     int W, H, D;
     int P1, P2;
     int blk_begin[5];
@@ -40,6 +46,8 @@ struct NgAggArgs {
 struct NgWtaArgs {
     const Cand* C;
     const uint32_t* S;
+    const uint16_t* cm;     // launch_ng_dedupe's kept-entry table and list lengths: the search runs over the groups of repeats,
+    const uint8_t* dk;      // whose sums sit at their first members' indices; both null: over all D candidates
     uint32_t* minC;         // [frames][NP]
     double* flow;           // [frames][2][NP]
     int W, H, D;
@@ -70,7 +78,12 @@ struct OtfArgs {
 void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames);
 void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames);
 // repeats among the D <= 128 candidates of every pixel (same motion vector and same cost), see ng_dedupe_kernel
-void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, int W, int H, int D, int frames);   // kstat: 256 words, zeroed here
+enum { NG_ROLE_ANY = 0, NG_ROLE_GRID = 1, NG_ROLE_LIST = 2, NG_ROLE_COMPACT = 3, NG_ROLE_REST = 4 };
+constexpr int NG_KSTAT_WORDS = 257;
+// kstat: NG_KSTAT_WORDS words, zeroed here; ck / cm may be null (no compact kernel)
+void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, uint32_t* ck, uint16_t* cm, int W, int H, int D, int frames);
+// S of the repeats := S of the entries they repeat (only needed when S itself is read back: the WTA looks them up)
+void launch_ng_fill_repeats(hipStream_t st, uint32_t* S, const uint16_t* dd, const uint16_t* cm, int W, int H, int D, int frames);
 void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames);
 void launch_ng_subpixel(hipStream_t st, const NgSubpixArgs& a, int frames);
 void launch_otf(hipStream_t st, const OtfArgs& a, int frames);

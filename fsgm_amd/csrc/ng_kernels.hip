@@ -277,10 +277,15 @@ constexpr int NG_GCELLS = NG_GS * NG_GS;
 constexpr uint32_t NG_BOX_WIDE = 0xFFFFFFFFu;
 constexpr uint32_t NG_GRID_MIN_K = 16;   // mean list length from which the grid form is the faster one (it costs the same at any length)
 
-// adaptive choice between the two aggregation kernels, made on the device: both are launched, each sums the 256 partial
-// list-length sums of the dedupe kernel and the one the mean length does not favour returns (block-uniform)
+constexpr uint32_t NG_COMPACT_MAX_K = 40;   // mean list length up to which the compact kernel (work ~ K^2) beats the grid form (flat)
+
+// Choice between the aggregation kernels of a launch, made on the device: all candidates are launched, each sums the
+// 256 partial list-length sums of the dedupe kernel, reads its flags, and those the lists do not favour return
+// (block-uniform).  Compact (one wave a line over the kept entries only): every list <= 64 entries, every entry inside
+// the packed key's range, mean length below NG_COMPACT_MAX_K.  Otherwise grid from a mean length of NG_GRID_MIN_K, list
+// below it; NG_ROLE_REST: whatever runs when the compact kernel does not (the split kernel of one or two frames).
 __device__ __forceinline__ bool ng_agg_not_mine(const NgAggArgs& a, uint32_t* scratch) {
-    if (a.pick == 0) return false;
+    if (a.role == NG_ROLE_ANY) return false;
     if (threadIdx.x == 0) *scratch = 0;
     __syncthreads();
     uint32_t v = threadIdx.x < 256 ? a.kstat[threadIdx.x] : 0u;
@@ -289,9 +294,16 @@ __device__ __forceinline__ bool ng_agg_not_mine(const NgAggArgs& a, uint32_t* sc
     if ((threadIdx.x & 63) == 0) atomicAdd(scratch, v);
     __syncthreads();
     const unsigned long long npix = ((((unsigned long long)a.W * a.H * gridDim.y + 3) / 4 + 15) / 16) * 4;   // the dedupe kernel's sample: every 16th workgroup of 4 pixels
-    const bool high = (unsigned long long)*scratch >= (unsigned long long)NG_GRID_MIN_K * npix;
+    const unsigned long long sum = *scratch;
+    const bool high = sum >= (unsigned long long)NG_GRID_MIN_K * npix;
+    const bool compact = a.with_compact && a.kstat[256] == 0u && sum < (unsigned long long)NG_COMPACT_MAX_K * npix;
     __syncthreads();
-    return a.pick > 0 ? !high : high;
+    switch (a.role) {
+        case NG_ROLE_COMPACT: return !compact;
+        case NG_ROLE_GRID: return compact || !high;
+        case NG_ROLE_LIST: return compact || high;
+        default: return compact;                                 // NG_ROLE_REST
+    }
 }
 
 // motion vector as 2 x u16 (valid for |mv| < 0x3FF0: the launch's unsafe flag is raised otherwise)
@@ -389,7 +401,8 @@ __device__ __forceinline__ void ng_match4_pair(const NgPre& q, int D, int mvxa, 
 // Also written per pixel: the bounding box of its motion vectors, as its packed origin (ng_pack_mv) when both
 // sides are <= NG_GB, NG_BOX_WIDE otherwise -- what the grid form of the matcher (ng_agg_grid_kernel) needs.
 __global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__ C, uint16_t* __restrict__ dd, uint8_t* __restrict__ dk,
-                                                        uint32_t* __restrict__ dbox, uint32_t* __restrict__ kstat, int NPtot, int D) {
+                                                        uint32_t* __restrict__ dbox, uint32_t* __restrict__ kstat, uint32_t* __restrict__ ck,
+                                                        uint16_t* __restrict__ cm, int NPtot, int D) {
     __shared__ __attribute__((aligned(16))) uint32_t sk[4][128];
     __shared__ __attribute__((aligned(16))) uint32_t stab[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -453,13 +466,35 @@ __global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__
     }
     const bool keep0 = has0 && last0 == d0, keep1 = has1 && last1 == d1;
     const unsigned long long b0 = __builtin_amdgcn_ballot_w64(keep0), b1 = __builtin_amdgcn_ballot_w64(keep1);
-    const unsigned long long below = (1ull << lane) - 1ull;
     const int n0 = __popcll(b0);
-    if (has0) dd[(size_t)p * D + d0] = keep0 ? (uint16_t)__popcll(b0 & below) : (uint16_t)0xFFFF;
-    if (has1) dd[(size_t)p * D + d1] = keep1 ? (uint16_t)(n0 + __popcll(b1 & below)) : (uint16_t)0xFFFF;
+    // place of entry e among the kept ones; a repeat records the place of the entry it repeats (its last twin, which is kept)
+    auto place_of = [&](int e) -> uint32_t {
+        return e < 64 ? (uint32_t)__popcll(b0 & ((1ull << e) - 1ull)) : (uint32_t)n0 + (uint32_t)__popcll(b1 & ((1ull << (e - 64)) - 1ull));
+    };
+    const uint32_t pl0 = place_of(keep0 ? d0 : last0), pl1 = place_of(keep1 ? d1 : last1);
+    if (has0) dd[(size_t)p * D + d0] = (uint16_t)(keep0 ? pl0 : 0x8000u | pl0);
+    if (has1) dd[(size_t)p * D + d1] = (uint16_t)(keep1 ? pl1 : 0x8000u | pl1);
+    const int K = n0 + __popcll(b1);
+    if (ck) {
+        // The kept entries in place order.  Each stands for its group of repeats; the group's sums live at its FIRST
+        // member's index (the WTA takes the first minimum over d, :281-299, and all members of a group tie): first
+        // index = minimum over the members, collected per group under the index of its last member.
+        uint32_t* fi = stab[wave];                               // (the hash table is done with)
+        __builtin_amdgcn_wave_barrier();
+        fi[d0] = 0xFFFFFFFFu; fi[d1] = 0xFFFFFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        if (has0) atomicMin(&fi[last0], (uint32_t)d0);
+        if (has1) atomicMin(&fi[last1], (uint32_t)d1);
+        __builtin_amdgcn_wave_barrier();
+        if (keep0) { ck[(size_t)p * D + pl0] = ng_pack_mv(e0.mvx, e0.mvy); cm[(size_t)p * D + pl0] = (uint16_t)((fi[d0] << 8) | ((uint32_t)e0.cost & 0xFFu)); }
+        if (keep1) { ck[(size_t)p * D + pl1] = ng_pack_mv(e1.mvx, e1.mvy); cm[(size_t)p * D + pl1] = (uint16_t)((fi[d1] << 8) | ((uint32_t)e1.cost & 0xFFu)); }
+    }
     if (lane == 0) {
-        dk[p] = (uint8_t)(n0 + __popcll(b1));
-        if (kstat && (blockIdx.x & 15) == 0) atomicAdd(&kstat[(blockIdx.x >> 4) & 255], (uint32_t)(n0 + __popcll(b1)));   // a 1-in-16 sample of the pixels
+        dk[p] = (uint8_t)K;
+        if (kstat) {
+            if ((blockIdx.x & 15) == 0) atomicAdd(&kstat[(blockIdx.x >> 4) & 255], (uint32_t)K);   // a 1-in-16 sample of the pixels
+            if (K > 64 || !all_ok) atomicOr(&kstat[256], (K > 64 ? 1u : 0u) | (all_ok ? 0u : 2u));  // rare: the compact kernel steps aside
+        }
     }
 }
 
@@ -538,7 +573,7 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
             if (tact) atomicMin(&smin[t % 3], (uint32_t)o & 0xFF);                // :74 narrowed
         }
         if (tact) {
-            if (place != 0xFFFFu) {
+            if (place < 0x8000u) {                                    // a kept entry (repeats carry 0x8000 | the place of the entry they repeat)
                 buf1[place] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + place] = (uint32_t)c.mvy;
                 buf1[2 * Dp + place] = (uint32_t)o & 0xFF; buf1[3 * Dp + place] = (uint32_t)(o + a.P1) & 0xFF;
             }
@@ -677,7 +712,7 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
             if (tact) atomicMin(&smin[t % 3], (uint32_t)o & 0xFF);                // :74 narrowed
         }
         if (tact) {
-            if (place != 0xFFFFu) {
+            if (place < 0x8000u) {                                    // a kept entry (repeats carry 0x8000 | the place of the entry they repeat)
                 const uint32_t c8 = (uint32_t)o & 0xFF, cp = (uint32_t)(o + a.P1) & 0xFF;
                 buf1[place] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + place] = (uint32_t)c.mvy;
                 buf1[2 * Dp + place] = c8; buf1[3 * Dp + place] = cp;
@@ -705,6 +740,120 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
         tmp = gpre; gpre = gcur; gcur = gnxt; gnxt = tmp;
       }
     }
+}
+
+// The same aggregation over the KEPT entries only: one wave per line, lane = place in the pixel's list without
+// repeats (launch_ng_dedupe writes that list as packed motion vector + (candidate index, cost): ck / cm).  A repeat gets
+// the same path cost as the entry it repeats on every path (ng_dedupe_kernel's header), so nothing is lost by not
+// computing it: S is added to at the kept entries only and the WTA reads a repeat's sum from the entry it repeats
+// (ng_wta_kernel; launch_ng_fill_repeats when S itself is wanted).  With the lists of real hint maps (10-20 of 81
+// entries distinct) that is a quarter of the matcher work and of the atomic adds; the line's minimum is a wave
+// reduction and a step has no workgroup barrier at all -- the four waves of a workgroup walk four lines independently.
+// Runs when every list of the launch has at most 64 entries inside the packed key's range (ng_agg_not_mine).
+__device__ __forceinline__ uint32_t ng_match4_key(const uint32_t* qk, const uint32_t* qc8, const uint32_t* qcp, int K4, uint32_t key, uint32_t jump) {
+    const uint32_t ck2 = key + 0x00020002u;
+    uint32_t min1 = jump, near2min = 0xFFFFu;
+    for (int d2 = 0; d2 < K4; d2 += 4) {
+        const uint4 k4 = *(const uint4*)(qk + d2);
+        const uint4 c8 = *(const uint4*)(qc8 + d2), cp = *(const uint4*)(qcp + d2);
+        const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w};
+        const uint32_t c8a[4] = {c8.x, c8.y, c8.z, c8.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t t = pk_sub(ck2, ka[i]);
+            const bool nr = pk_min(t, 0x00040004u) == t, eq = t == 0x00020002u;
+            min1 = eq ? c8a[i] : min1;                                        // last match wins
+            uint32_t sel = nr ? cpa[i] : 0xFFFFu;
+            sel = eq ? 0xFFFFu : sel;
+            near2min = min(near2min, sel);
+        }
+    }
+    return min(jump, min(min1, near2min));
+}
+
+__global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
+    constexpr int LS = 68;                                    // LDS stride of one array: 64 entries + padding to a multiple of 4
+    __shared__ __attribute__((aligned(16))) uint32_t sC[4][2][3][LS];    // [wave][buffer][key, cost & 0xFF, (cost + P1) & 0xFF][place]
+    __shared__ uint32_t sPick;
+    if (ng_agg_not_mine(a, &sPick)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int bb = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if ((int)blockIdx.x >= a.blk_begin_c[i]) bb = i;
+    const int slot = a.slot_of_c[bb];
+    const int base = slot & 1;                               // 0: along x, 1: along y
+    const bool mirror = slot >= 2;
+    const int W = a.W, H = a.H, D = a.D;
+    const int NP = W * H;
+    const int nlines = base == 0 ? H : W;
+    const int len = base == 0 ? W : H;
+    const int line = ((int)blockIdx.x - a.blk_begin_c[bb]) * 4 + wave;
+    if (line >= nlines) return;                               // wave-uniform; the waves of a workgroup never meet again
+    const size_t f = blockIdx.y;
+    const uint32_t* __restrict__ ckf = a.ck + f * (size_t)NP * D;
+    const uint16_t* __restrict__ cmf = a.cm + f * (size_t)NP * D;
+    const uint8_t* __restrict__ dkf = a.dk + f * (size_t)NP;
+    uint32_t* __restrict__ Sf = a.S + f * (size_t)NP * D;
+    int pix0 = base == 0 ? line * W : line;
+    if (mirror) pix0 = NP - 1 - pix0;
+    const int dpix = (mirror ? -1 : 1) * (base == 0 ? 1 : W);
+    const uint32_t dent = (uint32_t)(dpix * D);
+    const uint32_t pl = (uint32_t)min(lane, D - 1);          // lanes past the list read inside the pixel's D slots
+    uint32_t p_cur = (uint32_t)pix0, p_fet = p_cur, e_fet = p_cur * (uint32_t)D;
+    constexpr int PF = 4;
+    uint32_t rkey[PF], rmeta[PF], rlen[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        rkey[k] = ckf[e_fet + pl]; rmeta[k] = cmf[e_fet + pl]; rlen[k] = dkf[p_fet];
+        if (k + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
+    }
+    uint32_t* b0 = &sC[wave][0][0][0];
+    uint32_t* b1 = &sC[wave][1][0][0];
+    uint32_t m = 0;                                           // :172 / :77: stored minimum 0 at a path start
+    int K4pre = 0;
+    for (int t0 = 0; t0 < len; t0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int t = t0 + u;
+        if (t >= len) break;                                  // wave-uniform
+        const uint32_t key = rkey[u], meta = rmeta[u];
+        const int K = (int)rlen[u];
+        rkey[u] = ckf[e_fet + pl]; rmeta[u] = cmf[e_fet + pl]; rlen[u] = dkf[p_fet];
+        if (t + PF + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
+        const bool act = lane < K;
+        const int cost = (int)(meta & 0xFFu);
+        int o = cost;
+        if (t > 0) {
+            const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
+            o = (cost + (int)ng_match4_key(b0, b0 + LS, b0 + 2 * LS, K4pre, key, jump)) - (int)m;
+        }
+        const uint32_t lo = wave_min_u32(act ? ((uint32_t)o & 0xFFu) : 0xFFFFFFFFu);          // :74 narrowed
+        const int K4 = (K + 3) & ~3;
+        if (act) {
+            b1[lane] = key; b1[LS + lane] = (uint32_t)o & 0xFF; b1[2 * LS + lane] = (uint32_t)(o + a.P1) & 0xFF;
+            atomicAdd(&Sf[p_cur * (uint32_t)D + (meta >> 8)], (uint32_t)o);                    // :249
+        } else if (lane < K4) {                               // neutral entries up to the next multiple of 4
+            b1[lane] = NG_PADKEY; b1[LS + lane] = 0xFFFFu; b1[2 * LS + lane] = 0xFFFFu;
+        }
+        m = t > 0 ? lo : 0u;
+        K4pre = K4;
+        p_cur += (uint32_t)dpix;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t* tmp = b0; b0 = b1; b1 = tmp;
+      }
+    }
+}
+
+// S of every member of a group of repeats := S of the group's first member (for reading S back: the compact kernel
+// adds there only)
+__global__ __launch_bounds__(256) void ng_fill_repeats_kernel(uint32_t* __restrict__ S, const uint16_t* __restrict__ dd, const uint16_t* __restrict__ cm,
+                                                              long long n, int D) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long p0 = i - i % D;
+    const long long first = p0 + (cm[p0 + (dd[i] & 0x7FFFu)] >> 8);     // the group's first member holds the sums
+    if (first != i) S[i] = S[first];
 }
 
 // The matcher of one candidate over the entries [e0, e1) of a staged predecessor (e0 % 4 == 0): the last exact
@@ -752,6 +901,7 @@ __device__ __forceinline__ void ng_match_range(const NgPre& q, int e0, int e1, i
 template <int PARTS>
 __global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sNg[];
+    if (ng_agg_not_mine(a, sNg)) return;
     // [line][2 buffers][4 arrays][Dp] | [line][8]: 3 minima, staged lengths at [4 + step parity] | [line][Dp] candidate mvx | [line][Dp] mvy | [PARTS - 1][line][Dp][2]
     int k = 0;
 #pragma unroll
@@ -847,7 +997,7 @@ __global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) 
                 if (tact) atomicMin(&smin[t % 3], (uint32_t)o & 0xFF);            // :74 narrowed
             }
             if (tact) {
-                if (place != 0xFFFFu) {
+                if (place < 0x8000u) {                                    // a kept entry (repeats carry 0x8000 | the place of the entry they repeat)
                     buf1[place] = safe ? ng_pack_mv(c.mvx, c.mvy) : (uint32_t)c.mvx; buf1[Dp + place] = (uint32_t)c.mvy;
                     buf1[2 * Dp + place] = (uint32_t)o & 0xFF; buf1[3 * Dp + place] = (uint32_t)(o + a.P1) & 0xFF;
                 }
@@ -867,7 +1017,9 @@ __global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) 
     }
 }
 
-// WTA -> winning candidate's motion vector (calc_pyd_cost_sgm_ng.cpp:281-299); one wave per pixel
+// WTA -> winning candidate's motion vector (calc_pyd_cost_sgm_ng.cpp:281-299); one wave per pixel.  With the kept-entry
+// table of launch_ng_dedupe the search runs over the K groups of repeats instead of the D candidates: a group's sum sits
+// at its first member's index, every member ties with it, so the first minimum over d is the smallest (sum, first index).
 __global__ __launch_bounds__(256) void ng_wta_kernel(NgWtaArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NP = a.W * a.H, D = a.D;
@@ -875,10 +1027,13 @@ __global__ __launch_bounds__(256) void ng_wta_kernel(NgWtaArgs a) {
     if (p >= NP) return;
     const size_t f = blockIdx.y;
     const uint32_t* Sp = a.S + f * (size_t)NP * D + (size_t)p * D;
+    const uint16_t* cmp = a.cm ? a.cm + f * (size_t)NP * D + (size_t)p * D : nullptr;
+    const int n = cmp ? (int)a.dk[f * (size_t)NP + p] : D;
     uint32_t lo = 0xFFFFFFFFu, idx = 0xFFFFFFFFu;
-    for (int d = lane; d < D; d += 64) {
+    for (int e = lane; e < n; e += 64) {
+        const uint32_t d = cmp ? (uint32_t)(cmp[e] >> 8) : (uint32_t)e;
         const uint32_t s = Sp[d];
-        if (s < lo || idx == 0xFFFFFFFFu) { lo = s; idx = d; }
+        if (s < lo || idx == 0xFFFFFFFFu || (s == lo && d < idx)) { lo = s; idx = d; }
     }
     uint32_t glo = lo;
 #pragma unroll
@@ -1403,8 +1558,8 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         acc += (((i & 1) == 0 ? a.H : a.W) + 3) / 4;
     }
     a.blk_begin[4] = acc;
-    a.pick = 0;
-    { const char* e = getenv("FSGM_NG_DEDUPE"); if (e && atoi(e) == 0) { a.dd = nullptr; a.dk = nullptr; a.dbox = nullptr; } }   // A/B switch: stage every candidate
+    a.role = NG_ROLE_ANY; a.with_compact = 0;
+    { const char* e = getenv("FSGM_NG_DEDUPE"); if (e && atoi(e) == 0) { a.dd = nullptr; a.dk = nullptr; a.dbox = nullptr; a.ck = nullptr; a.cm = nullptr; } }   // A/B switch: stage every candidate
     if (a.D <= 128 && a.unsafe) {
         const int lpb = 256 / a.D, Dp = (a.D + 3) & ~3;
         // long lines first: with few frames their blocks decide when the launch ends
@@ -1412,6 +1567,27 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         const int nparts = frames <= 2 ? (env ? atoi(env) : 2) : 1;   // 1242x375, 3-level pyramid: 9.64 / 7.34 / 7.98 / 7.66 ms with 1 / 2 / 3 / 4 parts
         const bool split = nparts >= 2 && nparts <= 4;
         const int ord_x[4] = {0, 2, 1, 3}, ord_y[4] = {1, 3, 0, 2};
+        // Which kernel runs is settled on the device from what the dedupe kernel saw (ng_agg_not_mine): every candidate
+        // is launched, the ones not favoured return at once.  FSGM_NG_COMPACT=0 / FSGM_NG_GRID=0 take a kernel out of the
+        // set, =1 makes it the only one (A/B switches; the compact kernel still steps aside for lists it cannot hold).
+        const char* cenv = getenv("FSGM_NG_COMPACT");
+        const int compact_env = cenv && *cenv ? atoi(cenv) : -1;
+        const char* genv = getenv("FSGM_NG_GRID");
+        const int grid_env = genv && *genv ? atoi(genv) : -1;
+        const bool can_stat = a.dd && a.dk && a.kstat;
+        if (can_stat && a.ck && a.cm && compact_env != 0 && grid_env != 1) {
+            acc = 0;
+            for (int i = 0; i < 4; i++) {
+                const int sl = a.W >= a.H ? ord_x[i] : ord_y[i];
+                a.slot_of_c[i] = sl;
+                a.blk_begin_c[i] = acc;
+                acc += (((sl & 1) == 0 ? a.H : a.W) + 3) / 4;
+            }
+            a.blk_begin_c[4] = acc;
+            a.with_compact = 1;
+            a.role = NG_ROLE_COMPACT;
+            hipLaunchKernelGGL(ng_agg_compact_kernel, dim3(acc, frames), dim3(256), 0, st, a);
+        }
         acc = 0;
         for (int i = 0; i < 4; i++) {
             const int sl = split ? (a.W >= a.H ? ord_x[i] : ord_y[i]) : i;
@@ -1421,20 +1597,15 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         }
         a.blk_begin[4] = acc;
         // The grid form of the matcher costs the same at any list length, the list form grows with it: lists of a few
-        // entries (nearly constant hint maps) are faster walked, anything richer is faster looked up.  FSGM_NG_GRID: 0 list
-        // form only, 1 grid form only (also for one or two frames, where the split list matcher is the default), unset:
-        // both launched, the device picks by the mean list length of this launch (ng_agg_not_mine).
-        const char* genv = getenv("FSGM_NG_GRID");
-        const int grid_env = genv && *genv ? atoi(genv) : -1;
-        const bool can_grid = a.dd && a.dk && a.dbox && a.kstat;
-        a.pick = 0;
-        if (can_grid && grid_env != 0 && (grid_env == 1 || !split)) {
+        // entries (nearly constant hint maps) are faster walked, anything richer is faster looked up.
+        const bool with_grid = can_stat && a.dbox && grid_env != 0 && (grid_env == 1 || !split);
+        if (with_grid) {
             const size_t lds = ((size_t)lpb * 8 * Dp + (size_t)lpb * 6 * NG_GCELLS + lpb * 8 + 2 * lpb) * sizeof(uint32_t);
-            a.pick = grid_env == 1 ? 0 : 1;
+            a.role = grid_env == 1 ? NG_ROLE_ANY : NG_ROLE_GRID;
             hipLaunchKernelGGL(ng_agg_grid_kernel, dim3(acc, frames), dim3(256), lds, st, a);
             if (grid_env == 1) return;
-            a.pick = -1;
         }
+        a.role = with_grid ? NG_ROLE_LIST : (a.with_compact ? NG_ROLE_REST : NG_ROLE_ANY);
         if (split) {
             const size_t lds = ((size_t)lpb * (10 * Dp + 8) + (size_t)(nparts - 1) * lpb * Dp * 2) * sizeof(uint32_t);
             if (nparts == 2)      hipLaunchKernelGGL(ng_agg_split_kernel<2>, dim3(acc, frames), dim3(512), lds, st, a);
@@ -1449,10 +1620,15 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
     hipLaunchKernelGGL(ng_agg_kernel, dim3(acc, frames), dim3(256), 0, st, a);
 }
 
-void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, int W, int H, int D, int frames) {
+void launch_ng_fill_repeats(hipStream_t st, uint32_t* S, const uint16_t* dd, const uint16_t* cm, int W, int H, int D, int frames) {
+    const long long n = (long long)W * H * D * frames;
+    hipLaunchKernelGGL(ng_fill_repeats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, dd, cm, n, D);
+}
+
+void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, uint32_t* ck, uint16_t* cm, int W, int H, int D, int frames) {
     const int n = W * H * frames;                            // frames are contiguous in all arrays
-    if (kstat) (void)hipMemsetAsync(kstat, 0, 256 * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(ng_dedupe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, dd, dk, dbox, kstat, n, D);
+    if (kstat) (void)hipMemsetAsync(kstat, 0, NG_KSTAT_WORDS * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(ng_dedupe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, dd, dk, dbox, kstat, ck, cm, n, D);
 }
 
 void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames) {

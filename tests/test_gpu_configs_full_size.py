@@ -81,20 +81,33 @@ def test_config4_single_level_full_size(gpu_lib, oracle):
     I1, I2 = synth.image_pair(W, H, 16, seed=41)
     mv = _smooth_hints(W, H, 1, big=True)
     mc, fl, _, S = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 1, 6, 32, want_volumes=True)
-    saved = {k: os.environ.get(k) for k in ("FSGM_NG_SPLIT", "FSGM_NG_DEDUPE", "FSGM_NG_GRID")}
+    saved = {k: os.environ.get(k) for k in ("FSGM_NG_SPLIT", "FSGM_NG_DEDUPE", "FSGM_NG_GRID", "FSGM_NG_COMPACT")}
     try:
-        # (matcher parts, repeat removal, grid form: "" = the device picks between the list and the grid kernel when the
-        # matcher is not split, "1" / "0" = grid / list kernel whatever the lists look like)
-        for split, dedupe, grid in [("2", "1", ""), ("1", "1", ""), ("2", "0", ""), ("1", "0", ""), ("3", "1", ""), ("2", "1", "1"), ("1", "1", "0")]:
+        # (matcher parts, repeat removal, grid form, compact kernel): "" = picked on the device -- these hints hold regions
+        # outside the packed key's range, so the compact kernel (kept entries only) steps aside there and the split / list /
+        # grid kernels run; "1" / "0" = forced / taken out of the set
+        variants = [("2", "1", "", ""), ("1", "1", "", ""), ("2", "0", "", ""), ("1", "0", "", ""), ("3", "1", "", ""),
+                    ("2", "1", "1", ""), ("1", "1", "0", ""), ("2", "1", "", "0"), ("1", "1", "", "0")]
+        for split, dedupe, grid, compact in variants:
             os.environ["FSGM_NG_SPLIT"], os.environ["FSGM_NG_DEDUPE"] = split, dedupe
-            if grid:
-                os.environ["FSGM_NG_GRID"] = grid
-            else:
-                os.environ.pop("FSGM_NG_GRID", None)
+            for k, v in (("FSGM_NG_GRID", grid), ("FSGM_NG_COMPACT", compact)):
+                if v:
+                    os.environ[k] = v
+                else:
+                    os.environ.pop(k, None)
             gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, 1, 6, 32, return_sum=True)
-            np.testing.assert_array_equal(gS, S, err_msg=f"split {split} dedupe {dedupe} grid {grid!r}")
-            np.testing.assert_array_equal(gmc, mc, err_msg=f"split {split} dedupe {dedupe} grid {grid!r}")
-            np.testing.assert_array_equal(gfl, fl, err_msg=f"split {split} dedupe {dedupe} grid {grid!r}")
+            tag = f"split {split} dedupe {dedupe} grid {grid!r} compact {compact!r}"
+            np.testing.assert_array_equal(gS, S, err_msg=tag)
+            np.testing.assert_array_equal(gmc, mc, err_msg=tag)
+            np.testing.assert_array_equal(gfl, fl, err_msg=tag)
+        # the same frame without the out-of-range regions: every list fits, the compact kernel is what runs
+        os.environ.pop("FSGM_NG_GRID", None); os.environ.pop("FSGM_NG_COMPACT", None)
+        mv2 = _smooth_hints(W, H, 1, big=False)
+        mc2, fl2, _, S2 = oracle.calc_pyd_cost_sgm_ng(I1, I2, mv2, 1, 2, 1, 6, 32, want_volumes=True)
+        gmc, gfl, gS = calc_pyd_cost_sgm_ng(I1, I2, mv2, 1, 2, 1, 6, 32, return_sum=True)
+        np.testing.assert_array_equal(gS, S2, err_msg="compact")
+        np.testing.assert_array_equal(gmc, mc2, err_msg="compact")
+        np.testing.assert_array_equal(gfl, fl2, err_msg="compact")
     finally:
         for k, v in saved.items():
             if v is None:

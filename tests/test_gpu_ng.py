@@ -163,6 +163,40 @@ def test_calc_pyd_cost_sgm_ng_batch_picks_a_matcher_on_the_device(gpu_lib, oracl
             np.testing.assert_array_equal(gfl, fl, err_msg=f"rep {rep} frame {i}")
 
 
+@pytest.mark.parametrize("kind,amp,sub,P1,P2,n", [
+    ("zero", 1.0, 0, 6, 32, 1),            # 9 kept entries of 81
+    ("int", 1.0, 1, 6, 32, 3),             # up to 25
+    ("int", 2.0, 0, 6, 32, 1),             # up to 49: near the 64 lanes of a wave
+    ("int", 3.0, 1, 6, 32, 3),             # some pixels beyond 64 kept entries: the whole launch falls back
+    ("general", 0.8, 1, 6, 32, 1),         # fractional hints: equal vectors at different costs stay separate entries
+    ("general", 0.8, 0, 90, 120, 3),       # wrapping penalties
+])
+def test_calc_pyd_cost_sgm_ng_compact_kernel(gpu_lib, oracle, monkeypatch, kind, amp, sub, P1, P2, n):
+    """The aggregation over the kept entries only (ng_agg_compact_kernel: one wave per line, sums at the first member of
+    every group of repeats, WTA over the groups): S -- read back through launch_ng_fill_repeats --, minC and flow against
+    the oracle for lists from 9 entries to beyond what the kernel holds, single frames and batches; and with the kernel
+    taken out of the set (FSGM_NG_COMPACT=0) for the same inputs."""
+    from fsgm_amd import calc_pyd_cost_sgm_ng_batch
+    W, H = 83, 58
+    frames, want = [], []
+    for i in range(n):
+        I1, I2 = synth.image_pair(W, H, 16, seed=13 + i)
+        mv = synth.hint_map(W, H, kind, seed=17 + i, amp=amp)
+        frames.append((I1, I2, mv))
+        want.append(oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, sub, P1, P2, want_volumes=True))
+    for compact in ("", "0"):
+        if compact:
+            monkeypatch.setenv("FSGM_NG_COMPACT", compact)
+        gmc, gfl, gS = calc_pyd_cost_sgm_ng(*frames[0], 1, 2, sub, P1, P2, return_sum=True)
+        np.testing.assert_array_equal(gS, want[0][3], err_msg=f"compact {compact!r}")
+        np.testing.assert_array_equal(gmc, want[0][0], err_msg=f"compact {compact!r}")
+        np.testing.assert_array_equal(gfl, want[0][1], err_msg=f"compact {compact!r}")
+        if n > 1:
+            for i, (bmc, bfl) in enumerate(calc_pyd_cost_sgm_ng_batch(frames, 1, 2, sub, P1, P2)):
+                np.testing.assert_array_equal(bmc, want[i][0], err_msg=f"compact {compact!r} frame {i}")
+                np.testing.assert_array_equal(bfl, want[i][1], err_msg=f"compact {compact!r} frame {i}")
+
+
 def test_ng_batches_match_single_calls(gpu_lib, oracle):
     """Frames of a batch share one launch sequence (three or more frames: one thread per (line, candidate), no
     matcher split; the on-the-fly variant: one workgroup per frame): same results as the oracle frame by frame."""
