@@ -33,6 +33,8 @@ struct NgAggArgs {
     const uint16_t* cm;     // [frames][NP][D] (index of the group's first member << 8) | cost of the kept entry     } compact kernel's input
     int role;               // which of the launch's aggregation kernels this is (NG_ROLE_*): each decides on the device whether it runs
     int with_compact;       // the compact kernel is part of this launch set
+    int compact_g;          // compact kernel: lanes a line of this launch (16 / 32 / 64); the one the list statistics favour runs
+    int compact_force;      // ... or this one whatever they say (FSGM_NG_COMPACT_G, tests)
     int blk_begin_c[5];     // compact kernel: first block of each range (4 lines a workgroup)
     int slot_of_c[4];
     const uint32_t* kstat;  // [256] partial sums of the list lengths of a sample of this launch's pixels, [256] flags: bit 0 a list longer

@@ -296,10 +296,13 @@ __device__ __forceinline__ bool ng_agg_not_mine(const NgAggArgs& a, uint32_t* sc
     const unsigned long long npix = ((((unsigned long long)a.W * a.H * gridDim.y + 3) / 4 + 15) / 16) * 4;   // the dedupe kernel's sample: every 16th workgroup of 4 pixels
     const unsigned long long sum = *scratch;
     const bool high = sum >= (unsigned long long)NG_GRID_MIN_K * npix;
-    const bool compact = a.with_compact && a.kstat[256] == 0u && sum < (unsigned long long)NG_COMPACT_MAX_K * npix;
+    const uint32_t flags = a.kstat[256];
+    const bool compact = a.with_compact && (flags & 3u) == 0u && sum < (unsigned long long)NG_COMPACT_MAX_K * npix;
     __syncthreads();
     switch (a.role) {
-        case NG_ROLE_COMPACT: return !compact;
+        // one launch per lanes-a-line class: by the mean length for batches (throughput: more lines a wave), 64 for one or two
+        // frames (their long lines are serial chains: one line a wave is the shortest step)
+        case NG_ROLE_COMPACT: return !compact || (!a.compact_force && a.compact_g != (gridDim.y <= 2 ? 64 : sum < 14ull * npix ? 16 : sum < 28ull * npix ? 32 : 64));
         case NG_ROLE_GRID: return compact || !high;
         case NG_ROLE_LIST: return compact || high;
         default: return compact;                                 // NG_ROLE_REST
@@ -493,7 +496,10 @@ __global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__
         dk[p] = (uint8_t)K;
         if (kstat) {
             if ((blockIdx.x & 15) == 0) atomicAdd(&kstat[(blockIdx.x >> 4) & 255], (uint32_t)K);   // a 1-in-16 sample of the pixels
-            if (K > 64 || !all_ok) atomicOr(&kstat[256], (K > 64 ? 1u : 0u) | (all_ok ? 0u : 2u));  // rare: the compact kernel steps aside
+            // list-length classes of the launch (bit 0: a list beyond 64 entries, 2: beyond 16, 3: beyond 32) and bit 1: an entry
+            // outside the packed key's range; a bit is written by the first few pixels that find it clear
+            const uint32_t bits = (K > 64 ? 1u : 0u) | (all_ok ? 0u : 2u) | (K > 16 ? 4u : 0u) | (K > 32 ? 8u : 0u);
+            if (bits & ~__hip_atomic_load(&kstat[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&kstat[256], bits);
         }
     }
 }
@@ -771,12 +777,19 @@ __device__ __forceinline__ uint32_t ng_match4_key(const uint32_t* qk, const uint
     return min(jump, min(min1, near2min));
 }
 
+// G lanes a line (64 / G lines a wave), G = 16, 32 or 64 by the launch's MEAN list length: a lane takes the places
+// pl, pl + G, pl + 2G ... of its line's list, so a list longer than G costs the wave's lines extra rounds at that pixel only
+// (lists hold up to 64 entries whatever G).  Every round writes all G slots it covers (entries, then neutral ones), so
+// the matcher of a wave can run to the longest of its lines' staged lists.
+template <int G>
 __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
-    constexpr int LS = 68;                                    // LDS stride of one array: 64 entries + padding to a multiple of 4
-    __shared__ __attribute__((aligned(16))) uint32_t sC[4][2][3][LS];    // [wave][buffer][key, cost & 0xFF, (cost + P1) & 0xFF][place]
+    constexpr int LPW = 64 / G;                               // lines per wave
+    constexpr int LS = 68;                                    // LDS stride of one array: 64 entries + 4 (a multiple of 4: 16-byte reads)
+    __shared__ __attribute__((aligned(16))) uint32_t sC[4 * LPW][2][3][LS];    // [line of the workgroup][buffer][key, cost & 0xFF, (cost + P1) & 0xFF][place]
     __shared__ uint32_t sPick;
     if (ng_agg_not_mine(a, &sPick)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / G, pl_ = lane % G;                 // line of the wave, first place in its list
     int bb = 0;
 #pragma unroll
     for (int i = 1; i < 4; i++)
@@ -788,8 +801,10 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     const int NP = W * H;
     const int nlines = base == 0 ? H : W;
     const int len = base == 0 ? W : H;
-    const int line = ((int)blockIdx.x - a.blk_begin_c[bb]) * 4 + wave;
-    if (line >= nlines) return;                               // wave-uniform; the waves of a workgroup never meet again
+    const int line0 = (((int)blockIdx.x - a.blk_begin_c[bb]) * 4 + wave) * LPW;
+    if (line0 >= nlines) return;                              // wave-uniform; the waves of a workgroup never meet again
+    const bool lact = line0 + sub < nlines;                   // lines past the last redo the last one without adding to S
+    const int line = min(line0 + sub, nlines - 1);
     const size_t f = blockIdx.y;
     const uint32_t* __restrict__ ckf = a.ck + f * (size_t)NP * D;
     const uint16_t* __restrict__ cmf = a.cm + f * (size_t)NP * D;
@@ -799,45 +814,55 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     if (mirror) pix0 = NP - 1 - pix0;
     const int dpix = (mirror ? -1 : 1) * (base == 0 ? 1 : W);
     const uint32_t dent = (uint32_t)(dpix * D);
-    const uint32_t pl = (uint32_t)min(lane, D - 1);          // lanes past the list read inside the pixel's D slots
+    const uint32_t pl = (uint32_t)min(pl_, D - 1);           // lanes past the list read inside the pixel's D slots
     uint32_t p_cur = (uint32_t)pix0, p_fet = p_cur, e_fet = p_cur * (uint32_t)D;
     constexpr int PF = 4;
-    uint32_t rkey[PF], rmeta[PF], rlen[PF];
+    uint32_t rkey[PF], rmeta[PF], rlen[PF];                   // the first round's entry of the coming steps
 #pragma unroll
     for (int k = 0; k < PF; k++) {
         rkey[k] = ckf[e_fet + pl]; rmeta[k] = cmf[e_fet + pl]; rlen[k] = dkf[p_fet];
         if (k + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
     }
-    uint32_t* b0 = &sC[wave][0][0][0];
-    uint32_t* b1 = &sC[wave][1][0][0];
+    uint32_t* b0 = &sC[wave * LPW + sub][0][0][0];
+    uint32_t* b1 = &sC[wave * LPW + sub][1][0][0];
     uint32_t m = 0;                                           // :172 / :77: stored minimum 0 at a path start
-    int K4pre = 0;
+    int K4pre = 0;                                            // (wave-uniform: the longest staged list of the wave's lines)
     for (int t0 = 0; t0 < len; t0 += PF) {
 #pragma unroll
       for (int u = 0; u < PF; u++) {
         const int t = t0 + u;
         if (t >= len) break;                                  // wave-uniform
-        const uint32_t key = rkey[u], meta = rmeta[u];
+        uint32_t key = rkey[u], meta = rmeta[u];
         const int K = (int)rlen[u];
         rkey[u] = ckf[e_fet + pl]; rmeta[u] = cmf[e_fet + pl]; rlen[u] = dkf[p_fet];
         if (t + PF + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
-        const bool act = lane < K;
-        const int cost = (int)(meta & 0xFFu);
-        int o = cost;
-        if (t > 0) {
-            const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
-            o = (cost + (int)ng_match4_key(b0, b0 + LS, b0 + 2 * LS, K4pre, key, jump)) - (int)m;
+        int kmax = K;                                         // the longest list of the wave's lines at this step (K is uniform inside a line)
+        if (LPW > 1) {
+#pragma unroll
+            for (int sft = G; sft < 64; sft <<= 1) kmax = max(kmax, __shfl_xor(kmax, sft));
         }
-        const uint32_t lo = wave_min_u32(act ? ((uint32_t)o & 0xFFu) : 0xFFFFFFFFu);          // :74 narrowed
-        const int K4 = (K + 3) & ~3;
-        if (act) {
-            b1[lane] = key; b1[LS + lane] = (uint32_t)o & 0xFF; b1[2 * LS + lane] = (uint32_t)(o + a.P1) & 0xFF;
-            atomicAdd(&Sf[p_cur * (uint32_t)D + (meta >> 8)], (uint32_t)o);                    // :249
-        } else if (lane < K4) {                               // neutral entries up to the next multiple of 4
-            b1[lane] = NG_PADKEY; b1[LS + lane] = 0xFFFFu; b1[2 * LS + lane] = 0xFFFFu;
+        const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
+        const uint32_t ecur = p_cur * (uint32_t)D;
+        uint32_t lov = 0xFFFFFFFFu;
+        for (int e0 = 0; e0 < (G == 64 ? 1 : kmax); e0 += G) { // one round unless a list is longer than G (wave-uniform bound; 64 lanes hold any list)
+            const int e = e0 + pl_;
+            if (G < 64 && e0 > 0 && e < K) { key = ckf[ecur + e]; meta = cmf[ecur + e]; }
+            const bool act = e < K;
+            const int cost = (int)(meta & 0xFFu);
+            int o = cost;
+            if (t > 0) o = (cost + (int)ng_match4_key(b0, b0 + LS, b0 + 2 * LS, K4pre, key, jump)) - (int)m;
+            if (act) {
+                b1[e] = key; b1[LS + e] = (uint32_t)o & 0xFF; b1[2 * LS + e] = (uint32_t)(o + a.P1) & 0xFF;
+                if (lact) atomicAdd(&Sf[ecur + (meta >> 8)], (uint32_t)o);                     // :249
+                lov = min(lov, (uint32_t)o & 0xFFu);                                           // :74 narrowed
+            } else if (e < LS) {                              // neutral entries in every other slot of the round
+                b1[e] = NG_PADKEY; b1[LS + e] = 0xFFFFu; b1[2 * LS + e] = 0xFFFFu;
+            }
         }
+        uint32_t lo;
+        if constexpr (G == 64) lo = wave_min_u32(lov); else lo = group_min_u32<G>(lov);
         m = t > 0 ? lo : 0u;
-        K4pre = K4;
+        K4pre = min((kmax + 3) & ~3, 64);
         p_cur += (uint32_t)dpix;
         __builtin_amdgcn_wave_barrier();
         uint32_t* tmp = b0; b0 = b1; b1 = tmp;
@@ -1558,7 +1583,7 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         acc += (((i & 1) == 0 ? a.H : a.W) + 3) / 4;
     }
     a.blk_begin[4] = acc;
-    a.role = NG_ROLE_ANY; a.with_compact = 0;
+    a.role = NG_ROLE_ANY; a.with_compact = 0; a.compact_force = 0; a.compact_g = 0;
     { const char* e = getenv("FSGM_NG_DEDUPE"); if (e && atoi(e) == 0) { a.dd = nullptr; a.dk = nullptr; a.dbox = nullptr; a.ck = nullptr; a.cm = nullptr; } }   // A/B switch: stage every candidate
     if (a.D <= 128 && a.unsafe) {
         const int lpb = 256 / a.D, Dp = (a.D + 3) & ~3;
@@ -1586,7 +1611,24 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
             a.blk_begin_c[4] = acc;
             a.with_compact = 1;
             a.role = NG_ROLE_COMPACT;
-            hipLaunchKernelGGL(ng_agg_compact_kernel, dim3(acc, frames), dim3(256), 0, st, a);
+            // one launch per lanes-a-line class (16 / 32 / 64 for lists up to that long); the dedupe kernel's flags pick one
+            const char* gforce = getenv("FSGM_NG_COMPACT_G");     // 16 / 32 / 64: that class only, whatever the lists look like (tests)
+            const int g_only = gforce && *gforce ? atoi(gforce) : 0;
+            a.compact_force = g_only == 16 || g_only == 32 || g_only == 64;
+            for (int G = 16; G <= 64; G *= 2) {
+                if (a.compact_force && G != g_only) continue;
+                const int lpb = 4 * (64 / G);                    // lines a workgroup
+                acc = 0;
+                for (int i = 0; i < 4; i++) {
+                    a.blk_begin_c[i] = acc;
+                    acc += (((a.slot_of_c[i] & 1) == 0 ? a.H : a.W) + lpb - 1) / lpb;
+                }
+                a.blk_begin_c[4] = acc;
+                a.compact_g = G;
+                if (G == 16)      hipLaunchKernelGGL(ng_agg_compact_kernel<16>, dim3(acc, frames), dim3(256), 0, st, a);
+                else if (G == 32) hipLaunchKernelGGL(ng_agg_compact_kernel<32>, dim3(acc, frames), dim3(256), 0, st, a);
+                else              hipLaunchKernelGGL(ng_agg_compact_kernel<64>, dim3(acc, frames), dim3(256), 0, st, a);
+            }
         }
         acc = 0;
         for (int i = 0; i < 4; i++) {

@@ -184,9 +184,14 @@ def test_calc_pyd_cost_sgm_ng_compact_kernel(gpu_lib, oracle, monkeypatch, kind,
         mv = synth.hint_map(W, H, kind, seed=17 + i, amp=amp)
         frames.append((I1, I2, mv))
         want.append(oracle.calc_pyd_cost_sgm_ng(I1, I2, mv, 1, 2, sub, P1, P2, want_volumes=True))
-    for compact in ("", "0"):
-        if compact:
-            monkeypatch.setenv("FSGM_NG_COMPACT", compact)
+    # "": the kernel's lanes-a-line class picked on the device (one line a wave for a single frame, by the mean list length for
+    # a batch); "16" / "32": that class forced, so that lists of up to 64 entries take up to four / two rounds; "0": kernel off
+    for compact in ("", "16", "32", "0"):
+        if compact == "0":
+            monkeypatch.delenv("FSGM_NG_COMPACT_G", raising=False)
+            monkeypatch.setenv("FSGM_NG_COMPACT", "0")
+        elif compact:
+            monkeypatch.setenv("FSGM_NG_COMPACT_G", compact)
         gmc, gfl, gS = calc_pyd_cost_sgm_ng(*frames[0], 1, 2, sub, P1, P2, return_sum=True)
         np.testing.assert_array_equal(gS, want[0][3], err_msg=f"compact {compact!r}")
         np.testing.assert_array_equal(gmc, want[0][0], err_msg=f"compact {compact!r}")
