@@ -1046,27 +1046,31 @@ __global__ __launch_bounds__(256 * PARTS) void ng_agg_split_kernel(NgAggArgs a) 
 // table of launch_ng_dedupe the search runs over the K groups of repeats instead of the D candidates: a group's sum sits
 // at its first member's index, every member ties with it, so the first minimum over d is the smallest (sum, first index).
 __global__ __launch_bounds__(256) void ng_wta_kernel(NgWtaArgs a) {
+    // 16 lanes a pixel, 4 pixels a wave: the kept lists are mostly shorter than 16, and D = 81 candidates take 6 rounds
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, l16 = lane & 15;
     const int NP = a.W * a.H, D = a.D;
-    const int p = blockIdx.x * 4 + wave;
-    if (p >= NP) return;
+    const int pw = (blockIdx.x * 4 + wave) * 4;
+    if (pw >= NP) return;                                     // wave-uniform
+    const bool pact = pw + sub < NP;
+    const int p = min(pw + sub, NP - 1);
     const size_t f = blockIdx.y;
     const uint32_t* Sp = a.S + f * (size_t)NP * D + (size_t)p * D;
     const uint16_t* cmp = a.cm ? a.cm + f * (size_t)NP * D + (size_t)p * D : nullptr;
     const int n = cmp ? (int)a.dk[f * (size_t)NP + p] : D;
     uint32_t lo = 0xFFFFFFFFu, idx = 0xFFFFFFFFu;
-    for (int e = lane; e < n; e += 64) {
+    for (int e = l16; e < n; e += 16) {
         const uint32_t d = cmp ? (uint32_t)(cmp[e] >> 8) : (uint32_t)e;
         const uint32_t s = Sp[d];
         if (s < lo || idx == 0xFFFFFFFFu || (s == lo && d < idx)) { lo = s; idx = d; }
     }
     uint32_t glo = lo;
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) glo = min(glo, (uint32_t)__shfl_xor((int)glo, s));
+    for (int s = 8; s >= 1; s >>= 1) glo = min(glo, (uint32_t)__shfl_xor((int)glo, s));
     uint32_t gidx = (lo == glo && idx != 0xFFFFFFFFu) ? idx : 0xFFFFFFFFu;
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) gidx = min(gidx, (uint32_t)__shfl_xor((int)gidx, s));
-    if (lane == 0) {
+    for (int s = 8; s >= 1; s >>= 1) gidx = min(gidx, (uint32_t)__shfl_xor((int)gidx, s));
+    if (l16 == 0 && pact) {
         const Cand c = a.C[f * (size_t)NP * D + (size_t)p * D + gidx];
         a.minC[f * NP + p] = glo;
         a.flow[f * 2 * (size_t)NP + p] = (double)c.mvx;
@@ -1674,7 +1678,7 @@ void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, 
 }
 
 void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames) {
-    hipLaunchKernelGGL(ng_wta_kernel, dim3((a.W * a.H + 3) / 4, frames), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ng_wta_kernel, dim3((a.W * a.H + 15) / 16, frames), dim3(256), 0, st, a);
 }
 
 void launch_ng_subpixel(hipStream_t st, const NgSubpixArgs& a, int frames) {
