@@ -827,14 +827,13 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     uint32_t* b1 = &sC[wave * LPW + sub][1][0][0];
     uint32_t m = 0;                                           // :172 / :77: stored minimum 0 at a path start
     int K4pre = 0;                                            // (wave-uniform: the longest staged list of the wave's lines)
-    for (int t0 = 0; t0 < len; t0 += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; u++) {
-        const int t = t0 + u;
-        if (t >= len) break;                                  // wave-uniform
-        uint32_t key = rkey[u], meta = rmeta[u];
-        const int K = (int)rlen[u];
-        rkey[u] = ckf[e_fet + pl]; rmeta[u] = cmf[e_fet + pl]; rlen[u] = dkf[p_fet];
+    // one step; its ring slot is named by the caller, so that the steady-state loop below is straight-line code with the
+    // slots at fixed registers: with a way out of the middle of the unrolled group the compiler rotates the ring through
+    // copies, and every copy waits for the loads just requested (and for the step's atomic add) -- vmcnt(0) per step
+    auto step = [&](const int t, uint32_t& rk, uint32_t& rm, uint32_t& rl) {
+        uint32_t key = rk, meta = rm;
+        const int K = (int)rl;
+        rk = ckf[e_fet + pl]; rm = cmf[e_fet + pl]; rl = dkf[p_fet];
         if (t + PF + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
         int kmax = K;                                         // the longest list of the wave's lines at this step (K is uniform inside a line)
         if (LPW > 1) {
@@ -866,8 +865,15 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
         p_cur += (uint32_t)dpix;
         __builtin_amdgcn_wave_barrier();
         uint32_t* tmp = b0; b0 = b1; b1 = tmp;
-      }
+    };
+    int t0 = 0;
+    for (; t0 + PF <= len; t0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) step(t0 + u, rkey[u], rmeta[u], rlen[u]);
     }
+#pragma unroll
+    for (int u = 0; u < PF - 1; u++)
+        if (t0 + u < len) step(t0 + u, rkey[u], rmeta[u], rlen[u]);            // wave-uniform
 }
 
 // S of every member of a group of repeats := S of the group's first member (for reading S back: the compact kernel
