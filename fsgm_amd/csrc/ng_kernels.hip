@@ -558,16 +558,13 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
         if (k + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
     }
     __syncthreads();
-    for (int t0 = 0; t0 < len; t0 += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; u++) {
-        const int t = t0 + u;
-        if (t >= len) break;                                  // block-uniform
-        const Cand c = ring[u];
-        const uint32_t place = rpl[u], K = rlen[u];
-        ring[u] = Cf[e_fet];
-        rpl[u] = ddf ? ddf[e_fet] : (uint32_t)cand;
-        rlen[u] = dkf ? dkf[p_fet] : (uint32_t)D;
+    // one step with its ring slot named by the caller: the steady-state loop is straight-line code (see ng_agg_compact_kernel)
+    auto step = [&](const int t, Cand& rg, uint32_t& rp, uint32_t& rl) {
+        const Cand c = rg;
+        const uint32_t place = rp, K = rl;
+        rg = Cf[e_fet];
+        rp = ddf ? ddf[e_fet] : (uint32_t)cand;
+        rl = dkf ? dkf[p_fet] : (uint32_t)D;
         if (t + PF + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
         const NgPre q{(const int32_t*)buf0, (const int32_t*)buf0 + Dp, buf0 + 2 * Dp, buf0 + 3 * Dp};
         const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
@@ -593,8 +590,15 @@ __global__ __launch_bounds__(256) void ng_agg_lines_kernel(NgAggArgs a) {
         e_cur += dent;
         __syncthreads();
         uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
-      }
+    };
+    int t0 = 0;
+    for (; t0 + PF <= len; t0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) step(t0 + u, ring[u], rpl[u], rlen[u]);
     }
+#pragma unroll
+    for (int u = 0; u < PF - 1; u++)
+        if (t0 + u < len) step(t0 + u, ring[u], rpl[u], rlen[u]);                  // block-uniform
 }
 
 // ng_agg_lines_kernel with a second form of the matcher.  What a candidate needs from the predecessor's list is the
@@ -675,17 +679,14 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
     }
     uint32_t pbox = NG_BOX_WIDE;                              // box of the previous step's pixel
     __syncthreads();
-    for (int t0 = 0; t0 < len; t0 += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; u++) {
-        const int t = t0 + u;
-        if (t >= len) break;                                  // block-uniform
-        const Cand c = ring[u];
-        const uint32_t place = rpl[u], K = rlen[u], box = rbox[u];
-        ring[u] = Cf[e_fet];
-        rpl[u] = ddf[e_fet];
-        rlen[u] = dkf[p_fet];
-        rbox[u] = dbf[p_fet];
+    // one step with its ring slot named by the caller: the steady-state loop is straight-line code (see ng_agg_compact_kernel)
+    auto step = [&](const int t, Cand& rg, uint32_t& rp, uint32_t& rl, uint32_t& rb) {
+        const Cand c = rg;
+        const uint32_t place = rp, K = rl, box = rb;
+        rg = Cf[e_fet];
+        rp = ddf[e_fet];
+        rl = dkf[p_fet];
+        rb = dbf[p_fet];
         if (t + PF + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
         const uint32_t m = t >= 2 ? smin[(t - 1) % 3] : 0u;    // :172 / :77; stored minimum 0 at a path start
         const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
@@ -744,8 +745,15 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
         __syncthreads();
         uint32_t* tmp = buf0; buf0 = buf1; buf1 = tmp;
         tmp = gpre; gpre = gcur; gcur = gnxt; gnxt = tmp;
-      }
+    };
+    int t0 = 0;
+    for (; t0 + PF <= len; t0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) step(t0 + u, ring[u], rpl[u], rlen[u], rbox[u]);
     }
+#pragma unroll
+    for (int u = 0; u < PF - 1; u++)
+        if (t0 + u < len) step(t0 + u, ring[u], rpl[u], rlen[u], rbox[u]);                  // block-uniform
 }
 
 // The same aggregation over the KEPT entries only: one wave per line, lane = place in the pixel's list without
