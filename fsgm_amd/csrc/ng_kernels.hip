@@ -1611,8 +1611,9 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         const bool split = nparts >= 2 && nparts <= 4;
         const int ord_x[4] = {0, 2, 1, 3}, ord_y[4] = {1, 3, 0, 2};
         // Which kernel runs is settled on the device from what the dedupe kernel saw (ng_agg_not_mine): every candidate
-        // is launched, the ones not favoured return at once.  FSGM_NG_COMPACT=0 / FSGM_NG_GRID=0 take a kernel out of the
-        // set, =1 makes it the only one (A/B switches; the compact kernel still steps aside for lists it cannot hold).
+        // is launched, the ones not favoured return at once.  A/B switches: FSGM_NG_COMPACT=0 / FSGM_NG_GRID=0 take a kernel out
+        // of the set, FSGM_NG_GRID=1 makes the grid kernel the only one, FSGM_NG_COMPACT_G=16|32|64 fixes the compact kernel's
+        // lanes a line (it still steps aside for lists it cannot hold).
         const char* cenv = getenv("FSGM_NG_COMPACT");
         const int compact_env = cenv && *cenv ? atoi(cenv) : -1;
         const char* genv = getenv("FSGM_NG_GRID");
