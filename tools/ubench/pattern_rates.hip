@@ -11,19 +11,21 @@
 #include <cstdint>
 constexpr int W = 1242, H = 375, D = 128;
 
-template <int NIN, bool OUT>
+template <int NIN, bool OUT, int COLS = 32>
 __global__ __launch_bounds__(256) void sweep_pat(const uint4* __restrict__ A, const uint4* __restrict__ B, uint4* __restrict__ O, int y0, int rows, uint32_t* sink) {
-    const int x = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int x0 = blockIdx.x * COLS + (threadIdx.x >> 3);
     const int j = threadIdx.x & 7;
-    if (x >= W) return;
     const size_t f = blockIdx.y, vol = (size_t)W * H * 8;      // uint4 units
     uint4 acc = make_uint4(0, 0, 0, 0);
-    for (int r = 0; r < rows; r++) {
+    for (int r = 0; r < rows; r++)
+      for (int xs = 0; xs < COLS; xs += 32) {
+        const int x = x0 + xs;
+        if (x >= W) continue;
         const size_t idx = f * vol + ((size_t)(y0 + r) * W + x) * 8 + j;
         uint4 v = A[idx];
         if (NIN > 1) { const uint4 w = B[idx]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
         if (OUT) O[idx] = v; else { acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
-    }
+      }
     if (!OUT && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) *sink = 1;
 }
 
@@ -86,6 +88,18 @@ int main() {
     printf("sweep pattern, 2 in 1 out, one stream          %7.0f  (%.3f ms)\n", 3.0 * vol / (ms * 1e-3) / 1e9, ms);
     ms = ms_of([&]() { pass(sweep_pat<2, true>, s1, 0, F / 2); pass(sweep_pat<2, true>, s2, F / 2, F / 2); (void)hipStreamSynchronize(s1); (void)hipStreamSynchronize(s2); });
     printf("sweep pattern, 2 in 1 out, two lanes of frames %7.0f  (%.3f ms)\n", 3.0 * vol / (ms * 1e-3) / 1e9, ms);
+    {
+        auto pass64 = [&](hipStream_t st, int f0, int nf) {
+            for (int y0 = 0; y0 < H; y0 += 16) {
+                const int rows = H - y0 < 16 ? H - y0 : 16;
+                hipLaunchKernelGGL((sweep_pat<2, true, 64>), dim3((W + 63) / 64, nf), dim3(256), 0, st, a + (size_t)f0 * W * H * 8, b + (size_t)f0 * W * H * 8, o + (size_t)f0 * W * H * 8, y0, rows, sink);
+            }
+        };
+        ms = ms_of([&]() { pass64(0, 0, F); });
+        printf("sweep pattern, 64-column strips, 2 in 1 out     %7.0f  (%.3f ms)\n", 3.0 * vol / (ms * 1e-3) / 1e9, ms);
+        ms = ms_of([&]() { pass64(s1, 0, F / 2); pass64(s2, F / 2, F / 2); (void)hipStreamSynchronize(s1); (void)hipStreamSynchronize(s2); });
+        printf("sweep pattern, 64-column strips, two lanes      %7.0f  (%.3f ms)\n", 3.0 * vol / (ms * 1e-3) / 1e9, ms);
+    }
     ms = ms_of([&]() { hipLaunchKernelGGL(pair_pat, dim3((H + 31) / 32, F), dim3(256), 0, 0, a, o); });
     printf("pair pattern, 1 in 1 out                       %7.0f  (%.3f ms)\n", 2.0 * vol / (ms * 1e-3) / 1e9, ms);
     ms = ms_of([&]() { hipLaunchKernelGGL(pair_pat, dim3((H + 31) / 32, F), dim3(256), 0, s1, a, o); pass(sweep_pat<2, true>, s2, 0, F); (void)hipStreamSynchronize(s1); (void)hipStreamSynchronize(s2); });
