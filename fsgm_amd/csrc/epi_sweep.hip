@@ -124,6 +124,12 @@ __device__ __forceinline__ uint4 pack_p(const uint32_t (&R)[8]) {      // values
     o.w = __builtin_amdgcn_perm(R[7], R[6], SEL_PACK);
     return o;
 }
+// 16 bytes of a volume that is streamed (read or written once per pass): FSGM_VOL_NT=1 marks the accesses non-temporal
+#ifndef FSGM_VOL_NT
+#define FSGM_VOL_NT 0
+#endif
+__device__ __forceinline__ uint4 vol_load(const void* p) { return FSGM_VOL_NT ? load_nt(p) : *(const uint4*)p; }
+__device__ __forceinline__ void vol_store(void* p, const uint4 v) { if (FSGM_VOL_NT) store_nt(p, v); else *(uint4*)p = v; }
 __device__ __forceinline__ uint4 add4(const uint4 a, const uint4 b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // per-lane constants of the step: the v_perm selectors of the two lane-crossing neighbour registers
@@ -347,8 +353,8 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
 #pragma unroll
         for (int q = 0; q < GPW; q++) {
             const uint32_t off = vox_off(min(gx0 + q * PXG, W - 1), y);
-            ringOwn[q][i] = *(const uint4*)(Cf + off);
-            if (MODE == 2) { ringX[q][i] = *(const uint4*)(Xf + off); ringH[q][i] = *(const uint4*)(Lhf + off); }
+            ringOwn[q][i] = vol_load(Cf + off);
+            if (MODE == 2) { ringX[q][i] = vol_load(Xf + off); ringH[q][i] = vol_load(Lhf + off); }
         }
         ringHalo[i] = *(const uint4*)(Cf + vox_off(hxc, y));
     }
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
             }
             if (MODE != 2) {
                 // sum of this sweep's three y, one byte per voxel (3*P2 <= 255)      :227-232
-                if (own_ok) *(uint4*)(Xf + vox_off(gx, y)) = pack_p(YS);
+                if (own_ok) vol_store(Xf + vox_off(gx, y), pack_p(YS));
             } else {
                 // S = 8*(C + P2) - (Y_up (registers) + Y_dn + Y_h), all at this pixel
                 uint32_t E2[8], ST[8];
@@ -430,10 +436,10 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
             for (int q = 0; q < GPW; q++) {
                 const uint32_t off = vox_off(min(gx0 + q * PXG, W - 1), yn);
                 cOwn[q] = ringOwn[q][i];
-                ringOwn[q][i] = *(const uint4*)(Cf + off);
+                ringOwn[q][i] = vol_load(Cf + off);
                 if (MODE == 2) {
                     cX[q] = ringX[q][i]; cH[q] = ringH[q][i];
-                    ringX[q][i] = *(const uint4*)(Xf + off); ringH[q][i] = *(const uint4*)(Lhf + off);
+                    ringX[q][i] = vol_load(Xf + off); ringH[q][i] = vol_load(Lhf + off);
                 }
             }
             ringHalo[i] = *(const uint4*)(Cf + vox_off(hxc, yn));
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
     uint32_t S[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) S[i] = P2pk;                    // the path starts at the line's last position
-    auto load_c = [&](int t) -> uint4 { return *(const uint4*)(Cl + (size_t)max(t, 0) * tstride); };
+    auto load_c = [&](int t) -> uint4 { return vol_load(Cl + (size_t)max(t, 0) * tstride); };
     uint4 ring[PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) ring[i] = load_c(len - 1 - i);
@@ -853,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
     uint32_t FS[8];                                               // forward state, carried across tiles
 #pragma unroll
     for (int i = 0; i < 8; i++) FS[i] = P2pk;                    // position 0 starts the forward path
-    auto load_c = [&](int t) -> uint4 { return *(const uint4*)(Cl + (size_t)min(t, len - 1) * tstride); };
+    auto load_c = [&](int t) -> uint4 { return vol_load(Cl + (size_t)min(t, len - 1) * tstride); };
     auto load_k = [&](int t) -> uint4 { return *(const uint4*)(Kl + (size_t)min(t, max(NT - 2, 0)) * D); };
     uint4 cT[TC], cN[TC], kT = load_k(0), kN;
 #pragma unroll
@@ -888,7 +894,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
         uint4 xo[TC];
         if (FINAL) {
 #pragma unroll
-            for (int c = 0; c < TC; c++) xo[c] = *(const uint4*)(Ol + (size_t)min(tb + c, len - 1) * tstride);
+            for (int c = 0; c < TC; c++) xo[c] = vol_load(Ol + (size_t)min(tb + c, len - 1) * tstride);
         }
         // forward path, adding the two y
 #pragma unroll
@@ -899,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
             step_s<LPP>(FS, CP, Y, P1pk, P2, sel, (EDGE && x == 0) ? 0u : 0xFFFFu);
             if (!FINAL) {
                 // both y are <= P2 per byte and 2*P2 <= 255: the packed bytes add as plain words
-                if (!EDGE || x < len) *(uint4*)(Xl + (size_t)x * tstride) = add4(pack_p(Y), exR[c]);
+                if (!EDGE || x < len) vol_store(Xl + (size_t)x * tstride, add4(pack_p(Y), exR[c]));
             } else {
                 // S = nC*(C + P2) - (this pair + the other pair) (calc_cost_sgm.cpp:227-232), WTA on the spot
                 uint32_t ST[8], E2[8], E3[8];
