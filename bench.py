@@ -420,7 +420,15 @@ def main():
             for _ in range(10):
                 epipolar_sgm_of(I1, I2, Fm, Hm, epi, direction, D, VMAX, paths=PATHS)
             driver = (time.perf_counter() - t0) / 10 * 1e3
-            out["host_call_ms"] = {"one_frame": one, "eight_frames": eight, "ms_per_frame_in_batch": eight / 8,
+            # BASELINE configs[1]: one 320x240 call with D = 64 and the shipped 4 paths (the MEX plumbing case)
+            s1, s2 = synth.image_pair(320, 240, 64, seed=4)
+            smaps = synth.epi_maps(320, 240, "general", seed=41)
+            calc_cost_sgm(s1, s2, 64, VMAX, *smaps, P1, P2, paths=4)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                calc_cost_sgm(s1, s2, 64, VMAX, *smaps, P1, P2, paths=4)
+            small = (time.perf_counter() - t0) / 20 * 1e3
+            out["host_call_ms"] = {"one_frame": one, "eight_frames": eight, "ms_per_frame_in_batch": eight / 8, "config2_320x240x64_4paths_one_frame": small,
                                    "pcie_bytes_per_frame": bytes_frame,
                                    "epipolar_driver_one_frame": driver, "epipolar_driver_pcie_bytes": 2 * W * H + 3 * 8 * W * H + 4 * W * H,
                                    "note": "fsgm_calc_cost_sgm(_batch)_host from pageable numpy buffers, whole call incl. H2D of 2 images + 5 fp64 map planes and D2H of bestD/minC; "
