@@ -1689,6 +1689,7 @@ void launch_ng_fill_repeats(hipStream_t st, uint32_t* S, const uint16_t* dd, con
 void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, uint32_t* ck, uint16_t* cm, int W, int H, int D, int frames) {
     const int n = W * H * frames;                            // frames are contiguous in all arrays
     if (kstat) (void)hipMemsetAsync(kstat, 0, NG_KSTAT_WORDS * sizeof(uint32_t), st);
+    { const char* e = getenv("FSGM_NG_GRID"); if (e && e[0] == '0') dbox = nullptr; }      // no grid kernel in the set: no boxes needed
     hipLaunchKernelGGL(ng_dedupe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, dd, dk, dbox, kstat, ck, cm, n, D);
 }
 
