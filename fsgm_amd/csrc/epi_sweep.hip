@@ -130,6 +130,14 @@ __device__ __forceinline__ uint4 pack_p(const uint32_t (&R)[8]) {      // values
 #endif
 __device__ __forceinline__ uint4 vol_load(const void* p) { return FSGM_VOL_NT ? load_nt(p) : *(const uint4*)p; }
 __device__ __forceinline__ void vol_store(void* p, const uint4 v) { if (FSGM_VOL_NT) store_nt(p, v); else *(uint4*)p = v; }
+// The pair kernels' accesses are non-temporal by default: every line of C, Y and the other pair's Y is touched once per pass by
+// one wave; measured over three runs each, 8 paths 4.67 -> 4.55 ms per 40 frames, 4 paths 3.64 -> 3.53.  (The same hint on
+// the sweeps' accesses -- FSGM_VOL_NT -- cost them 0-4 %: their halo columns are read by two workgroups.)
+#ifndef FSGM_PAIR_NT
+#define FSGM_PAIR_NT 1
+#endif
+__device__ __forceinline__ uint4 pvol_load(const void* p) { return FSGM_PAIR_NT ? load_nt(p) : *(const uint4*)p; }
+__device__ __forceinline__ void pvol_store(void* p, const uint4 v) { if (FSGM_PAIR_NT) store_nt(p, v); else *(uint4*)p = v; }
 __device__ __forceinline__ uint4 add4(const uint4 a, const uint4 b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // per-lane constants of the step: the v_perm selectors of the two lane-crossing neighbour registers
@@ -813,7 +821,7 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
     uint32_t S[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) S[i] = P2pk;                    // the path starts at the line's last position
-    auto load_c = [&](int t) -> uint4 { return vol_load(Cl + (size_t)max(t, 0) * tstride); };
+    auto load_c = [&](int t) -> uint4 { return pvol_load(Cl + (size_t)max(t, 0) * tstride); };
     uint4 ring[PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) ring[i] = load_c(len - 1 - i);
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
     uint32_t FS[8];                                               // forward state, carried across tiles
 #pragma unroll
     for (int i = 0; i < 8; i++) FS[i] = P2pk;                    // position 0 starts the forward path
-    auto load_c = [&](int t) -> uint4 { return vol_load(Cl + (size_t)min(t, len - 1) * tstride); };
+    auto load_c = [&](int t) -> uint4 { return pvol_load(Cl + (size_t)min(t, len - 1) * tstride); };
     auto load_k = [&](int t) -> uint4 { return *(const uint4*)(Kl + (size_t)min(t, max(NT - 2, 0)) * D); };
     uint4 cT[TC], cN[TC], kT = load_k(0), kN;
 #pragma unroll
@@ -894,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
         uint4 xo[TC];
         if (FINAL) {
 #pragma unroll
-            for (int c = 0; c < TC; c++) xo[c] = vol_load(Ol + (size_t)min(tb + c, len - 1) * tstride);
+            for (int c = 0; c < TC; c++) xo[c] = pvol_load(Ol + (size_t)min(tb + c, len - 1) * tstride);
         }
         // forward path, adding the two y
 #pragma unroll
@@ -905,7 +913,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
             step_s<LPP>(FS, CP, Y, P1pk, P2, sel, (EDGE && x == 0) ? 0u : 0xFFFFu);
             if (!FINAL) {
                 // both y are <= P2 per byte and 2*P2 <= 255: the packed bytes add as plain words
-                if (!EDGE || x < len) vol_store(Xl + (size_t)x * tstride, add4(pack_p(Y), exR[c]));
+                if (!EDGE || x < len) pvol_store(Xl + (size_t)x * tstride, add4(pack_p(Y), exR[c]));
             } else {
                 // S = nC*(C + P2) - (this pair + the other pair) (calc_cost_sgm.cpp:227-232), WTA on the spot
                 uint32_t ST[8], E2[8], E3[8];
