@@ -124,15 +124,16 @@ __device__ __forceinline__ uint4 pack_p(const uint32_t (&R)[8]) {      // values
     o.w = __builtin_amdgcn_perm(R[7], R[6], SEL_PACK);
     return o;
 }
-// 16 bytes of a volume that is streamed (read or written once per pass): FSGM_VOL_NT=1 marks the accesses non-temporal
+// 16 bytes of one of the sweeps' Y volumes (read or written once per pass): FSGM_VOL_NT=1 marks these accesses non-temporal
+// (measured: -0.5 to -1.3 %, inside the run-to-run spread: off; with the own columns' C loads marked as well the sweeps
+// lose up to 4 % -- the neighbouring workgroup reads the same columns as its halo)
 #ifndef FSGM_VOL_NT
 #define FSGM_VOL_NT 0
 #endif
 __device__ __forceinline__ uint4 vol_load(const void* p) { return FSGM_VOL_NT ? load_nt(p) : *(const uint4*)p; }
 __device__ __forceinline__ void vol_store(void* p, const uint4 v) { if (FSGM_VOL_NT) store_nt(p, v); else *(uint4*)p = v; }
 // The pair kernels' accesses are non-temporal by default: every line of C, Y and the other pair's Y is touched once per pass by
-// one wave; measured over three runs each, 8 paths 4.67 -> 4.55 ms per 40 frames, 4 paths 3.64 -> 3.53.  (The same hint on
-// the sweeps' accesses -- FSGM_VOL_NT -- cost them 0-4 %: their halo columns are read by two workgroups.)
+// one wave; measured over three runs each, 8 paths 4.67 -> 4.55 ms per 40 frames, 4 paths 3.64 -> 3.53.  (The sweeps: see vol_load.)
 #ifndef FSGM_PAIR_NT
 #define FSGM_PAIR_NT 1
 #endif
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
 #pragma unroll
         for (int q = 0; q < GPW; q++) {
             const uint32_t off = vox_off(min(gx0 + q * PXG, W - 1), y);
-            ringOwn[q][i] = vol_load(Cf + off);
+            ringOwn[q][i] = *(const uint4*)(Cf + off);
             if (MODE == 2) { ringX[q][i] = vol_load(Xf + off); ringH[q][i] = vol_load(Lhf + off); }
         }
         ringHalo[i] = *(const uint4*)(Cf + vox_off(hxc, y));
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
             for (int q = 0; q < GPW; q++) {
                 const uint32_t off = vox_off(min(gx0 + q * PXG, W - 1), yn);
                 cOwn[q] = ringOwn[q][i];
-                ringOwn[q][i] = vol_load(Cf + off);
+                ringOwn[q][i] = *(const uint4*)(Cf + off);
                 if (MODE == 2) {
                     cX[q] = ringX[q][i]; cH[q] = ringH[q][i];
                     ringX[q][i] = vol_load(Xf + off); ringH[q][i] = vol_load(Lhf + off);
