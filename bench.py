@@ -26,17 +26,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # (tools/pmc_traffic.sh: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950,
 # + WRITE_SIZE; separate passes).  The summary names the kernels it measured; a summary whose kernel set is not the
 # one this build launches is not used (traffic = null).
-TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-
-
 def measured_traffic(kernel_name, paths):
-    try:
-        t = json.load(open(TRAFFIC_SUMMARY))
-        if t.get("pipeline") != kernel_name or t.get("paths") != paths:
-            return None, None
-        return float(t["bytes_per_voxel"]), os.path.relpath(TRAFFIC_SUMMARY, ROOT)
-    except Exception:
-        return None, None
+    """bytes per voxel of the newest profiles/rNN_pmc_traffic*.json that measured this pipeline at this path count."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+            if t.get("pipeline") == kernel_name and t.get("paths") == paths:
+                return float(t["bytes_per_voxel"]), os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+    return None, None
 
 
 def cpu_baseline(sample_rows=48, PATHS=PATHS):
@@ -228,6 +228,8 @@ def main():
                     help="strong scaling: a fixed batch of this many frames split over the ranks by fsgm_amd.batch.shard_indices "
                          "(BASELINE config 5 literally = 8); default 0 = weak scaling with --frames-per-gpu frames on every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed loop, the self-check and the roofline block (no whole-MEX / host-call legs): for profiler runs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--paths", type=int, default=8, choices=[4, 8],
                     help="8 = the headline metric (default); 4 = the reference's shipped configuration (no diagonal "
@@ -264,6 +266,22 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+
+    # which physical devices the ranks sit on: the PCI bus ids, gathered to rank 0 (a real N-GPU run shows N distinct ids)
+    bus_id = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else -1
+    try:
+        import ctypes as _C
+        _hip = _C.CDLL("libamdhip64.so")
+        _buf = _C.create_string_buffer(64)
+        if _hip.hipDeviceGetPCIBusId(_buf, 64, local_rank) == 0:
+            bus_id = _buf.value.decode()
+    except Exception:
+        pass
+    bus_ids = [str(bus_id)]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, str(bus_id))
+        bus_ids = gathered
 
     from fsgm_amd.batch import shard_indices
     strong = args.total_frames > 0
@@ -350,7 +368,9 @@ def main():
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"KITTI 1242x375 D=128, {PATHS} paths, aggregation stage (C resident in HBM -> bestD/minC)",
                        "frames_per_gpu": B, "total_frames": total_frames, "P1": P1, "P2": P2, "kernel": plan.kernel_name,
-                       "step": f"aggregate({PATHS} paths) + sum/WTA/subpixel", "sharding": "frames, no collective"},
+                       "step": f"aggregate({PATHS} paths) + sum/WTA/subpixel", "sharding": "frames, no collective",
+                       "pci_bus_ids": bus_ids, "distinct_devices": len(set(bus_ids))},
+            "argv": " ".join(sys.argv[1:]),
             # the aggregation is one stage of four kernel types that run concurrently on three streams
             # (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane; pair_ckpt_kernel<8,0> +
             # pair_sum_kernel<8,0,false> for the horizontal pair): the roofline is taken over the stage, HIP
@@ -377,7 +397,7 @@ def main():
             out["roofline"]["memcpy_d2d_GBps_measured"] = g.value
         except Exception as e:                                # pragma: no cover
             out["roofline"]["copy_GBps_measured"] = None
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # whole-MEX rate (reported separately, not the judged value): census x2 + cost fill
             # + 5x5 box + 8-path aggregation + WTA/sub-pixel/vz for the same 32 resident frames, on the
             # survey's timing maps (Pd0 = (x+1, y+1), direction (-1, 0), offset 200) and on a direction field
@@ -392,7 +412,7 @@ def main():
                 out[key] = {"ms_per_frame": all_ms / B, "frames_per_s": B / (all_ms * 1e-3),
                             "stages": f"census x2, cost fill, box, aggregate({PATHS} paths), WTA", "inputs": "resident in HBM",
                             "maps": "SURVEY 8(d) timing maps" if kind == "axis" else "random direction per pixel"}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # the boundary as a MATLAB caller feels it: host pointers in, host pointers out (pageable memory, PCIe
             # included; never `value`), one frame per call like epipolar_sgm_of.m:45, and 8 frames per call
             from fsgm_amd import calc_cost_sgm, calc_cost_sgm_batch

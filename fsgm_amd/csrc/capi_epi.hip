@@ -52,7 +52,7 @@ struct fsgm_epi_plan {
     // for the hand-off tags, the give-up flag of the bounded waits
     uint4* dEdge = nullptr;
     uint32_t *dTicket = nullptr, *dErr = nullptr;
-    uint32_t ticket_host[3] = {0, 0, 0}, salt[3] = {0, 0, 0};
+    uint32_t salt[3] = {0, 0, 0};
     bool strips = false;                 // FSGM_EPI_STRIPS=1: the strip sweeps (one launch per sweep, no halo) instead of the block sweeps
     size_t state_stride = 0;
     hipStream_t stream_h = nullptr, stream_b = nullptr, stream_c = nullptr;
@@ -78,6 +78,7 @@ struct fsgm_epi_plan {
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 static int par_min_batch() { static const int v = env_int("FSGM_EPI_PAR_MIN", 5); return v; }
 static int par_max_batch() { static const int v = env_int("FSGM_EPI_PAR_MAX", 18); return v; }
+static int pairs_min_batch() { static const int v = env_int("FSGM_EPI_PAIRS_MIN", 9); return v; }   // 4 paths: line kernels -> pair pipeline
 
 static void select_kernel(fsgm_epi_plan* p) {
     p->epoch++;
@@ -92,7 +93,7 @@ static void select_kernel(fsgm_epi_plan* p) {
     // up; three passes along 1242-pixel rows for a pair) is 1.0 / 2.0 ms (4 / 8 paths) whatever the frame count,
     // while the line kernels scale with it.  Measured at 1242x375x128 (ms per batch, line vs fused):
     // 8 paths 8 frames 1.96 / 2.20, 12 frames 2.89 / 2.29; 4 paths 8 frames 1.18 / 1.19, 12 frames 1.67 / 1.28.
-    const int min_batch = p->prm.paths == 8 ? par_min_batch() : 9;
+    const int min_batch = p->prm.paths == 8 ? par_min_batch() : pairs_min_batch();
     const bool want = p->agg_mode == 2 || p->agg_mode == 3 || (p->agg_mode == 0 && p->batch >= min_batch);
     // (P1 <= P2: the fused kernels' form of the step clamps path states at P2 first, epi_sweep.hip)
     const bool fusable = nowrap && p->P1 <= p->P2;
@@ -252,6 +253,23 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
         return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP,
                     "fsgm_epi_plan_create: %s", hipGetErrorString(e));
     }
+    // once per device: the fused kernels' packed 3-input max / min must be exact u16 operations (epi_sweep.hip)
+    {
+        static std::mutex mu;
+        static int state[64] = {0};                          // 0 unknown, 1 good, 2 bad
+        std::lock_guard<std::mutex> lk(mu);
+        int& s = state[pr.device & 63];
+        if (s == 0) {
+            const int r = fused_step_selftest(p->stream);
+            if (r < 0) { fsgm_epi_plan_destroy(p); return fail(FSGM_ERR_HIP, "fsgm_epi_plan_create: self-test of the packed step could not run"); }
+            s = r == 0 ? 1 : 2;
+        }
+        if (s == 2) {
+            fsgm_epi_plan_destroy(p);
+            return fail(FSGM_ERR_UNSUPPORTED, "this build's v_pk_maximum3_f16 / v_pk_minimum3_f16 do not act as u16 max / min on denormal "
+                                              "patterns (toolchain or float-mode change): the fused aggregation kernels would be wrong");
+        }
+    }
     select_kernel(p);
     *out = p;
     return FSGM_OK;
@@ -298,6 +316,7 @@ fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* p, int32_t f, const uint8_t* I1,
     FSGM_HIP(hipMemcpyAsync(p->dNd + f * 2 * NP, nd, NP * 16, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(p->dOff + f * NP, off, NP * 8, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));   // pageable host memory: keep the caller's buffers free to reuse
+    guard.dismiss();
     return FSGM_OK;
 }
 
@@ -357,8 +376,13 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     const size_t B = p->batch;
     const size_t state_stride = sweep_state_bytes(p->W, p->D);
     LazySet ls;
-    uint8_t *lh, *ck = nullptr, *state, *x; uint4 *rec, *edge; uint16_t* s0; uint32_t *ticket, *err;
+    uint8_t *lh, *ck = nullptr, *state, *x; uint4 *rec, *edge = nullptr; uint16_t* s0; uint32_t *ticket = nullptr, *err = nullptr;
     hipStream_t sh, sb, sc; hipEvent_t ef, eh, eb, ec, ehl[3];
+    // Block sweeps by default: the strip sweeps execute 19 % fewer instructions and need no state buffers, but measured
+    // 5-10 % slower at 32 frames; FSGM_EPI_STRIPS=1 selects them -- only then do their hand-off buffer
+    // (7.3 MB per 1242x375x128 frame), work counters and give-up flag exist.
+    bool strips = false;
+    { const char* e = getenv("FSGM_EPI_STRIPS"); strips = e && *e && atoi(e) != 0; }
     const size_t edge_bytes = B * strip_edge_uint4s(p->W, p->H, p->D) * sizeof(uint4);
     ls.alloc(&lh, B * p->N);
     ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
@@ -366,22 +390,22 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     ls.alloc(&rec, B * p->NP * sizeof(uint4));
     ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
     ls.alloc(&x, B * p->N);
-    ls.alloc(&edge, edge_bytes);
-    ls.alloc(&ticket, 4 * sizeof(uint32_t));
-    ls.alloc(&err, sizeof(uint32_t));
+    if (strips) {
+        ls.alloc(&edge, edge_bytes);
+        ls.alloc(&ticket, 4 * sizeof(uint32_t));
+        ls.alloc(&err, sizeof(uint32_t));
+    }
     ls.stream(&sh); ls.stream(&sb); ls.stream(&sc);
     ls.event(&ef); ls.event(&eh); ls.event(&eb); ls.event(&ec);
     for (int l = 0; l < 3; l++) ls.event(&ehl[l]);
     // hand-off dwords carry a launch tag in their bytes' top bits: all ones = "older than any launch"
-    if (ls.err == hipSuccess) ls.err = hipMemsetAsync(edge, 0xFF, edge_bytes, p->stream);
-    if (ls.err == hipSuccess) ls.err = hipMemsetAsync(ticket, 0, 4 * sizeof(uint32_t), p->stream);
-    if (ls.err == hipSuccess) ls.err = hipMemsetAsync(err, 0, sizeof(uint32_t), p->stream);
+    if (strips && ls.err == hipSuccess) ls.err = hipMemsetAsync(edge, 0xFF, edge_bytes, p->stream);
+    if (strips && ls.err == hipSuccess) ls.err = hipMemsetAsync(ticket, 0, 4 * sizeof(uint32_t), p->stream);
+    if (strips && ls.err == hipSuccess) ls.err = hipMemsetAsync(err, 0, sizeof(uint32_t), p->stream);
     if (ls.err != hipSuccess) return lazy_fail(ls, "sweep pipeline buffers");
     p->dEdge = edge; p->dTicket = ticket; p->dErr = err;
-    for (int l = 0; l < 3; l++) { p->ticket_host[l] = 0; p->salt[l] = 0; }
-    // Block sweeps by default: the strip sweeps execute 19 % fewer instructions and need no state buffers, but measured
-    // 5-10 % slower at 32 frames; FSGM_EPI_STRIPS=1 selects them.
-    { const char* e = getenv("FSGM_EPI_STRIPS"); p->strips = e && *e && atoi(e) != 0; }
+    for (int l = 0; l < 3; l++) p->salt[l] = 0;
+    p->strips = strips;
     p->state_stride = state_stride;
     p->dLh = lh; p->dCkpt = ck; p->dState = state; p->dRec = rec; p->dS0 = s0; p->dX = x;
     p->stream_h = sh; p->stream_b = sb; p->stream_c = sc;
@@ -510,16 +534,20 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
                 sa.edge = p->dEdge + (size_t)f0 * strip_edge_uint4s(p->W, p->H, p->D);
                 sa.ticket = p->dTicket + lane; sa.err = p->dErr;
                 sa.W = p->W; sa.H = p->H; sa.D = p->D; sa.P1 = p->P1; sa.P2 = p->P2; sa.frames = nf;
-                auto next_launch = [&]() {                            // bookkeeping of one launch of this lane
-                    sa.ticket_base = p->ticket_host[lane];
-                    p->ticket_host[lane] += (uint32_t)(sa.NS * nf);
+                // the work counter restarts at 0 on the lane's own stream ahead of every launch (no host mirror that a
+                // failed launch could leave out of step with the device); the hand-off tag only has to differ from the
+                // previous launches' of this lane
+                sa.ticket_base = 0;
+                auto next_tag = [&]() {
                     const uint32_t t = p->salt[lane]++ & 15u;
                     sa.tag = ((t & 1u) << 7) | ((t & 2u) << 14) | ((t & 4u) << 21) | ((t & 8u) << 28);
                 };
-                next_launch();
+                next_tag();
+                FSGM_HIP(hipMemsetAsync(sa.ticket, 0, sizeof(uint32_t), st));
                 launch_strips(st, sa, 0);                            // pass-0 paths from above -> Y_dn
                 FSGM_HIP(hipStreamWaitEvent(st, p->ev_hl[lane], 0));
-                next_launch();
+                next_tag();
+                FSGM_HIP(hipMemsetAsync(sa.ticket, 0, sizeof(uint32_t), st));
                 launch_strips(st, sa, 2);                            // pass-1 paths + everything else + WTA
             } else {
                 launch_sweep(st, w, nf, 0);                          // pass-0 paths from above -> Y_dn
@@ -650,7 +678,7 @@ fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* p, int32_t mode) {
 
 // the strip sweeps' bounded hand-off waits raise a device flag instead of hanging: surface it after a sync
 static fsgm_status check_handoff(fsgm_epi_plan* p) {
-    if (!p->dErr) return FSGM_OK;
+    if (!p->strips || !p->dErr) return FSGM_OK;                  // only the strip sweeps wait inside a kernel
     uint32_t e = 0;
     FSGM_HIP(hipMemcpy(&e, p->dErr, sizeof(e), hipMemcpyDeviceToHost));
     if (e == 0) return FSGM_OK;
@@ -1026,6 +1054,7 @@ fsgm_status fsgm_epipolar_maps_host(const fsgm_epi_geometry* g, int32_t W, int32
     FSGM_HIP(hipMemcpyAsync(Offset, p->dOff, p->NP * 8, hipMemcpyDeviceToHost, p->stream));
     FSGM_HIP(hipMemcpyAsync(Rflow, p->dRflow, p->NP * 16, hipMemcpyDeviceToHost, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 
@@ -1062,6 +1091,7 @@ fsgm_status fsgm_epipolar_sgm_of_host(const uint8_t* I0, const uint8_t* I1, int3
     FSGM_HIP(hipMemcpyAsync(flow, p->dFlow, NP * 24, hipMemcpyDeviceToHost, p->stream));
     if (minC) FSGM_HIP(hipMemcpyAsync(minC, p->dMinC, NP * 4, hipMemcpyDeviceToHost, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 

@@ -20,6 +20,7 @@ struct NgPool {
     int device = -1;
     char* base = nullptr;
     size_t cap = 0;
+    int small_calls = 0;               // consecutive calls that used at most a quarter of the arena
     hipStream_t stream = nullptr;
 };
 NgPool g_pool;
@@ -37,7 +38,11 @@ struct DevBufs {                       // the arena for the duration of one call
         size_t total = 0;
         for (auto& r : req) total += r.second;
         hipError_t e = hipSuccess;
-        if (g_pool.device != device || g_pool.cap < total) {
+        // the arena grows to the largest call and shrinks again once eight calls in a row used at most a quarter of it
+        // (a session that moved on to smaller frames does not hold the large frames' memory until fsgm_shutdown)
+        g_pool.small_calls = (g_pool.cap >= (1u << 24) && total <= g_pool.cap / 4) ? g_pool.small_calls + 1 : 0;
+        if (g_pool.device != device || g_pool.cap < total || g_pool.small_calls >= 8) {
+            g_pool.small_calls = 0;
             if (g_pool.base) { (void)hipSetDevice(g_pool.device); (void)hipFree(g_pool.base); (void)hipSetDevice(device); }
             if (g_pool.stream && g_pool.device != device) { (void)hipStreamDestroy(g_pool.stream); g_pool.stream = nullptr; }
             g_pool.base = nullptr; g_pool.cap = 0; g_pool.device = device;

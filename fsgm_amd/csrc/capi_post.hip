@@ -74,6 +74,7 @@ fsgm_status fsgm_post_plan_upload(fsgm_post_plan* p, const double* D1, const dou
     if (normDirect) FSGM_HIP(hipMemcpyAsync(p->dNd, normDirect, p->NP * 16, hipMemcpyHostToDevice, p->stream));
     if (O) FSGM_HIP(hipMemcpyAsync(p->dO, O, p->NP * 8, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 
@@ -169,6 +170,7 @@ fsgm_status fsgm_speckle_filter_host(const double* image, int32_t W, int32_t H, 
     FSGM_HIP(hipMemcpyAsync(imageFiltered, p->dOut, p->NP * 8, hipMemcpyDeviceToHost, p->stream));
     if (labelImage) FSGM_HIP(hipMemcpyAsync(labelImage, p->dLabels, p->NP * 4, hipMemcpyDeviceToHost, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 
@@ -187,6 +189,7 @@ fsgm_status fsgm_calc_disp_from_first_host(const double* D1, int32_t W, int32_t 
     StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(D2, p->dD2, p->NP * 8, hipMemcpyDeviceToHost, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 
@@ -205,6 +208,7 @@ fsgm_status fsgm_forward_backward_check_host(const double* D1, const double* D2,
     FSGM_HIP(hipGetLastError());
     FSGM_HIP(hipMemcpyAsync(D1checked, p->dOut, p->NP * 8, hipMemcpyDeviceToHost, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 
@@ -220,6 +224,7 @@ fsgm_status fsgm_scanline_in_fill_host(const double* input, int32_t W, int32_t H
     FSGM_HIP(hipGetLastError());
     FSGM_HIP(hipMemcpyAsync(output, p->dOut, p->NP * 8, hipMemcpyDeviceToHost, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 
@@ -236,6 +241,7 @@ fsgm_status fsgm_vzind2disp_host(const double* w, const double* O, int32_t W, in
     FSGM_HIP(hipGetLastError());
     FSGM_HIP(hipMemcpyAsync(D, p->dDisp, p->NP * 8, hipMemcpyDeviceToHost, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 

@@ -93,6 +93,7 @@ fsgm_status fsgm_pyd_plan_upload(fsgm_pyd_plan* p, int32_t f, const uint8_t* I1,
     FSGM_HIP(hipMemcpyAsync(p->dI2 + f * p->NP, I2, p->NP, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(p->dMv + f * 2 * p->MV, mv, p->MV * 16, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 
@@ -115,6 +116,7 @@ fsgm_status fsgm_pyd_plan_upload_cost(fsgm_pyd_plan* p, int32_t f, const uint8_t
     StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(p->dC + f * p->N, src, p->N, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 

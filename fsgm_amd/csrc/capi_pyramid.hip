@@ -123,6 +123,7 @@ fsgm_status fsgm_pyramid_plan_upload(fsgm_pyramid_plan* p, const uint8_t* I0, co
     FSGM_HIP(hipMemcpyAsync(d0, I0, n, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(d1, I1, n, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 

@@ -147,6 +147,7 @@ void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, con
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);
 void launch_fb_check(hipStream_t st, const FbArgs& a, int frames);
 void launch_vz_convert(hipStream_t st, uint32_t* bestD, const double* off, int W, int H, int D, double vMax, int frames);
+int  fused_step_selftest(hipStream_t st);   // 0: pk_max3 / pk_min3 of the fused step are exact u16 operations here
 void launch_copy16(hipStream_t st, void* dst, const void* src, size_t bytes);   // bytes % 4096 == 0; bandwidth probe
 void launch_sum_paths(hipStream_t st, const uint8_t* L, uint32_t* S, size_t n, size_t dir_stride, int ndirs);
 

@@ -1107,6 +1107,45 @@ __global__ __launch_bounds__(256) void pairx_sum_kernel(PairArgs a) {
     }
 }
 
+// =============================================================================================
+// Self-test of the step's 3-input maximum / minimum (pk_max3 / pk_min3): they are exact u16 operations only because
+// (a) hipcc fuses the nested 2-input builtins into v_pk_maximum3_f16 / v_pk_minimum3_f16 -- or emits anything else
+// that keeps denormal inputs -- and (b) the kernel's float mode does not flush fp16 denormals.  A toolchain or flag
+// change that breaks either would give silently wrong path costs; one wave checks 64 x 32 triples of values below
+// 1024 in both halves (every value the step produces) against integer max / min when the first plan of a device is made.
+// =============================================================================================
+__global__ void pk3_selftest_kernel(uint32_t* bad) {
+    uint32_t x = 0x9E3779B9u * (threadIdx.x + 1u), nbad = 0;
+    for (int it = 0; it < 32; it++) {
+        uint32_t v[3];
+        for (int k = 0; k < 3; k++) {
+            x = x * 1664525u + 1013904223u;
+            const uint32_t lo = (x >> 7) & 1023u, hi = (x >> 19) & 1023u;
+            // the corner values in the first rounds: 0, 1, the largest denormal
+            v[k] = it == 0 ? (k == 0 ? 0u : k == 1 ? 0x00010001u : 0x03FF03FFu) : (lo | (hi << 16));
+        }
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));      // not foldable at compile time
+        const uint32_t mx = pk_max3(v[0], v[1], v[2]), mn = pk_min3(v[0], v[1], v[2]);
+        const uint32_t rmx = max(max(v[0] & 0xFFFFu, v[1] & 0xFFFFu), v[2] & 0xFFFFu) | (max(max(v[0] >> 16, v[1] >> 16), v[2] >> 16) << 16);
+        const uint32_t rmn = min(min(v[0] & 0xFFFFu, v[1] & 0xFFFFu), v[2] & 0xFFFFu) | (min(min(v[0] >> 16, v[1] >> 16), v[2] >> 16) << 16);
+        nbad += (mx != rmx) + (mn != rmn);
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+// 0 = the fused step's packed 3-input operations are exact on this device / build; > 0 = mismatches; < 0 = HIP error
+int fused_step_selftest(hipStream_t st) {
+    uint32_t* d = nullptr;
+    uint32_t h = 0;
+    if (hipMalloc((void**)&d, sizeof(uint32_t)) != hipSuccess) return -1;
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(uint32_t), st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(pk3_selftest_kernel, dim3(1), dim3(64), 0, st, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    return e == hipSuccess ? (int)h : -1;
+}
+
 size_t pair_ckpt_bytes(int W, int H, int D, int axis) {
     const int len = axis ? H : W, nl = axis ? W : H;
     const int NT = (len + HP_TC - 1) / HP_TC;

@@ -141,7 +141,9 @@ fsgm_status fsgm_epi_plan_time(fsgm_epi_plan* plan, int32_t stages, int32_t warm
                                int32_t iters, float* ms_avg);
 /* the hipStream_t the plan launches on */
 void*       fsgm_epi_plan_stream(fsgm_epi_plan* plan);
-/* which aggregation kernel the plan selected: "sweep16/nowrap", "pairs16/nowrap", "packed16/nowrap", "packed16/wrap", "generic" */
+/* which aggregation kernel the plan selected: "sweep16/nowrap" (8 paths, full sweep pipeline), "sweep16par/nowrap" (8 paths,
+ * parallel sweeps: auto mode for 5..17 frames), "pairs16/nowrap" (4 paths, pair pipeline), "packed16/nowrap", "packed16/wrap"
+ * (per-direction line kernels), "generic" (any dMax).  New names may be added: dispatch on these with a default branch. */
 const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* plan);
 /* device-to-device copy bandwidth probe (GB/s, read+written bytes counted) used by bench.py: the library's own
  * grid-stride copy kernel, 16 B per lane per access -- the access width of the aggregation kernels */

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from fsgm_amd import synth, EpiPlan, calc_cost_sgm, calc_cost_sgm_batch, calc_pyd_cost_sgm_ng, census
+from fsgm_amd import synth, EpiPlan, calc_cost_sgm, calc_cost_sgm_batch, calc_pyd_cost_sgm, calc_pyd_cost_sgm_ng, census
 from fsgm_amd._lib import STAGE_COST
 
 pytestmark = pytest.mark.gpu
@@ -194,3 +194,67 @@ def test_cost_bound_reset_before_a_fused_run(gpu_lib, oracle):
             gbd, gmc = plan.download(f)
             np.testing.assert_array_equal(gmc, mc)
             np.testing.assert_array_equal(gbd, bd)
+
+
+# ------------------------------------------------------------------------------------------- config 4, full-window matcher
+@pytest.mark.parametrize("W,H", [(1242, 375), (621, 188)])
+def test_full_window_pyd_at_the_pyramid_level_sizes(gpu_lib, oracle, monkeypatch, W, H):
+    """SURVEY 8(d) reads config 4 as calc_pyd_cost_sgm at 1242x375 / 621x188 / 311x94 with pyramidal_sgm.m:50's arguments
+    (11x11 window, aggregation radius 2, 8 paths, 2 passes, P1=6, P2=32).  The two upper sizes against the oracle
+    (calc_pyd_cost_sgm.cpp:114-372, :374-437), all voxels of C and S, bestD, minC, mvSub; integer and fractional hints;
+    the aggregation kernel's mapping as the library picks it and both forced forms (the wide-rows mapping is chosen by
+    frame shape, 1242-step lines, padded 132-byte pixels).  ~25 s of oracle per 1242x375 call."""
+    I1, I2 = synth.image_pair(W, H, 16, seed=W)
+    for kind, sub in (("int", 1), ("general", 1)):
+        mv = synth.hint_map(W + 1, H + 2, kind, seed=H + len(kind))
+        bd, mc, ms, Cv, S = oracle.calc_pyd_cost_sgm(I1, I2, mv, 5, 5, 2, sub, 6, 32, 1, 2, 0, want_volumes=True)
+        for wide in (None, "0", "2"):
+            if wide is None:
+                monkeypatch.delenv("FSGM_PYD_WIDE", raising=False)
+            else:
+                monkeypatch.setenv("FSGM_PYD_WIDE", wide)
+            gbd, gmc, gms, gC, gS = calc_pyd_cost_sgm(I1, I2, mv, 5, 5, 2, sub, 6, 32, 1, 2, 0, return_volumes=True)
+            tag = f"hints {kind}, FSGM_PYD_WIDE={wide}"
+            np.testing.assert_array_equal(gC, Cv, err_msg=tag)
+            np.testing.assert_array_equal(gS, S, err_msg=tag)
+            np.testing.assert_array_equal(gbd, bd, err_msg=tag)
+            np.testing.assert_array_equal(gmc, mc, err_msg=tag)
+            np.testing.assert_array_equal(gms, ms, err_msg=tag)
+            del gC, gS
+        del Cv, S
+
+
+# ------------------------------------------------------------------------------------------- config 3 as shipped (4 paths)
+def test_calc_cost_sgm_kitti_shape_4_paths_as_shipped(gpu_lib, oracle):
+    """The configuration epipolar_sgm_of.m:45 actually runs: enableDiagnalPath = false (calc_cost_sgm.cpp:104), at
+    1242x375x128.  One host call (the line kernels) with C and S, and a batch of 9 resident pairs (the pair pipeline)
+    -- C, S, bestD, minC of every voxel / pixel against the oracle."""
+    W, H, D = 1242, 375, 128
+    I1, I2 = synth.image_pair(W, H, D, seed=77)
+    pd0, nd, off = synth.epi_maps(W, H, "general", seed=78)
+    bd, mc, Cv, S = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, 4, want_volumes=True)
+    gbd, gmc, gC, gS = calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, paths=4, return_volumes=True)
+    np.testing.assert_array_equal(gC, Cv)
+    np.testing.assert_array_equal(gS, S)
+    np.testing.assert_array_equal(gmc, mc)
+    np.testing.assert_array_equal(gbd, bd)
+    del gC, gS
+    B = 9
+    I1b, I2b = synth.image_pair(W, H, D, seed=79)
+    pd0b, ndb, offb = synth.epi_maps(W, H, "axis", seed=80)
+    bdb, mcb = oracle.calc_cost_sgm(I1b, I2b, D, 0.3, pd0b, ndb, offb, 6, 64, 4)
+    with EpiPlan(W, H, D, B, paths=4) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        for f in range(B):
+            if f in (0, B - 1):
+                plan.upload(f, I1, I2, pd0, nd, off)
+            else:
+                plan.upload(f, I1b, I2b, pd0b, ndb, offb)
+        plan.run()
+        assert plan.kernel_name == "pairs16/nowrap"
+        for f in range(B):
+            pbd, pmc = plan.download(f)
+            wbd, wmc = (bd, mc) if f in (0, B - 1) else (bdb, mcb)
+            np.testing.assert_array_equal(pmc, wmc, err_msg=f"frame {f} minC, pair pipeline")
+            np.testing.assert_array_equal(pbd, wbd, err_msg=f"frame {f} bestD, pair pipeline")
+        np.testing.assert_array_equal(plan.download_sum(0), S, err_msg="S rebuilt from the pair pipeline's volumes")

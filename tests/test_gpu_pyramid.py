@@ -97,7 +97,9 @@ def test_pyramid_plan_gray_pyramid_and_reuse(gpu_lib, oracle):
 
 
 def test_pyramidal_sgm_kitti_shape_level_sizes(gpu_lib, oracle):
-    """BASELINE config 4 shape: 1242x375, 3 levels -> 621x188, 311x94 (ceil(size/2), test_psgm.m:33)."""
+    """BASELINE config 4 shape: 1242x375, 3 levels -> 621x188, 311x94 (ceil(size/2), test_psgm.m:33); every level's
+    flow and the finest level's minC against the oracle's pyramidal_sgm (pyramidal_sgm.m:24-76 around
+    calc_pyd_cost_sgm.cpp:114-372), all pixels -- levels 1 and 2 included (~35 s of oracle)."""
     with PyramidPlan(1242, 375, 3, 3) as plan:
         assert [plan.level_size(l) for l in (1, 2, 3)] == [(1242, 375), (621, 188), (311, 94)]
         I0, I1 = _pair(1242, 375, 3, seed=1)
@@ -105,7 +107,7 @@ def test_pyramidal_sgm_kitti_shape_level_sizes(gpu_lib, oracle):
         plan.run()
         mv, minC = plan.download(1)
         assert mv.shape == (2, 375, 1242) and np.isfinite(mv).all()
-        # coarse levels are cheap enough for the oracle: compare the level-3 flow (311x94) exactly
+        # the coarsest level on its own, from the oracle's pieces
         c0, c1 = I0, I1
         for _ in range(2):
             c0 = np.stack([oracle.impyramid_reduce(c) for c in c0])
@@ -116,6 +118,14 @@ def test_pyramidal_sgm_kitti_shape_level_sizes(gpu_lib, oracle):
         np.testing.assert_array_equal(mc3, mc)
         np.testing.assert_array_equal(lv3[0], (bd // 11).astype(np.float64) - 5)
         np.testing.assert_array_equal(lv3[1], (bd % 11).astype(np.float64) - 5)
+        # the whole loop: levels 3, 2 and 1 exactly
+        want_mv, want_minC, want_lv = oracle.pyramidal_sgm(I0, I1, 3)
+        for l in (3, 2, 1):
+            got, _ = plan.download(l)
+            np.testing.assert_array_equal(got, want_lv[l - 1], err_msg=f"level {l} flow")
+        np.testing.assert_array_equal(minC, want_minC)
+        np.testing.assert_array_equal(mv, want_mv)
+        assert np.abs(mv).max() > 2                             # the hints did travel down the pyramid
 
 
 @pytest.mark.parametrize("W,H,ch,numPyd,sub", [(61, 45, 3, 3, 0), (48, 37, 1, 2, 1), (5, 4, 1, 2, 0), (33, 21, 1, 1, 1), (2, 3, 3, 3, 0)])

@@ -1,50 +1,87 @@
-# SQ counters of the headline bench's kernels (rocprofv3 --pmc, two passes of 8 SQ counters; the program directly
-# after `--`).  Under counter collection the dispatches are serialised, so the numbers are per kernel in isolation.
+# SQ counters of the library's kernels (rocprofv3 --pmc, two passes of 8 SQ counters each; the program directly after
+# `--`).  Under counter collection the dispatches are serialised, so the numbers are per kernel in isolation.
 # Run on the GPU box through gpurun; summary -> gpurun_out/sq_counters.md (copy to profiles/rNN_sq_counters.md).
+#
+# Legs (each a command profiled twice): the calibration kernels of tools/ubench/counter_calib.hip (known behaviour: what
+# the counters read for a saturated SIMD, for conflict-free b128 LDS traffic, for a 32-way conflict), then the benches
+# named in LEGS (default: headline 8 paths, 4 paths, 8-frame batch, pyramid3, pyramid3_ng).
+#
+# Normalisation: rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs (MI355X_MICROARCH.md, "DVFS give-back"), so the cycles
+# a kernel ran are GRBM_GUI_ACTIVE / 8 and the SIMD-cycles available to it GRBM_GUI_ACTIVE / 8 * 1024.  SQ_ACTIVE_INST_*
+# count quad-cycles: "VALU busy" = SQ_ACTIVE_INST_VALU * 4 / (GRBM_GUI_ACTIVE / 8 * 1024).  Round 2's table divided by
+# GRBM_GUI_ACTIVE * 1024 and so read 8x too low; the calibration rows are the sanity check (calib_valu_pk must read
+# what a saturated SIMD reads).
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-ARGS="${BENCH_ARGS:---steps 2 --warmup 1 --no-cpu-baseline}"
-rm -rf gpurun_out/pmc_sq1 gpurun_out/pmc_sq2
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_sq1 -- python3 bench.py $ARGS > gpurun_out/pmc_sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc_sq2 -- python3 bench.py $ARGS > gpurun_out/pmc_sq2.log 2>&1
+[ -x tools/ubench/counter_calib ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-value -o tools/ubench/counter_calib tools/ubench/counter_calib.hip
+C1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
+C2="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS"
+rm -rf gpurun_out/pmc_sq
+mkdir -p gpurun_out/pmc_sq
+rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d gpurun_out/pmc_sq/calib_1 -- tools/ubench/counter_calib > gpurun_out/pmc_sq/calib_1.log 2>&1
+rocprofv3 --kernel-trace --pmc $C2 --output-format csv -d gpurun_out/pmc_sq/calib_2 -- tools/ubench/counter_calib > gpurun_out/pmc_sq/calib_2.log 2>&1
+echo "calibration leg done"
+LEGS="${LEGS:-default paths4 batch8 pyramid3 pyramid3_ng}"
+for leg in $LEGS; do
+    case $leg in
+        default)     A="--steps 2 --warmup 1 --no-cpu-baseline" ;;
+        paths4)      A="--steps 2 --warmup 1 --no-cpu-baseline --paths 4" ;;
+        batch8)      A="--steps 2 --warmup 1 --no-cpu-baseline --frames-per-gpu 8" ;;
+        batch1)      A="--steps 2 --warmup 1 --no-cpu-baseline --frames-per-gpu 1" ;;
+        pyramid3)    A="--steps 4 --workload pyramid3" ;;
+        pyramid3_ng) A="--steps 4 --workload pyramid3_ng" ;;
+        *)           A="$leg" ;;
+    esac
+    rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d gpurun_out/pmc_sq/${leg}_1 -- python3 bench.py $A > gpurun_out/pmc_sq/${leg}_1.log 2>&1
+    rocprofv3 --kernel-trace --pmc $C2 --output-format csv -d gpurun_out/pmc_sq/${leg}_2 -- python3 bench.py $A > gpurun_out/pmc_sq/${leg}_2.log 2>&1
+    echo "leg $leg done"
+done
 python3 - <<'PY' | tee gpurun_out/sq_counters.md
-import csv, glob, collections
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(lambda: collections.Counter())
-dur = collections.defaultdict(list)
-for d in ("pmc_sq1", "pmc_sq2"):
-    for f in glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
-            acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
-    for f in glob.glob(f"gpurun_out/{d}/**/*kernel_trace.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
-            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+import csv, glob, collections, os
+legs = sorted({os.path.basename(d)[:-2] for d in glob.glob("gpurun_out/pmc_sq/*_1")}, key=lambda s: (s != "calib", s))
 names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
          "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS",
          "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_WAIT_INST_LDS"]
-print("per dispatch averages (serialised dispatches); cycles of SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles summed over waves\n")
-print("| kernel | n | avg us | " + " | ".join(names) + " |")
-print("|---|---|---|" + "---|" * len(names))
-for k in sorted(acc):
-    if not any(s in k for s in ("sweep", "strip", "pair", "agg_", "wta", "fwd", "bwd", "copy16")): continue
-    n = max(cnt[k].values())
-    row = [f"{acc[k][c] / max(cnt[k][c], 1):.4g}" if cnt[k][c] else "-" for c in names]
-    d = dur[k]
-    print(f"| {k} | {n} | {sum(d) / max(len(d), 1):.1f} | " + " | ".join(row) + " |")
-print("\nderived (per kernel): VALU instructions per wave; share of wave time with an instruction active / parked in s_waitcnt or barrier / issue-stalled;")
-print("VALU issue cycles per SIMD-cycle while the kernel ran = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE * 1024 SIMDs)\n")
-print("| kernel | VALU inst/wave | active% | wait_any% | wait_inst% | VALU busy of SIMD time | LDS conflict cycles / LDS active |")
-print("|---|---|---|---|---|---|---|")
-for k in sorted(acc):
-    a = acc[k]
-    if not a.get("SQ_WAVES") or not any(s in k for s in ("sweep", "strip", "pair", "agg_", "wta", "fwd", "bwd")): continue
-    wc = a["SQ_WAVE_CYCLES"] or 1
-    gui = a.get("GRBM_GUI_ACTIVE", 0)
-    print(f"| {k} | {a['SQ_INSTS_VALU'] / a['SQ_WAVES']:.0f} | {100 * a['SQ_ACTIVE_INST_ANY'] / wc:.1f} | {100 * a['SQ_WAIT_ANY'] / wc:.1f} | "
-          f"{100 * a['SQ_WAIT_INST_ANY'] / wc:.1f} | {(a['SQ_ACTIVE_INST_VALU'] * 4 / (gui * 1024)) if gui else float('nan'):.3f} | "
-          f"{a.get('SQ_LDS_BANK_CONFLICT', 0) / max(a.get('SQ_LDS_IDX_ACTIVE', 0), 1):.3f} |")
+keep = ("calib_", "sweep", "strip", "band", "pair", "agg_", "wta", "copy16", "rawcost", "box5x5", "census", "pyd_rows", "pyd_", "ng_", "finish")
+print("per dispatch averages (dispatches serialised by the counter collection).  SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles")
+print("summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs (cycles the kernel ran = GRBM_GUI_ACTIVE / 8).\n")
+for leg in legs:
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.Counter())
+    dur = collections.defaultdict(list)
+    for d in (f"{leg}_1", f"{leg}_2"):
+        for f in glob.glob(f"gpurun_out/pmc_sq/{d}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("fsgm::", "")[:64]
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+        for f in glob.glob(f"gpurun_out/pmc_sq/{d}/**/*kernel_trace.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("fsgm::", "")[:64]
+                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    ks = [k for k in sorted(acc) if any(s in k for s in keep) and acc[k].get("SQ_WAVES")]
+    if not ks:
+        continue
+    print(f"## leg `{leg}`\n")
+    print("| kernel | n | avg us | clock GHz | VALU inst/wave | active% | wait_any% (s_waitcnt/barrier) | wait_inst% (issue stall) | VALU busy of SIMD time | LDS busy of CU time | LDS conflict / LDS active | VMEM rd+wr inst/wave |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for k in ks:
+        a = {c: acc[k][c] / max(cnt[k][c], 1) for c in names}      # per dispatch
+        n = max(cnt[k].values())
+        us = sum(dur[k]) / max(len(dur[k]), 1)
+        wc = a["SQ_WAVE_CYCLES"] or 1
+        cyc = a["GRBM_GUI_ACTIVE"] / 8.0                              # cycles the kernel ran (per XCD)
+        ghz = cyc / (us * 1e3) if us else float("nan")
+        valu_busy = a["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * 1024) if cyc else float("nan")
+        lds_busy = a["SQ_LDS_IDX_ACTIVE"] / (cyc * 256) if cyc else float("nan")   # LDS-array cycles per CU-cycle
+        print(f"| {k} | {n} | {us:.1f} | {ghz:.2f} | {a['SQ_INSTS_VALU'] / a['SQ_WAVES']:.0f} | {100 * a['SQ_ACTIVE_INST_ANY'] / wc:.1f} | "
+              f"{100 * a['SQ_WAIT_ANY'] / wc:.1f} | {100 * a['SQ_WAIT_INST_ANY'] / wc:.1f} | {valu_busy:.3f} | {lds_busy:.3f} | "
+              f"{a['SQ_LDS_BANK_CONFLICT'] / max(a['SQ_LDS_IDX_ACTIVE'], 1):.3f} | {(a['SQ_INSTS_VMEM_RD'] + a['SQ_INSTS_VMEM_WR']) / a['SQ_WAVES']:.0f} |")
+    print("\nraw per-dispatch averages:\n")
+    print("| kernel | " + " | ".join(names) + " |")
+    print("|---|" + "---|" * len(names))
+    for k in ks:
+        print(f"| {k} | " + " | ".join(f"{acc[k][c] / max(cnt[k][c], 1):.4g}" if cnt[k][c] else "-" for c in names) + " |")
+    print()
 PY
-rm -rf gpurun_out/pmc_sq1 gpurun_out/pmc_sq2
+rm -rf gpurun_out/pmc_sq/*_1 gpurun_out/pmc_sq/*_2
