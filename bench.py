@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--total-frames", type=int, default=0,
                     help="strong scaling: a fixed batch of this many frames split over the ranks by fsgm_amd.batch.shard_indices "
                          "(BASELINE config 5 literally = 8); default 0 = weak scaling with --frames-per-gpu frames on every GPU")
+    ap.add_argument("--agg-mode", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="force an aggregation pipeline (fsgm_epi_plan_set_agg_mode): 0 auto (default), 1 line kernels, 2 fused sweeps / pairs, "
+                         "3 parallel sweeps, 4 band sweeps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed loop, the self-check and the roofline block (no whole-MEX / host-call legs): for profiler runs")
@@ -298,9 +301,15 @@ def main():
     def frame_volume(f):
         return bases[f] if f < 4 else np.ascontiguousarray(np.roll(bases[f % 4], 37 * (f // 4), axis=1))
 
+    if args.agg_mode:
+        plan.set_agg_mode(args.agg_mode)
     for f in range(B):
-        plan.upload_cost(f, frame_volume(f))
+        if f < 4:
+            plan.upload_cost(f, frame_volume(f))
+        else:
+            plan.copy_cost(f, f % 4, 37 * (f // 4))         # the same rotation, device to device (no PCIe transfer per frame)
         plan.upload_offset(f, off)
+    plan.sync()
     check_frames = sorted({0, B - 1})
     check_vols = [frame_volume(f) for f in check_frames]
     del bases
@@ -357,6 +366,7 @@ def main():
             "sweep16/nowrap": ("sweep_kernel<8,0> + sweep_kernel<8,2> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>", False),
             "sweep16par/nowrap": ("sweep_kernel<8,0> + sweep_kernel<8,1> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + wta_sweep_kernel<8>", True),
             "pairs16/nowrap": ("pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + pair_ckpt_kernel<8,1> + pair_sum_kernel<8,1,true>", False),
+            "band16/nowrap": (f"band_kernel<8,0,8,{PATHS}> + band_kernel<8,2,8,{PATHS}>", False),
         }.get(plan.kernel_name, ("agg_packed_kernel<128,false,true> + wta_packed_kernel<8>", True))
         stage_time_ms = agg_ms + (wta_ms if stage_kernels[1] else 0.0)
         achieved = alg_bytes_launch / (stage_time_ms * 1e-3) / 1e9

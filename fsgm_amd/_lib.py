@@ -65,6 +65,7 @@ def load():
     lib.fsgm_epi_plan_upload.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.fsgm_epi_plan_upload_cost.argtypes = [vp, i32, vp]
     lib.fsgm_epi_plan_upload_offset.argtypes = [vp, i32, vp]
+    lib.fsgm_epi_plan_copy_cost.argtypes = [vp, i32, i32, i32]
     lib.fsgm_epi_plan_run.argtypes = [vp, i32]
     lib.fsgm_epi_plan_sync.argtypes = [vp]
     lib.fsgm_epi_plan_download.argtypes = [vp, i32, vp, vp]

@@ -42,6 +42,9 @@ struct fsgm_epi_plan {
     // parallel sweeps (sweep_par): Y_up of every frame and the up sweep's own block-boundary states
     uint8_t *dXupAll = nullptr, *dStateUp = nullptr;
     bool sweep_par = false;              // AGG_SWEEP only: down and up sweeps side by side, WTA over the three Y volumes
+    // band sweeps (epi_band.hip): the first pass's 9th bits, the hand-off between the bands of a frame; dX, dRec, dS0 as above
+    uint32_t* dBits = nullptr;
+    uint4* dBandEdge = nullptr;
     // epipolar driver (fsgm_epipolar_sgm_of_host): rotation flow, composed flow, RGB staging
     double *dRflow = nullptr, *dFlow = nullptr;
     uint8_t* dRgb = nullptr;
@@ -78,6 +81,8 @@ struct fsgm_epi_plan {
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 static int par_min_batch() { static const int v = env_int("FSGM_EPI_PAR_MIN", 5); return v; }
 static int par_max_batch() { static const int v = env_int("FSGM_EPI_PAR_MAX", 18); return v; }
+// band sweeps (all four paths of a pass in one sweep, one workgroup per frame): from this many frames in auto mode
+static int band_min_batch() { static const int v = env_int("FSGM_EPI_BAND_MIN", 1 << 30); return v; }
 static int pairs_min_batch() { static const int v = env_int("FSGM_EPI_PAIRS_MIN", 9); return v; }   // 4 paths: line kernels -> pair pipeline
 
 static void select_kernel(fsgm_epi_plan* p) {
@@ -108,6 +113,11 @@ static void select_kernel(fsgm_epi_plan* p) {
     // the shipped 4-path configuration: both axes as pair kernels, the vertical one final (2*P2 <= 255:
     // the excess sum of a pair fits a byte)
     if (fusable && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
+    // very large batches (or mode 4): the band sweeps
+    if (fusable && band_ok(p->D, p->prm.paths, p->P2) && (p->agg_mode == 4 || (p->agg_mode == 0 && p->batch >= band_min_batch()))) {
+        p->kernel_kind = AGG_BAND;
+        p->sweep_par = false;
+    }
 }
 
 // Lazily allocated buffer sets of the two fused pipelines.  Everything is created into locals and committed to
@@ -183,7 +193,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dXupAll, p->dStateUp, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dEdge, p->dTicket, p->dErr};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dXupAll, p->dStateUp, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dEdge, p->dTicket, p->dErr, p->dBits, p->dBandEdge};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -333,6 +343,27 @@ fsgm_status fsgm_epi_plan_upload_cost(fsgm_epi_plan* p, int32_t f, const uint8_t
     return FSGM_OK;
 }
 
+// frame dst <- frame src of the resident cost volumes, columns rotated by roll_cols (dst[y][(x + roll) % W] = src[y][x]):
+// how bench.py fills a large batch with distinct volumes without pushing each through PCIe
+fsgm_status fsgm_epi_plan_copy_cost(fsgm_epi_plan* p, int32_t dst, int32_t src, int32_t roll_cols) {
+    FSGM_REQUIRE(p, "null plan");
+    FSGM_REQUIRE(dst >= 0 && dst < p->batch && src >= 0 && src < p->batch && dst != src, "fsgm_epi_plan_copy_cost: bad frame pair %d <- %d", dst, src);
+    FSGM_HIP(hipSetDevice(p->prm.device));
+    const size_t pitch = (size_t)p->W * p->D;
+    const int s = ((roll_cols % p->W) + p->W) % p->W;
+    uint8_t* d0 = p->dC + (size_t)dst * p->N;
+    const uint8_t* s0 = p->dC + (size_t)src * p->N;
+    if (s == 0) {
+        FSGM_HIP(hipMemcpyAsync(d0, s0, p->N, hipMemcpyDeviceToDevice, p->stream));
+    } else {
+        FSGM_HIP(hipMemcpy2DAsync(d0 + (size_t)s * p->D, pitch, s0, pitch, (size_t)(p->W - s) * p->D, p->H, hipMemcpyDeviceToDevice, p->stream));
+        FSGM_HIP(hipMemcpy2DAsync(d0, pitch, s0 + (size_t)(p->W - s) * p->D, pitch, (size_t)s * p->D, p->H, hipMemcpyDeviceToDevice, p->stream));
+    }
+    p->cmax[dst] = p->cmax[src];
+    select_kernel(p);
+    return FSGM_OK;
+}
+
 fsgm_status fsgm_epi_plan_upload_offset(fsgm_epi_plan* p, int32_t f, const double* off) {
     FSGM_REQUIRE(p && off, "fsgm_epi_plan_upload_offset: null argument");
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
@@ -416,6 +447,21 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     return FSGM_OK;
 }
 
+static fsgm_status ensure_band_buffers(fsgm_epi_plan* p) {
+    if (p->dBandEdge && p->dX && p->dRec && p->dS0) return FSGM_OK;
+    const size_t B = p->batch;
+    LazySet ls;
+    uint8_t* x = p->dX; uint4 *rec = p->dRec, *edge = p->dBandEdge; uint16_t* s0 = p->dS0; uint32_t* bits = p->dBits;
+    if (!x) ls.alloc(&x, B * p->N);
+    if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint4));
+    if (!s0) ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
+    if (!edge) ls.alloc(&edge, B * band_edge_uint4s(p->W, p->D, 8) * sizeof(uint4));
+    if (!bits && p->prm.paths == 8) ls.alloc(&bits, B * band_bits_u32s(p->W, p->H, p->D) * sizeof(uint32_t));
+    if (ls.err != hipSuccess) return lazy_fail(ls, "band pipeline buffers");
+    p->dX = x; p->dRec = rec; p->dS0 = s0; p->dBandEdge = edge; p->dBits = bits;
+    return FSGM_OK;
+}
+
 static fsgm_status ensure_par_buffers(fsgm_epi_plan* p) {
     if (p->dXupAll) return FSGM_OK;
     LazySet ls;
@@ -443,6 +489,7 @@ static fsgm_status prepare(fsgm_epi_plan* p, int stages) {
             return st;
         }
         if (p->kernel_kind == AGG_PAIRS) return ensure_pairs_buffers(p);
+        if (p->kernel_kind == AGG_BAND) return ensure_band_buffers(p);
     }
     return FSGM_OK;
 }
@@ -560,6 +607,17 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
             }
             f0 += nf;
         }
+    } else if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_BAND) {
+        // all four paths of a raster pass in one sweep, one workgroup per frame: first pass -> Y (+ 9th bits), second pass + WTA
+        BandArgs b;
+        b.C = p->dC; b.c_frame_stride = p->N;
+        b.Y = p->dX; b.y_frame_stride = p->N;
+        b.Yb = p->dBits; b.yb_frame_stride = band_bits_u32s(p->W, p->H, p->D);
+        b.edge = p->dBandEdge; b.edge_frame_stride = band_edge_uint4s(p->W, p->D, 8);
+        b.rec = p->dRec; b.s0 = p->dS0; b.Sdbg = nullptr;
+        b.W = p->W; b.H = p->H; b.D = p->D; b.P1 = p->P1; b.P2 = p->P2;
+        launch_band(p->stream, b, p->batch, p->prm.paths, 0);
+        launch_band(p->stream, b, p->batch, p->prm.paths, 2);
     } else if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_PAIRS) {
         // 4 paths: the horizontal pair -> X_h on stream_h while the vertical pair's checkpoint pass runs
         // here; then the vertical sum pass adds X_h + 4*C and does the WTA (7.5 B per voxel, S never in HBM)
@@ -600,7 +658,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         q.Lh = p->dLh; q.lh_frame_stride = p->N; q.lh_natural = 0;
         q.nC = 8; q.P2 = p->P2; q.Sdbg = nullptr;
         launch_wta_sweep(p->stream, a, q, p->batch);
-    } else if ((stages & FSGM_STAGE_WTA) && (p->kernel_kind == AGG_SWEEP || p->kernel_kind == AGG_PAIRS)) {
+    } else if ((stages & FSGM_STAGE_WTA) && (p->kernel_kind == AGG_SWEEP || p->kernel_kind == AGG_PAIRS || p->kernel_kind == AGG_BAND)) {
         WtaArgs a;                                   // the argmin happened inside the final sweep / pair pass; finish the records
         a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
         a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
@@ -670,7 +728,7 @@ fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* p, int32_t stages) {
 
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* p, int32_t mode) {
     FSGM_REQUIRE(p, "null plan");
-    FSGM_REQUIRE(mode >= 0 && mode <= 3, "agg mode must be 0 (auto), 1 (per-direction kernels), 2 (fused sweeps) or 3 (parallel sweeps)");
+    FSGM_REQUIRE(mode >= 0 && mode <= 4, "agg mode must be 0 (auto), 1 (per-direction kernels), 2 (fused sweeps), 3 (parallel sweeps) or 4 (band sweeps)");
     p->agg_mode = mode;
     select_kernel(p);
     return FSGM_OK;
@@ -797,6 +855,29 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         FSGM_HIP(hipMemcpy(S, p->dS, p->N * 4, hipMemcpyDeviceToHost));
         return FSGM_OK;
     }
+    if (p->kernel_kind == AGG_BAND) {
+        // S never exists in HBM in band mode either.  Debug tap: the second pass of that frame again (its first pass's Y is
+        // still in place), with the kernel's natural-order dump of S switched on.
+        FSGM_HIP(hipStreamSynchronize(p->stream));
+        fsgm_status es = ensure_band_buffers(p);
+        if (es != FSGM_OK) return es;
+        if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
+        BandArgs b;
+        const size_t fs = (size_t)f;
+        b.C = p->dC + fs * p->N; b.c_frame_stride = p->N;
+        b.Y = p->dX + fs * p->N; b.y_frame_stride = p->N;
+        b.yb_frame_stride = band_bits_u32s(p->W, p->H, p->D);
+        b.Yb = p->dBits ? p->dBits + fs * b.yb_frame_stride : nullptr;
+        b.edge_frame_stride = band_edge_uint4s(p->W, p->D, 8);
+        b.edge = p->dBandEdge + fs * b.edge_frame_stride;
+        b.rec = p->dRec + fs * p->NP; b.s0 = p->dS0 + fs * p->NP; b.Sdbg = p->dS;
+        b.W = p->W; b.H = p->H; b.D = p->D; b.P1 = p->P1; b.P2 = p->P2;
+        launch_band(p->stream, b, 1, p->prm.paths, 2);
+        FSGM_HIP(hipGetLastError());
+        FSGM_HIP(hipStreamSynchronize(p->stream));
+        FSGM_HIP(hipMemcpy(S, p->dS, p->N * 4, hipMemcpyDeviceToHost));
+        return FSGM_OK;
+    }
     if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
     launch_sum_paths(p->stream, p->dL + (size_t)f * p->N * p->prm.paths, p->dS, p->N, p->N, p->prm.paths);
     FSGM_HIP(hipGetLastError());
@@ -836,6 +917,7 @@ const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* p) {
         case AGG_PACKED_WRAP: return "packed16/wrap";
         case AGG_SWEEP: return p->sweep_par ? "sweep16par/nowrap" : "sweep16/nowrap";
         case AGG_PAIRS: return "pairs16/nowrap";
+        case AGG_BAND: return "band16/nowrap";
         default: return "generic";
     }
 }

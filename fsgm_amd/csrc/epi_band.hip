@@ -1,0 +1,320 @@
+// epi_band.hip -- band sweeps: ALL FOUR paths of a raster pass of calc_cost_sgm.cpp:86-257 in one sweep (gfx950).
+//
+// Why.  The block sweeps of epi_sweep.hip compute the three paths that advance row by row together and leave the two
+// along-x paths to the pair kernels: C is read four times, the pair's sum Y_h is written and read, a quarter of the sweeps'
+// DP steps are halo recomputation and the pair recomputes one of its two paths -- 9.7 B per voxel through HBM and
+// ~880 wave-instructions per 8 pixels for 8 voxel-paths each.  A raster pass's four paths -- from the left (-1,0), from
+// above (0,-1), from above-left (-1,-1), from above-right (+1,-1), calc_cost_sgm.cpp:183-226 -- all take their
+// predecessor from an earlier pixel in raster order, so they CAN be computed together if the sweep order respects all four
+// dependencies: in the skewed coordinate u = x + 2*y the predecessors of (u, y) are (u-1, y), (u-2, y-1), (u-3, y-1) and
+// (u-1, y-1) -- all at smaller u.  A workgroup therefore walks u and computes, per step, one pixel of every row of a BAND of
+// rows, all four paths each: C is read once per pass, the only volume between the two passes is the sum of the first
+// pass's four y (9 bits per voxel: a byte volume plus a bit plane when 4*P2 > 255), and there is no halo, no recomputed path,
+// no pair kernel:
+//
+//   down pass (MODE 0)   C -> Y_dn (+ bit plane), the four pass-0 paths
+//   final pass (MODE 2)  on the point-mirrored frame (pass 1, :114-123): its own four paths, then in registers
+//                        S = 8*(C + P2) - (Y_up + Y_dn) and the WTA; one 18-byte record per pixel (sweep_finish_kernel
+//                        does the parabola / vz conversion as for the block sweeps)
+//   4.3-4.6 B per voxel instead of 9.7, ~650 wave-instructions per 8 pixels instead of ~880.
+//
+// PATHS = 4 (the shipped configuration, :104): the two paths of a pass that remain (from the left, from above) need only
+// u = x + y; Y_dn <= 2*P2 fits a byte; 4 B per voxel instead of 7.5.
+//
+// Layout.  LPP = D/16 lanes own a pixel (16 costs each, register layout of epi_step.h); a wave owns 64/LPP consecutive
+// ROWS (lane group g <-> row), a workgroup of NWV waves a band of R = NWV*64/LPP rows; one workgroup walks one frame,
+// band after band (375 rows = 6 bands of 64).  The from-the-left state never leaves its registers.  The three states that
+// cross rows go through LDS: every row writes its new states of step u into buffer u&1 at its own row slot and reads the
+// row above's states of step u-1 from the other buffer -- that is pixel x+1 of the row above: the from-above-right
+// predecessor; the from-above (pixel x) and from-above-left (pixel x-1) predecessors are the same reads of one and two steps
+// ago, kept in registers (packed bytes, 12 VGPRs).  One workgroup barrier per step.  Between bands the last row's states
+// go through a per-frame global buffer indexed by image column, written in place behind the reads (a band reads column
+// u+2 of it at step u and writes column u-2(R-1)); wave 0 plays "row -1" for row 0.  Frames are independent workgroups: no
+// inter-workgroup synchronisation of any kind, no tickets, no polling.
+//
+// Path starts (:152-180): a predecessor outside the image means the path starts here -- the consumer presets the state to
+// P2 in every element and masks the stored minimum to 0 (epi_step.h); waves whose eight pixels are all strictly inside
+// the image run a variant without those selects.
+//
+// What it needs: many frames.  One band of one frame is in flight per workgroup, two workgroups of 8 waves per CU: 512
+// frames fill the chip.  That is what 288 GB of HBM are for; smaller batches take the block sweeps / line kernels.
+#include "epi_kernels.h"
+#include "fsgm_device.h"
+#include "epi_step.h"
+#include <type_traits>
+#include <stdlib.h>
+
+namespace fsgm {
+
+#ifndef FSGM_BAND_PF
+#define FSGM_BAND_PF 2          // steps of C (and, final pass, Y_dn) in flight per lane (A/B knob)
+#endif
+
+// 9th bits of the eight packed-u16 registers of a lane -> one dword (bit k of byte b = bit 8 of register 2k + (b&1), half b>>1)
+__device__ __forceinline__ uint32_t pack_hi_bits(const uint32_t (&R)[8]) {
+    constexpr uint32_t SEL_HI = 0x07030501u;                 // v_perm(b, a): bytes a.1, b.1, a.3, b.3
+    const uint32_t h0 = __builtin_amdgcn_perm(R[1], R[0], SEL_HI), h1 = __builtin_amdgcn_perm(R[3], R[2], SEL_HI);
+    const uint32_t h2 = __builtin_amdgcn_perm(R[5], R[4], SEL_HI), h3 = __builtin_amdgcn_perm(R[7], R[6], SEL_HI);
+    return h0 | (h1 << 1) | (h2 << 2) | (h3 << 3);
+}
+// private u8 order + bit plane -> registers (values up to 511)
+__device__ __forceinline__ void unpack_p9(const uint4 v, const uint32_t bits, uint32_t (&R)[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t hk = (bits >> k) & 0x01010101u;
+        R[2 * k] = __builtin_amdgcn_perm(hk, w[k], 0x06020400u);          // (w.0, h.0, w.2, h.2)
+        R[2 * k + 1] = __builtin_amdgcn_perm(hk, w[k], 0x07030501u);      // (w.1, h.1, w.3, h.3)
+    }
+}
+
+template <int LPP, int MODE, int NWV, int PATHS, bool BITS>
+__global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
+    constexpr bool UP = MODE != 0;
+    constexpr bool P8 = PATHS == 8;
+    constexpr int PXG = 64 / LPP;            // rows per wave
+    constexpr int R = NWV * PXG;             // rows per band
+    constexpr int D = LPP * 16;
+    constexpr int SKEW = P8 ? 2 : 1;         // u = x + SKEW * (row in band)
+    constexpr int NST = P8 ? 3 : 1;          // states that cross rows: 0 from above, 1 from above-left, 2 from above-right
+    constexpr int PF = FSGM_BAND_PF;
+    __shared__ uint4 sSt[2][NST][(R + 1) * LPP];              // [step parity][state][row slot (row + 1; slot 0 = the row above the band)][lane of pixel]
+    __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 4];   // final pass: S of the wave's pixels (u16, two planes: epi_step.h)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane / LPP, j = lane % LPP;
+    const int r = wave * PXG + g;                              // row within the band
+    const int W = a.W, H = a.H, NP = W * H;
+    const size_t f = blockIdx.x;
+    const uint8_t* __restrict__ Cf = a.C + f * a.c_frame_stride;
+    uint8_t* __restrict__ Yf = a.Y + f * a.y_frame_stride;
+    uint32_t* __restrict__ Bf = BITS ? a.Yb + f * a.yb_frame_stride : nullptr;
+    uint4* __restrict__ Ef = a.edge + f * a.edge_frame_stride;        // [W][NST][LPP]
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const uint4 startP = make_uint4(P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u);
+    const LaneSel sel = lane_sel<LPP>(j);
+    const int elane = min(lane, NST * LPP - 1);                // wave 0: lane = state * LPP + lane-of-pixel of the hand-off words
+
+    auto pix_of = [&](int x, int y) -> int { const int p = y * W + x; return UP ? NP - 1 - p : p; };
+
+    for (int yb = 0; yb < H; yb += R) {                        // ---- one band ----
+        const int Rp = min(R, H - yb);
+        const int y = yb + r, yc = min(y, H - 1);
+        const bool row_ok = r < Rp;
+        const int nsteps = W + SKEW * (Rp - 1);
+        const bool have_above = yb > 0, last_band = yb + R >= H;
+        const bool loader = wave == 0 && lane < NST * LPP && have_above;
+        // steps in which this wave has a pixel inside the image / in which all of its pixels are strictly inside
+        const int r_lo = wave * PXG, r_hi = r_lo + PXG - 1;
+        // (8 paths: one step early -- the from-above / from-above-left predecessors of a row's first pixels are read from
+        // LDS one and two steps before they are used, and the slot they sit in is rewritten every other step)
+        const int act_lo = SKEW * r_lo - (P8 ? 1 : 0), act_hi = W - 1 + SKEW * r_hi;
+        const bool wave_rows = r_lo < Rp;
+        const int pl_lo = SKEW * r_hi + 1, pl_hi = W - 2 + SKEW * r_lo;
+        const bool wave_plain_rows = r_hi < Rp && yb + r_lo >= 1;
+
+        auto vox_off = [&](int u) -> uint32_t {               // byte offset of this lane's 16 bytes at step u (clamped into the image)
+            const int x = min(max(u - SKEW * r, 0), W - 1);
+            return (uint32_t)pix_of(x, yc) * D + (uint32_t)j * 16;
+        };
+        auto bit_off = [&](int u) -> uint32_t {
+            const int x = min(max(u - SKEW * r, 0), W - 1);
+            return (uint32_t)pix_of(x, yc) * LPP + (uint32_t)j;
+        };
+        auto edge_at = [&](int x) -> const uint4* { return Ef + (size_t)min(max(x, 0), W - 1) * (NST * LPP) + elane; };
+
+        uint32_t FS[8];                                        // from the left: stays in these lanes
+#pragma unroll
+        for (int i = 0; i < 8; i++) FS[i] = P2pk;
+        // from above / from above-left of the row above, read one / two steps before they are used
+        uint4 hU = startP, hD1 = startP, hD2 = startP;
+        if (P8 && have_above && r == 0) {                      // row 0: column 0 of the band above ("read at step -1")
+            hU = load_nt(Ef + 0 * LPP + j);
+            hD1 = load_nt(Ef + 1 * LPP + j);
+        }
+        if (loader) sSt[1][elane / LPP][elane % LPP] = load_nt(edge_at(SKEW - 1));     // what row 0 reads at step 0
+        uint4 ringC[PF], ringY[MODE == 2 ? PF : 1];
+        uint4 nextE = startP;                                  // wave 0: the band above's states for the next step (one step ahead: L2 / MALL resident)
+        uint32_t ringB[MODE == 2 && BITS ? PF : 1];
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const uint32_t off = vox_off(i);
+            ringC[i] = *(const uint4*)(Cf + off);
+            if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = Bf[bit_off(i)]; }
+        }
+        if (loader) nextE = load_nt(edge_at(SKEW));
+        __syncthreads();
+
+        // one step of this wave's rows.  EDGE: a pixel of the wave is at / outside an image border or in row 0, or a row
+        // of the wave lies below the image (selects allowed); the plain variant has none.
+        auto do_step = [&](const int u, const uint4 cw, const uint4 cy, const uint32_t cb, auto edge_tag) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            const int par = u & 1;
+            const int x = u - SKEW * r;
+            const bool inside = !EDGE || (row_ok && x >= 0 && x < W);
+            const int xc = EDGE ? min(max(x, 0), W - 1) : x;
+            // the row above's states of the previous step (pixel x+1 there): the from-above-right predecessor now (4 paths:
+            // the from-above one); the other two are for the coming steps and are read further down, when registers are free
+            const uint4 nNow = sSt[par ^ 1][P8 ? 2 : 0][r * LPP + j];
+            uint32_t CP[8], Y[8], YS[8], S[8];
+            unpack_c(cw, CP, P2pk);
+            const bool top = EDGE && y == 0;                   // row 0 of the frame: every path from above starts (:152-180)
+            // from the left (-1,0): :183-191
+            {
+                const bool st = EDGE && x <= 0;
+                if (st) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) FS[i] = P2pk;
+                }
+                step_s<LPP, EDGE>(FS, CP, YS, P1pk, P2, sel, st ? 0u : 0xFFFFu);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // from above (0,-1): :193-202
+            uint4 newU, newD, newR;
+            {
+                unpack_p(P8 ? hU : nNow, S);
+                if (top) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) S[i] = P2pk;
+                }
+                step_s<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, top ? 0u : 0xFFFFu);
+                newU = pack_p(S);
+                sSt[par][0][(r + 1) * LPP + j] = newU;
+#pragma unroll
+                for (int i = 0; i < 8; i++) YS[i] += Y[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);                 // one path after the other: interleaving them costs registers (spills)
+            if constexpr (P8) {
+                // from above-left (-1,-1): :205-213
+                {
+                    const bool st = top || (EDGE && x <= 0);
+                    unpack_p(hD2, S);
+                    if (st) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) S[i] = P2pk;
+                    }
+                    step_s<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, st ? 0u : 0xFFFFu);
+                    newD = pack_p(S);
+                    sSt[par][1][(r + 1) * LPP + j] = newD;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) YS[i] += Y[i];
+                    hD2 = hD1;
+                    hD1 = sSt[par ^ 1][1][r * LPP + j];          // pixel x+1's from-above-left state: used two steps on
+                    hU = sSt[par ^ 1][0][r * LPP + j];           // its from-above state: used next step
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // from above-right (+1,-1): :215-225
+                {
+                    const bool st = top || (EDGE && x >= W - 1);
+                    unpack_p(nNow, S);
+                    if (st) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) S[i] = P2pk;
+                    }
+                    step_s<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, st ? 0u : 0xFFFFu);
+                    newR = pack_p(S);
+                    sSt[par][2][(r + 1) * LPP + j] = newR;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) YS[i] += Y[i];
+                }
+            }
+            // the band's last row hands its states to the band below, by image column
+            if (!last_band && r == R - 1 && inside) {
+                uint4* o = Ef + (size_t)xc * (NST * LPP) + j;
+                o[0] = newU;
+                if constexpr (P8) { o[LPP] = newD; o[2 * LPP] = newR; }
+            }
+            if (MODE != 2) {
+                // the sum of this pass's y (:227-232): low bytes + 9th bits
+                if (inside) {
+                    vol_store(Yf + (uint32_t)pix_of(xc, yc) * D + (uint32_t)j * 16, pack_p(YS));
+                    if (BITS) Bf[(uint32_t)pix_of(xc, yc) * LPP + j] = pack_hi_bits(YS);
+                }
+            } else {
+                // S = PATHS*(C + P2) - (this pass's y + the first pass's), WTA on the spot (:227-232, :259-275)
+                uint32_t E2[8], ST[8];
+                if (BITS) unpack_p9(cy, cb, E2); else unpack_p(cy, E2);
+#pragma unroll
+                for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], (uint32_t)PATHS * 0x10001u, 0u), pk_add(YS[i], E2[i]));
+                wta_row_record<LPP, NWV * 64>(ST, sRow, tid, j, inside, a.rec, a.s0, f * (size_t)NP + pix_of(xc, yc));
+                if (a.Sdbg && inside) {                        // debug tap (block-uniform test): S in natural d order
+                    uint32_t* o = a.Sdbg + (f * (size_t)NP + pix_of(xc, yc)) * D + j * 16;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { o[i] = ST[i] & 0xFFFFu; o[i + 8] = ST[i] >> 16; }
+                }
+            }
+        };
+        auto step = [&](const int u, const uint4 cw, const uint4 cy, const uint32_t cb) {
+            if (wave == 0 && loader) {                                                // "row -1" of step u: column u + SKEW of the band above
+                sSt[u & 1][elane / LPP][elane % LPP] = nextE;
+                nextE = load_nt(edge_at(u + 1 + SKEW));
+            }
+            if (wave_rows && u >= act_lo && u <= act_hi) {                            // wave-uniform
+                if (wave_plain_rows && u >= pl_lo && u <= pl_hi) do_step(u, cw, cy, cb, std::false_type{});
+                else do_step(u, cw, cy, cb, std::true_type{});
+            }
+#ifndef FSGM_BAND_NOBAR                                                  /* timing experiment only: wrong results without it */
+            __syncthreads();                                   // states of step u visible to step u+1
+#endif
+        };
+
+        int u0 = 0;
+        for (; u0 + PF <= nsteps; u0 += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; i++) {
+                const int u = u0 + i;
+                const uint4 cw = ringC[i];
+                const uint4 cy = ringY[MODE == 2 ? i : 0];
+                const uint32_t cb = ringB[MODE == 2 && BITS ? i : 0];
+                const uint32_t off = vox_off(u + PF);
+                ringC[i] = *(const uint4*)(Cf + off);
+                if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = Bf[bit_off(u + PF)]; }
+                step(u, cw, cy, cb);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PF - 1; i++)
+            if (u0 + i < nsteps) step(u0 + i, ringC[i], ringY[MODE == 2 ? i : 0], ringB[MODE == 2 && BITS ? i : 0]);   // workgroup-uniform
+        // the band below reads what the last row stored: stores done before anyone goes on
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+#ifndef FSGM_BAND_WAVES
+#define FSGM_BAND_WAVES 8        // waves per band workgroup (8: 64-row bands at D = 128, two workgroups per CU)
+#endif
+
+size_t band_edge_uint4s(int W, int D, int paths) { const int lpp = agg_packed_lpp(D); return (size_t)W * (paths == 8 ? 3 : 1) * lpp; }   // per frame
+size_t band_bits_u32s(int W, int H, int D) { return (size_t)W * H * agg_packed_lpp(D); }                                                 // per frame
+bool band_needs_bits(int paths, int P2) { return paths == 8 && 4 * P2 > 255; }
+bool band_ok(int D, int paths, int P2) { return agg_packed_lpp(D) != 0 && P2 <= 127 && (paths == 8 || paths == 4); }
+
+template <int LPP, int MODE>
+static void launch_band_t(hipStream_t st, const BandArgs& a, int frames, int paths) {
+    constexpr int NWV = FSGM_BAND_WAVES;
+    const bool bits = band_needs_bits(paths, a.P2);
+    dim3 grid((unsigned)frames), block(NWV * 64);
+    if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false>), grid, block, 0, st, a);
+    else if (!bits)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, false>), grid, block, 0, st, a);
+    else             hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, true>), grid, block, 0, st, a);
+}
+
+// One whole pass of `frames` frames: mode 0 = first pass -> Y (+ bit plane), mode 2 = second pass + WTA records
+void launch_band(hipStream_t st, const BandArgs& a, int frames, int paths, int mode) {
+#define FSGM_BAND(L) do { if (mode == 0) launch_band_t<L, 0>(st, a, frames, paths); else launch_band_t<L, 2>(st, a, frames, paths); } while (0)
+    switch (agg_packed_lpp(a.D)) {
+        case 1: FSGM_BAND(1); break;
+        case 2: FSGM_BAND(2); break;
+        case 4: FSGM_BAND(4); break;
+        case 8: FSGM_BAND(8); break;
+        case 16: FSGM_BAND(16); break;
+        default: break;
+    }
+#undef FSGM_BAND
+}
+
+}  // namespace fsgm

@@ -83,6 +83,23 @@ struct StripArgs {
     int frames, NS;
 };
 
+// band sweeps: all four paths of a raster pass in one sweep, one workgroup per frame (epi_band.hip)
+struct BandArgs {
+    const uint8_t* C;         // [frames] cost volumes
+    size_t c_frame_stride;
+    uint8_t* Y;               // [frames] low bytes of the first pass's sum of y (private byte order): written by mode 0, read by mode 2
+    size_t y_frame_stride;
+    uint32_t* Yb;             // [frames][NP][LPP] its 9th bits, one dword per lane (8 paths with 4*P2 > 255), else unused
+    size_t yb_frame_stride;   // in dwords
+    uint4* edge;              // [frames][W][states][LPP] path states of a band's last row for the band below (3 states at 8 paths, 1 at 4)
+    size_t edge_frame_stride; // in uint4
+    uint4* rec;               // mode 2: [frames][NP] {best, minC, S[best-1], S[best+1]}
+    uint16_t* s0;             // mode 2: [frames][NP] S[0] of every pixel
+    uint32_t* Sdbg;           // mode 2, optional: natural-order u32 dump of S [frames][NP][D] (debug tap)
+    int W, H, D;
+    int P1, P2;
+};
+
 struct SweepSumArgs {          // what wta_sweep_kernel adds up (u8 volumes; the Y volumes in the sweeps' private byte order)
     const uint8_t* C;
     const uint8_t* Xdn;       // Y of the down sweep (or of the vertical pair)
@@ -126,7 +143,7 @@ struct FbArgs {                // forward-backward check (calc_cost_sgm.cpp:429-
     int W, H, n, thr;
 };
 
-enum { AGG_PACKED_NOWRAP = 0, AGG_PACKED_WRAP = 1, AGG_GENERIC = 2, AGG_SWEEP = 3, AGG_PAIRS = 4 };
+enum { AGG_PACKED_NOWRAP = 0, AGG_PACKED_WRAP = 1, AGG_GENERIC = 2, AGG_SWEEP = 3, AGG_PAIRS = 4, AGG_BAND = 5 };
 
 int  agg_packed_lpp(int D);   // lanes per pixel of the packed kernels, 0 if D is not 16<<k, k<=4
 void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int H, int frames);
@@ -143,6 +160,11 @@ size_t pair_ckpt_bytes(int W, int H, int D, int axis);      // per frame; axis 0
 void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase = 0);
 bool pair_x_fine_ok(int D);                                                        // the along-x pair with 8 costs a lane exists for this D
 void launch_pair_x_fine(hipStream_t st, const PairArgs& a, int frames);            // checkpoint + sum pass, Y in natural d order
+size_t band_edge_uint4s(int W, int D, int paths);           // hand-off buffer between the bands of one frame, in uint4
+size_t band_bits_u32s(int W, int H, int D);                 // bit plane of one frame, in dwords
+bool   band_needs_bits(int paths, int P2);
+bool   band_ok(int D, int paths, int P2);
+void launch_band(hipStream_t st, const BandArgs& a, int frames, int paths, int mode);   // 0 first pass, 2 second pass + WTA records
 void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames);
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);
 void launch_fb_check(hipStream_t st, const FbArgs& a, int frames);

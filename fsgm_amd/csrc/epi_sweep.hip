@@ -54,165 +54,11 @@
 #include "epi_kernels.h"
 #include "fsgm_device.h"
 #include "epi_wta_tail.h"
+#include "epi_step.h"
 #include <type_traits>
 #include <stdlib.h>
 
 namespace fsgm {
-
-namespace {
-
-constexpr uint32_t SEL_ODD = 0x0C030C01u;    // v_perm: bytes 1,3 -> 2 x u16
-constexpr uint32_t SEL_PACK = 0x06020400u;   // v_perm(b, a): bytes a.0, b.0, a.2, b.2
-constexpr uint32_t SEL_NB = 0x05040302u;     // v_perm(a, b): (b.hi16, a.lo16)
-constexpr uint32_t SEL_NB_NOLO = 0x05040C0Cu;   // ... with 0 in the low half  (no d-1 neighbour)
-constexpr uint32_t SEL_NB_NOHI = 0x0C0C0302u;   // ... with 0 in the high half (no d+1 neighbour)
-
-__device__ __forceinline__ uint32_t pk_mad16(uint32_t a, uint32_t b, uint32_t c) {        // v_pk_mad_u16
-    u16x2 r = __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c);
-    return __builtin_bit_cast(uint32_t, r);
-}
-// max(a - b, 0) per half (v_pk_sub_u16 clamp)
-__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) {
-    u16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
-    return __builtin_bit_cast(uint32_t, r);
-}
-// 3-input maximum / minimum of packed u16 values below 0x7C00 (see the header: fp16 order = integer order there);
-// hipcc fuses the nested 2-input forms into v_pk_maximum3_f16 / v_pk_minimum3_f16 on gfx950
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
-    f16x2 r = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
-                                            __builtin_bit_cast(f16x2, c));
-    return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
-    f16x2 r = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
-                                            __builtin_bit_cast(f16x2, c));
-    return __builtin_bit_cast(uint32_t, r);
-}
-// min(x.lo, x.hi) in the low half, zero above (v_min_u16 with SDWA half selects)
-__device__ __forceinline__ uint32_t min_halves(uint32_t x) {
-    uint32_t r;
-    asm("v_min_u16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0" : "=v"(r) : "v"(x));
-    return r;
-}
-
-// 16 natural-order cost bytes of a lane -> CP[i] = (C[i] + P2, C[i+8] + P2)
-__device__ __forceinline__ void unpack_c(const uint4 w, uint32_t (&CP)[8], const uint32_t P2pk) {
-    CP[0] = pk_add(__builtin_amdgcn_perm(w.z, w.x, 0x0C040C00u), P2pk);
-    CP[1] = pk_add(__builtin_amdgcn_perm(w.z, w.x, 0x0C050C01u), P2pk);
-    CP[2] = pk_add(__builtin_amdgcn_perm(w.z, w.x, 0x0C060C02u), P2pk);
-    CP[3] = pk_add(__builtin_amdgcn_perm(w.z, w.x, 0x0C070C03u), P2pk);
-    CP[4] = pk_add(__builtin_amdgcn_perm(w.w, w.y, 0x0C040C00u), P2pk);
-    CP[5] = pk_add(__builtin_amdgcn_perm(w.w, w.y, 0x0C050C01u), P2pk);
-    CP[6] = pk_add(__builtin_amdgcn_perm(w.w, w.y, 0x0C060C02u), P2pk);
-    CP[7] = pk_add(__builtin_amdgcn_perm(w.w, w.y, 0x0C070C03u), P2pk);
-}
-// private u8 order <-> registers
-__device__ __forceinline__ void unpack_p(const uint4 v, uint32_t (&R)[8]) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        R[2 * k] = w[k] & 0x00FF00FFu;
-        R[2 * k + 1] = __builtin_amdgcn_perm(0u, w[k], SEL_ODD);
-    }
-}
-__device__ __forceinline__ uint4 pack_p(const uint32_t (&R)[8]) {      // values <= 255 per half
-    uint4 o;
-    o.x = __builtin_amdgcn_perm(R[1], R[0], SEL_PACK);
-    o.y = __builtin_amdgcn_perm(R[3], R[2], SEL_PACK);
-    o.z = __builtin_amdgcn_perm(R[5], R[4], SEL_PACK);
-    o.w = __builtin_amdgcn_perm(R[7], R[6], SEL_PACK);
-    return o;
-}
-// 16 bytes of one of the sweeps' Y volumes (read or written once per pass): FSGM_VOL_NT=1 marks these accesses non-temporal
-// (measured: -0.5 to -1.3 %, inside the run-to-run spread: off; with the own columns' C loads marked as well the sweeps
-// lose up to 4 % -- the neighbouring workgroup reads the same columns as its halo)
-#ifndef FSGM_VOL_NT
-#define FSGM_VOL_NT 0
-#endif
-__device__ __forceinline__ uint4 vol_load(const void* p) { return FSGM_VOL_NT ? load_nt(p) : *(const uint4*)p; }
-__device__ __forceinline__ void vol_store(void* p, const uint4 v) { if (FSGM_VOL_NT) store_nt(p, v); else *(uint4*)p = v; }
-// The pair kernels' accesses are non-temporal by default: every line of C, Y and the other pair's Y is touched once per pass by
-// one wave; measured over three runs each, 8 paths 4.67 -> 4.55 ms per 40 frames, 4 paths 3.64 -> 3.53.  (The sweeps: see vol_load.)
-#ifndef FSGM_PAIR_NT
-#define FSGM_PAIR_NT 1
-#endif
-__device__ __forceinline__ uint4 pvol_load(const void* p) { return FSGM_PAIR_NT ? load_nt(p) : *(const uint4*)p; }
-__device__ __forceinline__ void pvol_store(void* p, const uint4 v) { if (FSGM_PAIR_NT) store_nt(p, v); else *(uint4*)p = v; }
-__device__ __forceinline__ uint4 add4(const uint4 a, const uint4 b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-
-// per-lane constants of the step: the v_perm selectors of the two lane-crossing neighbour registers
-struct LaneSel { uint32_t lo, hi; };
-template <int LPP>
-__device__ __forceinline__ LaneSel lane_sel(const int j) {
-    LaneSel s;
-    s.lo = j == 0 ? SEL_NB_NOLO : SEL_NB;            // d = 0 has no d-1     (:47)
-    s.hi = j == LPP - 1 ? SEL_NB_NOHI : SEL_NB;      // d = D-1 has no d+1   (:48)
-    return s;
-}
-
-// One DP step (calc_cost_sgm.cpp:33-66) in the mirrored variable, see the header.  S: previous pixel's state
-// s = P2 - min(L - m, P2), replaced by the new pixel's; Y: y = P2 - (L_new - C) of the new pixel, in [0, P2].
-// A path start (:152-180) = S preset to P2 in every element and mmask = 0 (the stored minimum is 0 there, :154).
-template <int LPP, bool MASKED = true>
-__device__ __forceinline__ void step_s(uint32_t (&S)[8], const uint32_t (&CP)[8], uint32_t (&Y)[8], const uint32_t P1pk,
-                                       const uint32_t P2, const LaneSel sel, const uint32_t mmask) {
-    uint32_t T[8], N[8];
-    T[7] = pk_subs(S[7], P1pk);                      // the two registers that cross lanes first: the DPP moves below
-    T[0] = pk_subs(S[0], P1pk);                      // read them two instructions after they are written
-#pragma unroll
-    for (int i = 1; i < 7; i++) T[i] = pk_subs(S[i], P1pk);
-    // d-1 of register 0 = (previous lane's d = 15, own d = 7); d+1 of register 7 = (own d = 8, next lane's d = 0);
-    // lanes without a source lane in their row of 16 read 0
-    const uint32_t LT = __builtin_amdgcn_perm(T[7], (uint32_t)__builtin_amdgcn_mov_dpp((int)T[7], DPP_ROW_SHR1, 0xF, 0xF, true), sel.lo);
-    const uint32_t RT = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_mov_dpp((int)T[0], DPP_ROW_SHL1, 0xF, 0xF, true), T[0], sel.hi);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        Y[i] = pk_max3(S[i], i ? T[i - 1] : LT, i < 7 ? T[i + 1] : RT);
-        N[i] = pk_sub(CP[i], Y[i]);
-    }
-    const uint32_t mm = pk_min(pk_min3(N[0], N[1], N[2]), pk_min3(N[3], N[4], pk_min3(N[5], N[6], N[7])));
-    uint32_t mx = group_min_u32<LPP>(min_halves(mm));
-    if (MASKED) mx &= mmask;
-    const uint32_t p2m = __umul24(mx, 0x10001u) + P2 * 0x10001u;     // (P2 + m) in both halves: one v_mad_u32_u24
-#pragma unroll
-    for (int i = 0; i < 8; i++) S[i] = pk_subs(p2m, N[i]);
-}
-
-// Per-pixel WTA of the final passes: S (packed u16, register layout of the header) of the LPP lanes of a pixel -> one
-// record {best, minC, S[best-1], S[best+1]} + S[0] (calc_cost_sgm.cpp:263-271; the parabola runs in
-// sweep_finish_kernel).  First minimum over d: inside a lane as packed u16 keys S*16 + (index in the
-// lane) (S <= 8*255, so a key fits 16 bits and two of them compare per v_pk_min_u16); across the lanes
-// of a pixel as (S << 8 | d).  sRow: 8 u32 per lane, rows private to the wave that writes them; element d of a pixel
-// sits at u16 index ((d >> 4) * 8 + (d & 7)) * 2 + ((d >> 3) & 1).
-__device__ __forceinline__ uint32_t srow_index(uint32_t d) { return (((d >> 4) * 8 + (d & 7)) << 1) + ((d >> 3) & 1); }
-
-template <int LPP>
-__device__ __forceinline__ void wta_row_record(const uint32_t (&ST)[8], uint32_t* sRow, int tid, int j,
-                                               bool ok, uint4* rec, uint16_t* s0, size_t idx) {
-    constexpr int D = LPP * 16;
-    uint32_t* row = sRow + (size_t)(tid / LPP) * (D / 2) + j * 8;
-    uint32_t kmin = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        row[i] = ST[i];
-        kmin = pk_min(kmin, pk_mad16(ST[i], 0x00100010u, (uint32_t)i | ((uint32_t)(i + 8) << 16)));
-    }
-    const uint32_t k16 = min(kmin & 0xFFFFu, kmin >> 16);
-    uint32_t key = ((k16 >> 4) << 8) | ((uint32_t)j * 16u + (k16 & 15u));
-    key = group_min_u32<LPP>(key);
-    __builtin_amdgcn_wave_barrier();
-    if (j == 0 && ok) {
-        const uint32_t best = key & 0xFF, minc = key >> 8;
-        const uint16_t* srow = (const uint16_t*)(sRow + (size_t)(tid / LPP) * (D / 2));
-        const uint32_t c_1 = best > 0 ? srow[srow_index(best - 1)] : 0u;
-        const uint32_t c1 = best + 1 < (uint32_t)D ? srow[srow_index(best + 1)] : 0u;   // best == D-1: the finish kernel takes the next pixel's S[0]
-        rec[idx] = make_uint4(best, minc, c_1, c1);
-        s0[idx] = (uint16_t)srow[0];
-    }
-}
-
-}  // namespace
 
 // =============================================================================================
 // sweep kernel: rows [y0, y0+rows) of the sweep frame.
@@ -246,7 +92,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
     constexpr bool L16 = MODE != 2 && GPW == 1 && FSGM_SWEEP_L16 != 0;
     constexpr int PF = MODE == 2 ? 2 : (GPW > 1 ? 2 : FSGM_SWEEP_PF);    // rows of C in flight per lane and group
     __shared__ uint4 sDiag[2][2][L16 ? 2 : 1][NCD * LPP];  // [row parity][direction][plane][column][lane-of-pixel]
-    __shared__ uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 1];   // MODE 2: S of the wave's pixels (u16)
+    __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 4];   // MODE 2: S of the wave's pixels (u16, two planes: epi_step.h)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPP, j = lane % LPP;
@@ -304,10 +150,25 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
     auto vox_off = [&](int x, int y) -> uint32_t {               // byte offset of (x,y)'s 16 bytes of this lane
         return (uint32_t)pix_of(x, y) * D + (uint32_t)j * 16;
     };
+    // L16: both planes as ds_read_b128, spelled out -- left to itself the compiler splits the first plane's load into two
+    // ds_read2_b32 (dwords 0,3 and 1,2: it wants registers 0 and 7 of the state first), and dword accesses at a 16-byte
+    // lane stride put eight lanes on every bank: 0.44 conflict cycles per LDS cycle in round 2's counters
+    // (profiles/r02_sq_counters.md; the b128 form reads 0.00 in tools/ubench/counter_calib.hip).  Requests and wait are
+    // separate statements so that a row's reads are in flight during its first DP step.
+    struct LdsPair { u32x4 lo, hi; };
+    auto lds_issue = [&](int par, int dir, int col, LdsPair& v) {
+        const uint32_t addr = (uint32_t)(size_t)&sDiag[par][dir][0][col * LPP + j];
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(v.lo), "=&v"(v.hi) : "v"(addr), "n"(NCD * LPP * 16) : "memory");
+    };
+    auto lds_take = [&](LdsPair& v, uint32_t (&S)[8]) {       // the requests of lds_issue have landed after this
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.lo), "+v"(v.hi) :: "memory");
+        S[0] = v.lo.x; S[1] = v.lo.y; S[2] = v.lo.z; S[3] = v.lo.w; S[4] = v.hi.x; S[5] = v.hi.y; S[6] = v.hi.z; S[7] = v.hi.w;
+    };
     auto lds_get = [&](int par, int dir, int col, uint32_t (&S)[8]) {
         if (L16) {
-            const uint4 lo = sDiag[par][dir][0][col * LPP + j], hi = sDiag[par][dir][L16 ? 1 : 0][col * LPP + j];
-            S[0] = lo.x; S[1] = lo.y; S[2] = lo.z; S[3] = lo.w; S[4] = hi.x; S[5] = hi.y; S[6] = hi.z; S[7] = hi.w;
+            LdsPair v;
+            lds_issue(par, dir, col, v);
+            lds_take(v, S);
         } else {
             unpack_p(sDiag[par][dir][0][col * LPP + j], S);
         }
@@ -379,6 +240,8 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
             const int gx = gx0 + q * PXG;
             const bool own_ok = gx < W;
             uint32_t CP[8], Y[8], YS[8];
+            LdsPair pdl, pdr;
+            if (L16) { lds_issue(par, 0, gx - 1 - base0, pdl); lds_issue(par, 1, gx + 1 - base1, pdr); }    // in flight during the first step
             unpack_c(cOwn[q], CP, P2pk);
 
             // from above (0,+1)                                            calc_cost_sgm.cpp:193-202
@@ -387,7 +250,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
             // from above-left (+1,+1): predecessor column gx-1                        :205-213
             {
                 uint32_t S[8];
-                lds_get(par, 0, gx - 1 - base0, S);
+                if (L16) lds_take(pdl, S); else lds_get(par, 0, gx - 1 - base0, S);
                 step_s<LPP, MASKED>(S, CP, Y, P1pk, P2, sel, mask_dl[q] & tmask);
                 if (own_ok) lds_put(par ^ 1, 0, gx - base0, S);
 #pragma unroll
@@ -396,7 +259,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
             // from above-right (-1,+1): predecessor column gx+1                       :215-225
             {
                 uint32_t S[8];
-                lds_get(par, 1, gx + 1 - base1, S);
+                if (L16) lds_take(pdr, S); else lds_get(par, 1, gx + 1 - base1, S);
                 step_s<LPP, MASKED>(S, CP, Y, P1pk, P2, sel, mask_dr[q] & tmask);
                 if (own_ok) lds_put(par ^ 1, 1, gx - base1, S);
 #pragma unroll
@@ -414,7 +277,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
                 unpack_p(curH[q], E2);
 #pragma unroll
                 for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], 0x00080008u, 0u), pk_add(YS[i], E2[i]));
-                wta_row_record<LPP>(ST, sRow, tid, j, own_ok, a.rec, a.s0, f * (size_t)NP + pix_of(min(gx, W - 1), y));
+                wta_row_record<LPP, NWV * 64>(ST, sRow, tid, j, own_ok, a.rec, a.s0, f * (size_t)NP + pix_of(min(gx, W - 1), y));
             }
         }
         // halo unit: keeps the inward-flowing diagonal correct for the next rows
@@ -522,7 +385,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
     constexpr int PF = MODE == 2 ? 2 : 3;    // rows of C in flight per lane
     constexpr int MARGIN = 2;                // columns outside the image that still run (to settle on the start state)
     __shared__ uint4 sD[2][2][NSLOT * LPP];  // [row parity][0: from-above states, 1: from-above-left states][slot][lane-of-pixel]
-    __shared__ uint32_t sRow[MODE == 2 ? 4 * 64 * 8 : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? 4 * 64 * 8 : 4];
     __shared__ uint32_t sTicket;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -625,7 +488,7 @@ __global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
             unpack_p(curH, E2);
 #pragma unroll
             for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], 0x00080008u, 0u), pk_add(YS[i], E2[i]));
-            wta_row_record<LPP>(ST, sRow, tid, j, inside, a.rec, a.s0, f * (size_t)NP + pix_of(xc, y));
+            wta_row_record<LPP, 256>(ST, sRow, tid, j, inside, a.rec, a.s0, f * (size_t)NP + pix_of(xc, y));
         }
     };
 
@@ -725,7 +588,7 @@ template <int LPP>
 __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs q) {
     constexpr int D = LPP * 16;
     constexpr int PPB = 256 / LPP;
-    __shared__ uint32_t sS[256 * 8];
+    __shared__ __attribute__((aligned(16))) uint32_t sS[256 * 8];     // two planes of 16 bytes per lane (epi_step.h, srow_store)
     const int tid = threadIdx.x;
     const int NP = a.W * a.H;
     const int gp = blockIdx.x * PPB + tid / LPP, j = tid % LPP;
@@ -748,10 +611,9 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
     for (int k = 0; k < 8; k++) ST[k] = pk_sub(pk_mad16(CP[k], nC * 0x10001u, 0u), pk_add(YT[k], E2[k]));
 
     uint32_t key = 0xFFFFFFFFu;
-    uint32_t* row = sS + (size_t)(tid / LPP) * (D / 2) + j * 8;
+    srow_store<256>(sS, tid, ST);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        row[k] = ST[k];
         const uint32_t v0 = ST[k] & 0xFFFF, v1 = ST[k] >> 16;
         const uint32_t d0 = (uint32_t)j * 16 + k, d1 = d0 + 8;
         key = min(key, min((v0 << 8) | d0, (v1 << 8) | d1));
@@ -764,11 +626,11 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
     __syncthreads();
     if (j == 0 && valid) {
         const uint32_t best = key & 0xFF, minc = key >> 8;
-        const uint16_t* srow = (const uint16_t*)(sS + (size_t)(tid / LPP) * (D / 2));
+        const uint16_t* srow = (const uint16_t*)sS;
         uint32_t c_1 = 0, c1 = 0;
         if (a.subpixel && best > 1) {
-            c_1 = srow[srow_index(best - 1)];
-            if (best + 1 < (uint32_t)D) c1 = srow[srow_index(best + 1)];
+            c_1 = srow[srow_index<256>(tid, best - 1)];
+            if (best + 1 < (uint32_t)D) c1 = srow[srow_index<256>(tid, best + 1)];
             else if (p + 1 < NP) {                                           // next pixel's d=0 (:296): byte 0 of its lane 0 in every volume
                 const size_t nb = f * q.v_frame_stride + (size_t)(p + 1) * D;
                 const size_t nh = f * q.lh_frame_stride + (size_t)(p + 1) * D;
@@ -851,7 +713,7 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
 template <int LPP, int AXIS, bool FINAL>
 __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        // two waves per SIMD: at most 256 registers
     constexpr int PXW = 64 / LPP, D = LPP * 16, TC = HP_TC;
-    __shared__ uint32_t sRow[FINAL ? 4 * 64 * 8 : 1];            // FINAL: S of the wave's pixels (u16)
+    __shared__ __attribute__((aligned(16))) uint32_t sRow[FINAL ? 4 * 64 * 8 : 4];            // FINAL: S of the wave's pixels (u16)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPP, j = lane % LPP;
     const int W = a.W, NP = a.W * a.H;
@@ -930,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
 #pragma unroll
                 for (int q = 0; q < 8; q++) ST[q] = pk_sub(pk_mad16(CP[q], nC, 0u), pk_add(pk_add(Y[q], E2[q]), E3[q]));
                 const int ap = AXIS ? x * W + l : l * W + x;     // pixel index (wave-uniform validity: x < len)
-                wta_row_record<LPP>(ST, sRow, tid, j, own_ok && (!EDGE || x < len), a.rec, a.s0, f * (size_t)NP + (size_t)min(ap, NP - 1));
+                wta_row_record<LPP, 256>(ST, sRow, tid, j, own_ok && (!EDGE || x < len), a.rec, a.s0, f * (size_t)NP + (size_t)min(ap, NP - 1));
             }
         }
 #pragma unroll

@@ -138,7 +138,8 @@ class EpiPlan:
         check(self.lib.fsgm_epi_plan_set_penalties(self._h, int(P1), int(P2), float(vMax)))
 
     def set_agg_mode(self, mode):
-        """0 auto, 1 per-direction line kernels, 2 fused pipeline when eligible, 3 parallel sweeps (8 paths) when eligible."""
+        """0 auto, 1 per-direction line kernels, 2 fused pipeline when eligible, 3 parallel sweeps (8 paths) when eligible,
+        4 band sweeps (all four paths of a pass in one sweep, one workgroup per frame: very large batches)."""
         check(self.lib.fsgm_epi_plan_set_agg_mode(self._h, int(mode)))
 
     def upload(self, frame, I1, I2, pd0, nd, off):
@@ -153,6 +154,10 @@ class EpiPlan:
         if Cvol.dtype != np.uint8 or Cvol.shape != (self.H, self.W, self.D):
             raise TypeError(f"C must be uint8 of shape {(self.H, self.W, self.D)}")
         check(self.lib.fsgm_epi_plan_upload_cost(self._h, frame, ptr(Cvol)))
+
+    def copy_cost(self, dst, src, roll_cols=0):
+        """Resident cost volume of frame dst <- frame src, columns rotated by roll_cols (device to device)."""
+        check(self.lib.fsgm_epi_plan_copy_cost(self._h, int(dst), int(src), int(roll_cols)))
 
     def upload_offset(self, frame, off):
         off = _f64(off, (self.H, self.W), "offsetFromPosD0")

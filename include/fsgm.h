@@ -113,7 +113,9 @@ fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t
 /* Aggregation strategy: 0 = auto, 1 = the per-direction line kernels, 2 = the fused pipeline whenever eligible
  * (8 paths: horizontal pair + down sweep + final up sweep with the WTA inside -- D = 16<<k, no-wrap penalties with
  * P1 <= P2 and 3*P2 <= 255; the shipped 4 paths: the pair kernels -- 2*P2 <= 255), 3 = 8 paths only: the down and the
- * up sweep side by side and a WTA kernel over the three sums (half the latency of 2, 3 B per voxel more traffic).
+ * up sweep side by side and a WTA kernel over the three sums (half the latency of 2, 3 B per voxel more traffic),
+ * 4 = the band sweeps (epi_band.hip: all four paths of a raster pass in one sweep, one workgroup per frame, for batches of
+ * hundreds of frames; D = 16<<k, no-wrap penalties with P1 <= P2 <= 127).
  * Auto, 8 paths: line kernels below 5 frames, 3 below 18, 2 from there; 4 paths: line kernels below 9 frames, then 2
  * (the measured crossovers at 1242x375x128).  Results are identical. */
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* plan, int32_t mode);
@@ -123,6 +125,9 @@ fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* plan, int32_t frame, const uint8
                                  const double* normDir, const double* offset);
 /* aggregation-only use: put a ready cost volume into slot `frame` (skips FSGM_STAGE_COST) */
 fsgm_status fsgm_epi_plan_upload_cost(fsgm_epi_plan* plan, int32_t frame, const uint8_t* C);
+/* resident cost volume of frame dst <- frame src with the columns rotated by roll_cols (dst[y][(x + roll) % W] = src[y][x]),
+ * device to device on the plan's stream: fills a large batch with distinct volumes without a PCIe transfer each (bench.py) */
+fsgm_status fsgm_epi_plan_copy_cost(fsgm_epi_plan* plan, int32_t dst, int32_t src, int32_t roll_cols);
 /* offset map only (needed by the vz->disp step when the cost stage is skipped) */
 fsgm_status fsgm_epi_plan_upload_offset(fsgm_epi_plan* plan, int32_t frame, const double* offset);
 fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* plan, int32_t stages);

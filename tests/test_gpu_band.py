@@ -1,0 +1,157 @@
+"""GPU parity tests of the band sweeps (fsgm_amd/csrc/epi_band.hip): all four paths of a raster pass of
+calc_cost_sgm.cpp:86-257 in one sweep over the skewed coordinate u = x + 2y (8 paths) / u = x + y (the shipped 4 paths,
+:104), one workgroup per frame, band after band.  Against the CPU oracle: S of every voxel (the kernel's debug tap),
+bestD and minC of every pixel; shapes chosen around the band height (64 rows at D = 128, 128 at D = 64, 512 at D = 16),
+the image borders (path starts, :152-180), one-pixel-wide / -high frames, penalties with and without the 9th-bit plane
+(4*P2 > 255)."""
+import numpy as np
+import pytest
+
+from fsgm_amd import synth, EpiPlan
+from fsgm_amd._lib import STAGE_AGGREGATE, STAGE_WTA
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(oracle, plan, vols, off, P1, P2, paths, W, H, D, taps=(0,)):
+    for f, v in enumerate(vols):
+        S = oracle.epi_aggregate(v, P1, P2, paths)
+        bd, mc = oracle.epi_wta(S, W, H, D, 1)
+        gbd, gmc = plan.download(f)
+        np.testing.assert_array_equal(gmc, mc, err_msg=f"frame {f} minC")
+        np.testing.assert_array_equal(gbd, oracle.epi_vz_to_disp(bd, off, 0.3, D + 1), err_msg=f"frame {f} bestD")
+        if f in taps:
+            np.testing.assert_array_equal(plan.download_sum(f), S[:-1].reshape(H, W, D), err_msg=f"frame {f} S")
+
+
+SHAPES = [
+    # W, H, D, frames
+    (40, 30, 128, 2),        # one band, partly filled
+    (37, 64, 128, 1),        # exactly one band
+    (29, 65, 128, 2),        # one row into the second band
+    (130, 150, 128, 2),      # three bands, the last partial
+    (70, 129, 64, 1),        # D = 64: bands of 128 rows
+    (33, 260, 32, 1),        # D = 32: bands of 256 rows
+    (21, 530, 16, 1),        # D = 16: bands of 512 rows
+    (50, 20, 256, 2),        # D = 256: bands of 32 rows... still one band
+    (45, 70, 256, 1),        # D = 256, three bands
+    (1, 9, 128, 1), (9, 1, 128, 2), (1, 1, 64, 1), (2, 2, 128, 1), (3, 140, 128, 1), (140, 3, 64, 1),
+    (320, 240, 64, 1),       # BASELINE configs[1] shape
+]
+
+
+@pytest.mark.parametrize("paths", [8, 4])
+@pytest.mark.parametrize("W,H,D,B", SHAPES)
+def test_band_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, paths):
+    vols = [synth.cost_volume(W, H, D, seed=W * 3 + H + f, cmax=24) for f in range(B)]
+    for v in vols:
+        v[:, ::5, :] = 0                                     # strong structure: paths carry information far
+    _, _, off = synth.epi_maps(W, H, "general", seed=3)
+    with EpiPlan(W, H, D, B, paths=paths) as plan:
+        plan.set_penalties(6, 64, 0.3)                       # 4 * P2 > 255: the first pass's sums need their 9th bits
+        for f in range(B):
+            plan.upload_cost(f, vols[f])
+            plan.upload_offset(f, off)
+        plan.set_agg_mode(4)
+        assert plan.kernel_name == "band16/nowrap"
+        for _ in range(2):                                   # twice: the hand-off buffer and the volumes are reused
+            plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        _check(oracle, plan, vols, off, 6, 64, paths, W, H, D, taps=(0, B - 1))
+
+
+@pytest.mark.parametrize("paths", [8, 4])
+@pytest.mark.parametrize("P1,P2,cmax", [(6, 32, 24), (0, 0, 24), (10, 10, 60), (3, 63, 24), (6, 85, 24), (20, 100, 50), (1, 127, 0)])
+def test_band_sweeps_penalties(gpu_lib, oracle, P1, P2, cmax, paths):
+    """With and without the bit plane (4*P2 <= 255 / > 255), P1 = P2, zero penalties, the largest P2 the bytes hold."""
+    W, H, D, B = 61, 90, 128, 2
+    vols = [synth.cost_volume(W, H, D, seed=P2 + f, cmax=cmax) for f in range(B)]
+    _, _, off = synth.epi_maps(W, H, "axis")
+    with EpiPlan(W, H, D, B, paths=paths) as plan:
+        plan.set_penalties(P1, P2, 0.3)
+        for f in range(B):
+            plan.upload_cost(f, vols[f])
+            plan.upload_offset(f, off)
+        plan.set_agg_mode(4)
+        assert plan.kernel_name == "band16/nowrap"
+        plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        _check(oracle, plan, vols, off, P1, P2, paths, W, H, D, taps=(0,))
+
+
+def test_band_sweeps_fall_back_outside_their_range(gpu_lib):
+    """Wrapping penalties, P1 > P2, P2 > 127 or a D that is not 16 << k: mode 4 leaves the line kernels in place."""
+    with EpiPlan(20, 10, 128, 1, paths=8) as plan:
+        plan.set_agg_mode(4)
+        plan.set_penalties(6, 64, 0.3)
+        assert plan.kernel_name == "band16/nowrap"
+        plan.set_penalties(100, 200, 0.3)
+        assert plan.kernel_name == "packed16/wrap"
+        plan.set_penalties(70, 64, 0.3)
+        assert plan.kernel_name == "packed16/nowrap"
+        plan.set_penalties(6, 128, 0.3)
+        assert plan.kernel_name != "band16/nowrap"
+    with EpiPlan(20, 10, 20, 1, paths=8) as plan:
+        plan.set_agg_mode(4)
+        assert plan.kernel_name == "generic"
+
+
+def test_band_sweeps_whole_mex_and_batch_copy(gpu_lib, oracle):
+    """All stages through the band pipeline (cost stage feeding it), and fsgm_epi_plan_copy_cost's rotated copies."""
+    W, H, D, B = 96, 70, 128, 3
+    I1, I2 = synth.image_pair(W, H, D, seed=12)
+    pd0, nd, off = synth.epi_maps(W, H, "general", seed=13)
+    for paths in (8, 4):
+        bd, mc = oracle.calc_cost_sgm(I1, I2, D, 0.3, pd0, nd, off, 6, 64, paths)
+        with EpiPlan(W, H, D, B, paths=paths) as plan:
+            plan.set_penalties(6, 64, 0.3)
+            for f in range(B):
+                plan.upload(f, I1, I2, pd0, nd, off)
+            plan.set_agg_mode(4)
+            plan.run()
+            assert plan.kernel_name == "band16/nowrap"
+            for f in range(B):
+                gbd, gmc = plan.download(f)
+                np.testing.assert_array_equal(gmc, mc)
+                np.testing.assert_array_equal(gbd, bd)
+    Cv = synth.cost_volume(W, H, D, seed=5, cmax=24)
+    with EpiPlan(W, H, D, B, paths=8) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        plan.upload_cost(0, Cv)
+        plan.copy_cost(1, 0, 37)
+        plan.copy_cost(2, 0, -5)
+        for f in range(B):
+            plan.upload_offset(f, off)
+        plan.set_agg_mode(4)
+        plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        np.testing.assert_array_equal(plan.download_cost(1), np.roll(Cv, 37, axis=1))
+        np.testing.assert_array_equal(plan.download_cost(2), np.roll(Cv, -5, axis=1))
+        _check(oracle, plan, [Cv, np.ascontiguousarray(np.roll(Cv, 37, axis=1)), np.ascontiguousarray(np.roll(Cv, -5, axis=1))],
+               off, 6, 64, 8, W, H, D, taps=())
+
+
+def test_band_sweeps_kitti_shape_against_the_line_kernels_and_the_oracle(gpu_lib, oracle):
+    """1242x375x128, 8 and 4 paths: six bands of 64 rows, 1368-step walks; frame 0 against the oracle (S of every voxel),
+    every frame against the line kernels on a second plan."""
+    W, H, D, B = 1242, 375, 128, 3
+    _, _, off = synth.epi_maps(W, H, "axis")
+    vols = [synth.cost_volume(W, H, D, seed=900 + f, cmax=24) for f in range(B)]
+    for paths in (8, 4):
+        with EpiPlan(W, H, D, B, paths=paths) as plan, EpiPlan(W, H, D, B, paths=paths) as ref:
+            for pl in (plan, ref):
+                pl.set_penalties(6, 64, 0.3)
+                for f in range(B):
+                    pl.upload_cost(f, vols[f])
+                    pl.upload_offset(f, off)
+            plan.set_agg_mode(4)
+            ref.set_agg_mode(1)
+            plan.run(STAGE_AGGREGATE | STAGE_WTA)
+            ref.run(STAGE_AGGREGATE | STAGE_WTA)
+            assert plan.kernel_name == "band16/nowrap" and ref.kernel_name == "packed16/nowrap"
+            for f in range(B):
+                a, b = plan.download(f), ref.download(f)
+                np.testing.assert_array_equal(a[1], b[1], err_msg=f"{paths} paths, frame {f} minC")
+                np.testing.assert_array_equal(a[0], b[0], err_msg=f"{paths} paths, frame {f} bestD")
+            S = oracle.epi_aggregate(vols[0], 6, 64, paths)
+            np.testing.assert_array_equal(plan.download_sum(0), S[:-1].reshape(H, W, D), err_msg=f"{paths} paths, S")
+            bd, mc = oracle.epi_wta(S, W, H, D, 1)
+            np.testing.assert_array_equal(plan.download(0)[1], mc)
+            np.testing.assert_array_equal(plan.download(0)[0], oracle.epi_vz_to_disp(bd, off, 0.3, D + 1))

@@ -31,10 +31,11 @@ for leg in $LEGS; do
         batch1)      A="--steps 2 --warmup 1 --no-cpu-baseline --frames-per-gpu 1" ;;
         pyramid3)    A="--steps 4 --workload pyramid3" ;;
         pyramid3_ng) A="--steps 4 --workload pyramid3_ng" ;;
-        *)           A="$leg" ;;
+        *)           A="${leg//%/ }" ;;                 # a custom leg: bench.py arguments with % in place of spaces
     esac
-    rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d gpurun_out/pmc_sq/${leg}_1 -- python3 bench.py $A > gpurun_out/pmc_sq/${leg}_1.log 2>&1
-    rocprofv3 --kernel-trace --pmc $C2 --output-format csv -d gpurun_out/pmc_sq/${leg}_2 -- python3 bench.py $A > gpurun_out/pmc_sq/${leg}_2.log 2>&1
+    tag=$(echo "$leg" | tr -c 'A-Za-z0-9\n' '_' | cut -c1-40)
+    rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d gpurun_out/pmc_sq/${tag}_1 -- python3 bench.py $A > gpurun_out/pmc_sq/${tag}_1.log 2>&1
+    rocprofv3 --kernel-trace --pmc $C2 --output-format csv -d gpurun_out/pmc_sq/${tag}_2 -- python3 bench.py $A > gpurun_out/pmc_sq/${tag}_2.log 2>&1
     echo "leg $leg done"
 done
 python3 - <<'PY' | tee gpurun_out/sq_counters.md
