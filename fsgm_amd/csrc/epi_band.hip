@@ -47,7 +47,16 @@
 namespace fsgm {
 
 #ifndef FSGM_BAND_PF
-#define FSGM_BAND_PF 2          // steps of C (and, final pass, Y_dn) in flight per lane (A/B knob)
+#define FSGM_BAND_PF 2          // steps of C in flight per lane, first pass (A/B knob)
+#endif
+#ifndef FSGM_BAND_PF2
+#define FSGM_BAND_PF2 1         // steps of C, Y_dn and its bit plane in flight per lane, final pass (A/B knob; 2 spills registers inside the loop: 57.4 -> 45.8 ms per 512 frames with 1)
+#endif
+#ifndef FSGM_BAND_WAVES
+#define FSGM_BAND_WAVES 8        // waves per band workgroup (8: 64-row bands at D = 128, two workgroups per CU)
+#endif
+#ifndef FSGM_BAND_MINW
+#define FSGM_BAND_MINW 4         // waves per SIMD the register allocation must allow (A/B knob: 3 with 6-wave workgroups)
 #endif
 
 // 9th bits of the eight packed-u16 registers of a lane -> one dword (bit k of byte b = bit 8 of register 2k + (b&1), half b>>1)
@@ -68,8 +77,8 @@ __device__ __forceinline__ void unpack_p9(const uint4 v, const uint32_t bits, ui
     }
 }
 
-template <int LPP, int MODE, int NWV, int PATHS, bool BITS>
-__global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
+template <int LPP, int MODE, int NWV, int PATHS, bool BITS, bool TAP>
+__global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs a) {
     constexpr bool UP = MODE != 0;
     constexpr bool P8 = PATHS == 8;
     constexpr int PXG = 64 / LPP;            // rows per wave
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
     constexpr int D = LPP * 16;
     constexpr int SKEW = P8 ? 2 : 1;         // u = x + SKEW * (row in band)
     constexpr int NST = P8 ? 3 : 1;          // states that cross rows: 0 from above, 1 from above-left, 2 from above-right
-    constexpr int PF = FSGM_BAND_PF;
+    constexpr int PF = MODE == 2 ? FSGM_BAND_PF2 : FSGM_BAND_PF;
     __shared__ uint4 sSt[2][NST][(R + 1) * LPP];              // [step parity][state][row slot (row + 1; slot 0 = the row above the band)][lane of pixel]
     __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 4];   // final pass: S of the wave's pixels (u16, two planes: epi_step.h)
 
@@ -88,8 +97,11 @@ __global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
     const size_t f = blockIdx.x;
     const uint8_t* __restrict__ Cf = a.C + f * a.c_frame_stride;
     uint8_t* __restrict__ Yf = a.Y + f * a.y_frame_stride;
-    uint32_t* __restrict__ Bf = BITS ? a.Yb + f * a.yb_frame_stride : nullptr;
-    uint4* __restrict__ Ef = a.edge + f * a.edge_frame_stride;        // [W][NST][LPP]
+    uint8_t* __restrict__ Bf = BITS ? (uint8_t*)(a.Yb + f * a.yb_frame_stride) : nullptr;     // [NP][LPP] dwords
+    uint8_t* __restrict__ Ef = (uint8_t*)(a.edge + f * a.edge_frame_stride);                  // [W][NST][LPP] uint4
+    uint8_t* __restrict__ recb = MODE == 2 ? (uint8_t*)(a.rec + f * (size_t)NP) : nullptr;
+    uint8_t* __restrict__ s0b = MODE == 2 ? (uint8_t*)(a.s0 + f * (size_t)NP) : nullptr;
+    // every global access below is a wave-uniform base + a 32-bit byte offset per lane (no 64-bit address registers)
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
     const uint4 startP = make_uint4(P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u);
     const LaneSel sel = lane_sel<LPP>(j);
@@ -117,11 +129,11 @@ __global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
             const int x = min(max(u - SKEW * r, 0), W - 1);
             return (uint32_t)pix_of(x, yc) * D + (uint32_t)j * 16;
         };
-        auto bit_off = [&](int u) -> uint32_t {
+        auto bit_off = [&](int u) -> uint32_t {                // byte offset of this lane's dword of the bit plane
             const int x = min(max(u - SKEW * r, 0), W - 1);
-            return (uint32_t)pix_of(x, yc) * LPP + (uint32_t)j;
+            return ((uint32_t)pix_of(x, yc) * LPP + (uint32_t)j) * 4u;
         };
-        auto edge_at = [&](int x) -> const uint4* { return Ef + (size_t)min(max(x, 0), W - 1) * (NST * LPP) + elane; };
+        auto edge_at = [&](int x) -> const uint8_t* { return Ef + ((uint32_t)min(max(x, 0), W - 1) * (NST * LPP) + (uint32_t)elane) * 16u; };
 
         uint32_t FS[8];                                        // from the left: stays in these lanes
 #pragma unroll
@@ -129,8 +141,8 @@ __global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
         // from above / from above-left of the row above, read one / two steps before they are used
         uint4 hU = startP, hD1 = startP, hD2 = startP;
         if (P8 && have_above && r == 0) {                      // row 0: column 0 of the band above ("read at step -1")
-            hU = load_nt(Ef + 0 * LPP + j);
-            hD1 = load_nt(Ef + 1 * LPP + j);
+            hU = load_nt(Ef + (uint32_t)(0 * LPP + j) * 16u);
+            hD1 = load_nt(Ef + (uint32_t)(1 * LPP + j) * 16u);
         }
         if (loader) sSt[1][elane / LPP][elane % LPP] = load_nt(edge_at(SKEW - 1));     // what row 0 reads at step 0
         uint4 ringC[PF], ringY[MODE == 2 ? PF : 1];
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
         for (int i = 0; i < PF; i++) {
             const uint32_t off = vox_off(i);
             ringC[i] = *(const uint4*)(Cf + off);
-            if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = Bf[bit_off(i)]; }
+            if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = *(const uint32_t*)(Bf + bit_off(i)); }
         }
         if (loader) nextE = load_nt(edge_at(SKEW));
         __syncthreads();
@@ -167,6 +179,13 @@ __global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
                     for (int i = 0; i < 8; i++) FS[i] = P2pk;
                 }
                 step_s<LPP, EDGE>(FS, CP, YS, P1pk, P2, sel, st ? 0u : 0xFFFFu);
+            }
+            if (MODE == 2) {
+                // the first pass's sum joins the running sum right away: its five registers are free for the rest of the step
+                uint32_t E2[8];
+                if (BITS) unpack_p9(cy, cb, E2); else unpack_p(cy, E2);
+#pragma unroll
+                for (int i = 0; i < 8; i++) YS[i] += E2[i];
             }
             __builtin_amdgcn_sched_barrier(0);
             // from above (0,-1): :193-202
@@ -220,24 +239,24 @@ __global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
             }
             // the band's last row hands its states to the band below, by image column
             if (!last_band && r == R - 1 && inside) {
-                uint4* o = Ef + (size_t)xc * (NST * LPP) + j;
-                o[0] = newU;
-                if constexpr (P8) { o[LPP] = newD; o[2 * LPP] = newR; }
+                uint8_t* o = Ef + ((uint32_t)xc * (NST * LPP) + (uint32_t)j) * 16u;
+                *(uint4*)o = newU;
+                if constexpr (P8) { *(uint4*)(o + LPP * 16) = newD; *(uint4*)(o + 2 * LPP * 16) = newR; }
             }
             if (MODE != 2) {
                 // the sum of this pass's y (:227-232): low bytes + 9th bits
                 if (inside) {
-                    vol_store(Yf + (uint32_t)pix_of(xc, yc) * D + (uint32_t)j * 16, pack_p(YS));
-                    if (BITS) Bf[(uint32_t)pix_of(xc, yc) * LPP + j] = pack_hi_bits(YS);
+                    const uint32_t px = (uint32_t)pix_of(xc, yc);
+                    vol_store(Yf + px * D + (uint32_t)j * 16, pack_p(YS));
+                    if (BITS) *(uint32_t*)(Bf + (px * LPP + (uint32_t)j) * 4u) = pack_hi_bits(YS);
                 }
             } else {
                 // S = PATHS*(C + P2) - (this pass's y + the first pass's), WTA on the spot (:227-232, :259-275)
-                uint32_t E2[8], ST[8];
-                if (BITS) unpack_p9(cy, cb, E2); else unpack_p(cy, E2);
+                uint32_t ST[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], (uint32_t)PATHS * 0x10001u, 0u), pk_add(YS[i], E2[i]));
-                wta_row_record<LPP, NWV * 64>(ST, sRow, tid, j, inside, a.rec, a.s0, f * (size_t)NP + pix_of(xc, yc));
-                if (a.Sdbg && inside) {                        // debug tap (block-uniform test): S in natural d order
+                for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], (uint32_t)PATHS * 0x10001u, 0u), YS[i]);
+                wta_row_record_at<LPP, NWV * 64>(ST, sRow, tid, j, inside, recb, s0b, (uint32_t)pix_of(xc, yc));
+                if (TAP && inside) {                           // debug tap (an instantiation of its own): S in natural d order
                     uint32_t* o = a.Sdbg + (f * (size_t)NP + pix_of(xc, yc)) * D + j * 16;
 #pragma unroll
                     for (int i = 0; i < 8; i++) { o[i] = ST[i] & 0xFFFFu; o[i + 8] = ST[i] >> 16; }
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
                 const uint32_t cb = ringB[MODE == 2 && BITS ? i : 0];
                 const uint32_t off = vox_off(u + PF);
                 ringC[i] = *(const uint4*)(Cf + off);
-                if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = Bf[bit_off(u + PF)]; }
+                if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = *(const uint32_t*)(Bf + bit_off(u + PF)); }
                 step(u, cw, cy, cb);
             }
         }
@@ -284,10 +303,6 @@ __global__ __launch_bounds__(NWV * 64, 4) void band_kernel(BandArgs a) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-#ifndef FSGM_BAND_WAVES
-#define FSGM_BAND_WAVES 8        // waves per band workgroup (8: 64-row bands at D = 128, two workgroups per CU)
-#endif
-
 size_t band_edge_uint4s(int W, int D, int paths) { const int lpp = agg_packed_lpp(D); return (size_t)W * (paths == 8 ? 3 : 1) * lpp; }   // per frame
 size_t band_bits_u32s(int W, int H, int D) { return (size_t)W * H * agg_packed_lpp(D); }                                                 // per frame
 bool band_needs_bits(int paths, int P2) { return paths == 8 && 4 * P2 > 255; }
@@ -298,9 +313,15 @@ static void launch_band_t(hipStream_t st, const BandArgs& a, int frames, int pat
     constexpr int NWV = FSGM_BAND_WAVES;
     const bool bits = band_needs_bits(paths, a.P2);
     dim3 grid((unsigned)frames), block(NWV * 64);
-    if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false>), grid, block, 0, st, a);
-    else if (!bits)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, false>), grid, block, 0, st, a);
-    else             hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, true>), grid, block, 0, st, a);
+    if (MODE == 2 && a.Sdbg) {                               // the S debug tap: instantiations of their own, none of it in the product kernels
+        if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false, MODE == 2>), grid, block, 0, st, a);
+        else if (!bits)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, false, MODE == 2>), grid, block, 0, st, a);
+        else             hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, true, MODE == 2>), grid, block, 0, st, a);
+        return;
+    }
+    if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false, false>), grid, block, 0, st, a);
+    else if (!bits)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, false, false>), grid, block, 0, st, a);
+    else             hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, true, false>), grid, block, 0, st, a);
 }
 
 // One whole pass of `frames` frames: mode 0 = first pass -> Y (+ bit plane), mode 2 = second pass + WTA records

@@ -149,9 +149,11 @@ __device__ __forceinline__ uint32_t srow_index(int tid0, uint32_t d) {
     return ((((i >> 2) * NT + t) * 4 + (i & 3u)) << 1) + ((d >> 3) & 1u);
 }
 
+// recb / s0b: byte pointers to the frame's records / S[0] words (wave-uniform), pix: the pixel's index in the frame -- 32-bit
+// offsets from uniform bases keep the stores' addresses out of 64-bit vector registers
 template <int LPP, int NT>
-__device__ __forceinline__ void wta_row_record(const uint32_t (&ST)[8], uint32_t* sRow, int tid, int j,
-                                               bool ok, uint4* rec, uint16_t* s0, size_t idx) {
+__device__ __forceinline__ void wta_row_record_at(const uint32_t (&ST)[8], uint32_t* sRow, int tid, int j,
+                                                  bool ok, uint8_t* recb, uint8_t* s0b, uint32_t pix) {
     constexpr int D = LPP * 16;
     srow_store<NT>(sRow, tid, ST);
     uint32_t kmin = 0xFFFFFFFFu;
@@ -166,9 +168,15 @@ __device__ __forceinline__ void wta_row_record(const uint32_t (&ST)[8], uint32_t
         const uint16_t* srow = (const uint16_t*)sRow;
         const uint32_t c_1 = best > 0 ? srow[srow_index<NT>(tid, best - 1)] : 0u;
         const uint32_t c1 = best + 1 < (uint32_t)D ? srow[srow_index<NT>(tid, best + 1)] : 0u;   // best == D-1: the finish kernel takes the next pixel's S[0]
-        rec[idx] = make_uint4(best, minc, c_1, c1);
-        s0[idx] = (uint16_t)srow[srow_index<NT>(tid, 0)];
+        *(uint4*)(recb + pix * 16u) = make_uint4(best, minc, c_1, c1);
+        *(uint16_t*)(s0b + pix * 2u) = (uint16_t)srow[srow_index<NT>(tid, 0)];
     }
+}
+
+template <int LPP, int NT>
+__device__ __forceinline__ void wta_row_record(const uint32_t (&ST)[8], uint32_t* sRow, int tid, int j,
+                                               bool ok, uint4* rec, uint16_t* s0, size_t idx) {
+    wta_row_record_at<LPP, NT>(ST, sRow, tid, j, ok, (uint8_t*)(rec + idx), (uint8_t*)(s0 + idx), 0u);
 }
 
 }  // namespace
