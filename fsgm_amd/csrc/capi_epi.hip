@@ -114,7 +114,7 @@ static void select_kernel(fsgm_epi_plan* p) {
     // the excess sum of a pair fits a byte)
     if (fusable && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
     // very large batches (or mode 4): the band sweeps
-    if (fusable && band_ok(p->D, p->prm.paths, p->P2) && (p->agg_mode == 4 || (p->agg_mode == 0 && p->batch >= band_min_batch()))) {
+    if (fusable && band_ok(p->D, p->prm.paths, p->P1, p->P2, cm) && (p->agg_mode == 4 || (p->agg_mode == 0 && p->batch >= band_min_batch()))) {
         p->kernel_kind = AGG_BAND;
         p->sweep_par = false;
     }

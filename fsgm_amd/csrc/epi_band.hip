@@ -52,6 +52,9 @@ namespace fsgm {
 #ifndef FSGM_BAND_PF2
 #define FSGM_BAND_PF2 1         // steps of C, Y_dn and its bit plane in flight per lane, final pass (A/B knob; 2 spills registers inside the loop: 57.4 -> 45.8 ms per 512 frames with 1)
 #endif
+#ifndef FSGM_BAND_PF4
+#define FSGM_BAND_PF4 3         // the same for both passes of the 4-path form (A/B knob; 1 / 2 / 3 / 4: 31.5 / 30.0 / 28.9 / 29.1 ms per 512 frames)
+#endif
 #ifndef FSGM_BAND_WAVES
 #define FSGM_BAND_WAVES 8        // waves per band workgroup (8: 64-row bands at D = 128, two workgroups per CU)
 #endif
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
     constexpr int D = LPP * 16;
     constexpr int SKEW = P8 ? 2 : 1;         // u = x + SKEW * (row in band)
     constexpr int NST = P8 ? 3 : 1;          // states that cross rows: 0 from above, 1 from above-left, 2 from above-right
-    constexpr int PF = MODE == 2 ? FSGM_BAND_PF2 : FSGM_BAND_PF;
+    constexpr int PF = P8 ? (MODE == 2 ? FSGM_BAND_PF2 : FSGM_BAND_PF) : FSGM_BAND_PF4;   // 4 paths: half the registers, twice the bytes per instruction
     __shared__ uint4 sSt[2][NST][(R + 1) * LPP];              // [step parity][state][row slot (row + 1; slot 0 = the row above the band)][lane of pixel]
     __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 4];   // final pass: S of the wave's pixels (u16, two planes: epi_step.h)
 
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
     uint8_t* __restrict__ s0b = MODE == 2 ? (uint8_t*)(a.s0 + f * (size_t)NP) : nullptr;
     // every global access below is a wave-uniform base + a 32-bit byte offset per lane (no 64-bit address registers)
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const uint32_t Bpk = (P2 + (uint32_t)a.P1) * 0x10001u;     // the costs' bias in the step's variable (epi_step.h, step_b): P2 + P1
     const uint4 startP = make_uint4(P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u);
     const LaneSel sel = lane_sel<LPP>(j);
     const int elane = min(lane, NST * LPP - 1);                // wave 0: lane = state * LPP + lane-of-pixel of the hand-off words
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             // the from-above one); the other two are for the coming steps and are read further down, when registers are free
             const uint4 nNow = sSt[par ^ 1][P8 ? 2 : 0][r * LPP + j];
             uint32_t CP[8], Y[8], YS[8], S[8];
-            unpack_c(cw, CP, P2pk);
+            unpack_cb(cw, CP, Bpk);
             const bool top = EDGE && y == 0;                   // row 0 of the frame: every path from above starts (:152-180)
             // from the left (-1,0): :183-191
             {
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 #pragma unroll
                     for (int i = 0; i < 8; i++) FS[i] = P2pk;
                 }
-                step_s<LPP, EDGE>(FS, CP, YS, P1pk, P2, sel, st ? 0u : 0xFFFFu);
+                step_b<LPP, EDGE>(FS, CP, YS, P1pk, P2, sel, st ? 0u : 0xFFFFu);
             }
             if (MODE == 2) {
                 // the first pass's sum joins the running sum right away: its five registers are free for the rest of the step
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 #pragma unroll
                     for (int i = 0; i < 8; i++) S[i] = P2pk;
                 }
-                step_s<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, top ? 0u : 0xFFFFu);
+                step_b<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, top ? 0u : 0xFFFFu);
                 newU = pack_p(S);
                 sSt[par][0][(r + 1) * LPP + j] = newU;
 #pragma unroll
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 #pragma unroll
                         for (int i = 0; i < 8; i++) S[i] = P2pk;
                     }
-                    step_s<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, st ? 0u : 0xFFFFu);
+                    step_b<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, st ? 0u : 0xFFFFu);
                     newD = pack_p(S);
                     sSt[par][1][(r + 1) * LPP + j] = newD;
 #pragma unroll
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 #pragma unroll
                         for (int i = 0; i < 8; i++) S[i] = P2pk;
                     }
-                    step_s<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, st ? 0u : 0xFFFFu);
+                    step_b<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, st ? 0u : 0xFFFFu);
                     newR = pack_p(S);
                     sSt[par][2][(r + 1) * LPP + j] = newR;
 #pragma unroll
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
                 // S = PATHS*(C + P2) - (this pass's y + the first pass's), WTA on the spot (:227-232, :259-275)
                 uint32_t ST[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], (uint32_t)PATHS * 0x10001u, 0u), YS[i]);
-                wta_row_record_at<LPP, NWV * 64>(ST, sRow, tid, j, inside, recb, s0b, (uint32_t)pix_of(xc, yc));
+                for (int i = 0; i < 8; i++) ST[i] = pk_mad16(CP[i], (uint32_t)PATHS * 0x10001u, 0u) - YS[i];    // the P1 biases of CP and YS cancel; no borrow between the halves
+                wta_row_record_at<LPP, NWV * 64, true>(ST, sRow, tid, j, inside, recb, s0b, (uint32_t)pix_of(xc, yc));
                 if (TAP && inside) {                           // debug tap (an instantiation of its own): S in natural d order
                     uint32_t* o = a.Sdbg + (f * (size_t)NP + pix_of(xc, yc)) * D + j * 16;
 #pragma unroll
@@ -305,13 +309,18 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 // ---------------------------------------------------------------------------------------------
 size_t band_edge_uint4s(int W, int D, int paths) { const int lpp = agg_packed_lpp(D); return (size_t)W * (paths == 8 ? 3 : 1) * lpp; }   // per frame
 size_t band_bits_u32s(int W, int H, int D) { return (size_t)W * H * agg_packed_lpp(D); }                                                 // per frame
-bool band_needs_bits(int paths, int P2) { return paths == 8 && 4 * P2 > 255; }
-bool band_ok(int D, int paths, int P2) { return agg_packed_lpp(D) != 0 && P2 <= 127 && (paths == 8 || paths == 4); }
+// the first pass's sum of four (y + P1) needs a 9th bit above 255
+bool band_needs_bits(int paths, int P1, int P2) { return paths == 8 && 4 * (P1 + P2) > 255; }
+// D = 16 << k; P1 + P2 <= 127: states and the biased y as bytes, two / four of them summed in 8 / 9 bits;
+// 16 * paths * (cmax + P2 + P1) + 15 < 0x7C00: the WTA's packed keys stay below the fp16 infinity pattern (epi_step.h)
+bool band_ok(int D, int paths, int P1, int P2, int cmax) {
+    return agg_packed_lpp(D) != 0 && P1 >= 0 && P2 >= 0 && P1 + P2 <= 127 && (paths == 8 || paths == 4) && 16 * paths * (cmax + P2 + P1) + 15 < 0x7C00;
+}
 
 template <int LPP, int MODE>
 static void launch_band_t(hipStream_t st, const BandArgs& a, int frames, int paths) {
     constexpr int NWV = FSGM_BAND_WAVES;
-    const bool bits = band_needs_bits(paths, a.P2);
+    const bool bits = band_needs_bits(paths, a.P1, a.P2);
     dim3 grid((unsigned)frames), block(NWV * 64);
     if (MODE == 2 && a.Sdbg) {                               // the S debug tap: instantiations of their own, none of it in the product kernels
         if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false, MODE == 2>), grid, block, 0, st, a);

@@ -162,8 +162,8 @@ bool pair_x_fine_ok(int D);                                                     
 void launch_pair_x_fine(hipStream_t st, const PairArgs& a, int frames);            // checkpoint + sum pass, Y in natural d order
 size_t band_edge_uint4s(int W, int D, int paths);           // hand-off buffer between the bands of one frame, in uint4
 size_t band_bits_u32s(int W, int H, int D);                 // bit plane of one frame, in dwords
-bool   band_needs_bits(int paths, int P2);
-bool   band_ok(int D, int paths, int P2);
+bool   band_needs_bits(int paths, int P1, int P2);
+bool   band_ok(int D, int paths, int P1, int P2, int cmax);
 void launch_band(hipStream_t st, const BandArgs& a, int frames, int paths, int mode);   // 0 first pass, 2 second pass + WTA records
 void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames);
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);

@@ -128,6 +128,48 @@ __device__ __forceinline__ void step_s(uint32_t (&S)[8], const uint32_t (&CP)[8]
     for (int i = 0; i < 8; i++) S[i] = pk_subs(p2m, N[i]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The step again, for the band sweeps (epi_band.hip), with the instructions that need no packed form as plain 32-bit
+// ones -- a 32-bit-encoded v_add_u32 / v_sub_u32 issues in ~3.9 cycles per wave where a v_pk_* takes ~4.8 at four waves
+// per SIMD (tools/ubench/pk_rates.hip), and this kernel is bound by vector issue (profiles/r03_sq_counters.md):
+//   * y + P1 = max3(s[d] + P1, s[d-1], s[d+1])   -- the clamp of t = max(s - P1, 0) is redundant under a maximum with
+//     s[d] >= 0, so in the variable biased by P1 the neighbours are the states themselves and the own term is one plain
+//     add; absent neighbours read 0 as before.  The step's Y comes out as y + P1 (YB) and takes its costs biased the
+//     same way: CB = C + P2 + P1, so that n = CB - YB = C + P2 - y is unchanged.  Sums of YB carry P1 per path, and
+//     paths*CB - sum(YB) = paths*(C + P2) - sum(y) = S: the bias cancels where S is rebuilt.
+//   * CB - YB per 32-bit register: no borrow between the halves (n >= 0 in each).
+// Needs P1 + P2 <= 127 for the byte forms of the states and sums (epi_band.hip checks).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack_cb(const uint4 w, uint32_t (&CB)[8], const uint32_t biaspk) {   // bias = P2 + P1 in both halves
+    CB[0] = __builtin_amdgcn_perm(w.z, w.x, 0x0C040C00u) + biaspk;
+    CB[1] = __builtin_amdgcn_perm(w.z, w.x, 0x0C050C01u) + biaspk;
+    CB[2] = __builtin_amdgcn_perm(w.z, w.x, 0x0C060C02u) + biaspk;
+    CB[3] = __builtin_amdgcn_perm(w.z, w.x, 0x0C070C03u) + biaspk;
+    CB[4] = __builtin_amdgcn_perm(w.w, w.y, 0x0C040C00u) + biaspk;
+    CB[5] = __builtin_amdgcn_perm(w.w, w.y, 0x0C050C01u) + biaspk;
+    CB[6] = __builtin_amdgcn_perm(w.w, w.y, 0x0C060C02u) + biaspk;
+    CB[7] = __builtin_amdgcn_perm(w.w, w.y, 0x0C070C03u) + biaspk;
+}
+template <int LPP, bool MASKED = true>
+__device__ __forceinline__ void step_b(uint32_t (&S)[8], const uint32_t (&CB)[8], uint32_t (&YB)[8], const uint32_t P1pk,
+                                       const uint32_t P2, const LaneSel sel, const uint32_t mmask) {
+    uint32_t N[8];
+    // d-1 of register 0 = (previous lane's d = 15, own d = 7); d+1 of register 7 = (own d = 8, next lane's d = 0)
+    const uint32_t LT = __builtin_amdgcn_perm(S[7], (uint32_t)__builtin_amdgcn_mov_dpp((int)S[7], DPP_ROW_SHR1, 0xF, 0xF, true), sel.lo);
+    const uint32_t RT = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_mov_dpp((int)S[0], DPP_ROW_SHL1, 0xF, 0xF, true), S[0], sel.hi);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        YB[i] = pk_max3(S[i] + P1pk, i ? S[i - 1] : LT, i < 7 ? S[i + 1] : RT);
+        N[i] = CB[i] - YB[i];
+    }
+    const uint32_t mm = pk_min(pk_min3(N[0], N[1], N[2]), pk_min3(N[3], N[4], pk_min3(N[5], N[6], N[7])));
+    uint32_t mx = group_min_u32<LPP>(min_halves(mm));
+    if (MASKED) mx &= mmask;
+    const uint32_t p2m = __umul24(mx, 0x10001u) + P2 * 0x10001u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) S[i] = pk_subs(p2m, N[i]);
+}
+
 // Per-pixel WTA of the final passes: S (packed u16, register layout of the header) of the LPP lanes of a pixel -> one
 // record {best, minC, S[best-1], S[best+1]} + S[0] (calc_cost_sgm.cpp:263-271; the parabola runs in
 // sweep_finish_kernel).  First minimum over d: inside a lane as packed u16 keys S*16 + (index in the
@@ -151,14 +193,16 @@ __device__ __forceinline__ uint32_t srow_index(int tid0, uint32_t d) {
 
 // recb / s0b: byte pointers to the frame's records / S[0] words (wave-uniform), pix: the pixel's index in the frame -- 32-bit
 // offsets from uniform bases keep the stores' addresses out of 64-bit vector registers
-template <int LPP, int NT>
+template <int LPP, int NT, bool WTA_MIN3 = false>
 __device__ __forceinline__ void wta_row_record_at(const uint32_t (&ST)[8], uint32_t* sRow, int tid, int j,
                                                   bool ok, uint8_t* recb, uint8_t* s0b, uint32_t pix) {
     constexpr int D = LPP * 16;
     srow_store<NT>(sRow, tid, ST);
-    uint32_t kmin = 0xFFFFFFFFu;
+    uint32_t K[8];                                             // keys S*16 + index in the lane: < 2^15, so the fp16 3-input minimum orders them as integers
 #pragma unroll
-    for (int i = 0; i < 8; i++) kmin = pk_min(kmin, pk_mad16(ST[i], 0x00100010u, (uint32_t)i | ((uint32_t)(i + 8) << 16)));
+    for (int i = 0; i < 8; i++) K[i] = pk_mad16(ST[i], 0x00100010u, (uint32_t)i | ((uint32_t)(i + 8) << 16));
+    const uint32_t kmin = WTA_MIN3 ? pk_min(pk_min3(K[0], K[1], K[2]), pk_min3(K[3], K[4], pk_min3(K[5], K[6], K[7])))
+                                   : pk_min(pk_min(pk_min(K[0], K[1]), pk_min(K[2], K[3])), pk_min(pk_min(K[4], K[5]), pk_min(K[6], K[7])));
     const uint32_t k16 = min(kmin & 0xFFFFu, kmin >> 16);
     uint32_t key = ((k16 >> 4) << 8) | ((uint32_t)j * 16u + (k16 & 15u));
     key = group_min_u32<LPP>(key);

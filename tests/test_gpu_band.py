@@ -48,7 +48,7 @@ def test_band_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, paths):
         v[:, ::5, :] = 0                                     # strong structure: paths carry information far
     _, _, off = synth.epi_maps(W, H, "general", seed=3)
     with EpiPlan(W, H, D, B, paths=paths) as plan:
-        plan.set_penalties(6, 64, 0.3)                       # 4 * P2 > 255: the first pass's sums need their 9th bits
+        plan.set_penalties(6, 64, 0.3)                       # 4 * (P1 + P2) > 255: the first pass's sums need their 9th bits
         for f in range(B):
             plan.upload_cost(f, vols[f])
             plan.upload_offset(f, off)
@@ -60,9 +60,9 @@ def test_band_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, paths):
 
 
 @pytest.mark.parametrize("paths", [8, 4])
-@pytest.mark.parametrize("P1,P2,cmax", [(6, 32, 24), (0, 0, 24), (10, 10, 60), (3, 63, 24), (6, 85, 24), (20, 100, 50), (1, 127, 0)])
+@pytest.mark.parametrize("P1,P2,cmax", [(6, 32, 24), (0, 0, 24), (10, 10, 60), (3, 63, 24), (6, 85, 24), (20, 100, 50), (1, 126, 0), (63, 64, 24)])
 def test_band_sweeps_penalties(gpu_lib, oracle, P1, P2, cmax, paths):
-    """With and without the bit plane (4*P2 <= 255 / > 255), P1 = P2, zero penalties, the largest P2 the bytes hold."""
+    """With and without the bit plane (4*(P1+P2) <= 255 / > 255), P1 = P2, zero penalties, the largest P1 + P2 the bytes hold."""
     W, H, D, B = 61, 90, 128, 2
     vols = [synth.cost_volume(W, H, D, seed=P2 + f, cmax=cmax) for f in range(B)]
     _, _, off = synth.epi_maps(W, H, "axis")
@@ -89,6 +89,8 @@ def test_band_sweeps_fall_back_outside_their_range(gpu_lib):
         assert plan.kernel_name == "packed16/nowrap"
         plan.set_penalties(6, 128, 0.3)
         assert plan.kernel_name != "band16/nowrap"
+        plan.set_penalties(60, 70, 0.3)                      # P1 + P2 > 127: the biased y no longer fits the byte forms
+        assert plan.kernel_name == "packed16/nowrap"
     with EpiPlan(20, 10, 20, 1, paths=8) as plan:
         plan.set_agg_mode(4)
         assert plan.kernel_name == "generic"
