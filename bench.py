@@ -2,8 +2,8 @@
 """bench.py -- headline benchmark: aggregated cost-volume voxel-paths/s on synthetic KITTI-shape
 volumes (1242 x 375 x 128, 8 paths), one process per GPU.
 
-A "step" is one pass of the aggregation stage (multi-path DP C -> L_r, then sum + WTA + sub-pixel)
-over one batch of --frames-per-gpu (default 40) cost volumes that are already resident in HBM.  Frames shard
+A "step" is one pass of the aggregation stage (multi-path DP over C, then sum + WTA + sub-pixel)
+over one batch of --frames-per-gpu (default 512) cost volumes that are already resident in HBM.  Frames shard
 across ranks with no collective in the data path (weak scaling: per-GPU batch fixed).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
@@ -221,9 +221,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-gpu", type=int, default=40,
-                    help="frames resident per GPU and processed per step (two lanes of 20: the measured optimum, 36-40; "
-                         "32: -6 %%, 44: -3 %%)")
+    ap.add_argument("--frames-per-gpu", type=int, default=512,
+                    help="frames resident per GPU and processed per step.  512 = one band-sweep workgroup per frame, two per CU "
+                         "(31 GB of cost volumes, 118 GB with the plan's other buffers: what 288 GB of HBM are for); the block "
+                         "sweeps' optimum is 40 (two lanes of 20), the line kernels take single frames")
     ap.add_argument("--total-frames", type=int, default=0,
                     help="strong scaling: a fixed batch of this many frames split over the ranks by fsgm_amd.batch.shard_indices "
                          "(BASELINE config 5 literally = 8); default 0 = weak scaling with --frames-per-gpu frames on every GPU")
@@ -381,10 +382,10 @@ def main():
                        "step": f"aggregate({PATHS} paths) + sum/WTA/subpixel", "sharding": "frames, no collective",
                        "pci_bus_ids": bus_ids, "distinct_devices": len(set(bus_ids))},
             "argv": " ".join(sys.argv[1:]),
-            # the aggregation is one stage of four kernel types that run concurrently on three streams
-            # (sweep_kernel<8,0> x24, sweep_kernel<8,2> x24 per frame lane; pair_ckpt_kernel<8,0> +
-            # pair_sum_kernel<8,0,false> for the horizontal pair): the roofline is taken over the stage, HIP
-            # events fork->join
+            # band sweeps: the stage is two kernels back to back on the plan's stream (first pass, second pass + WTA),
+            # each 4 voxel-paths per voxel: HIP events around the pair = the sum of their durations (rocprofv3 kernel
+            # stats of this command: profiles/).  Block sweeps / pair pipeline (smaller batches): kernel types that run
+            # concurrently on three streams, roofline over the stage, HIP events fork->join
             "roofline": {"bound": "hbm", "kernel": "aggregation stage: " + stage_kernels[0],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": bpv * B * W * H * D if bpv else None, "traffic_source": traffic_src,
@@ -409,7 +410,7 @@ def main():
             out["roofline"]["copy_GBps_measured"] = None
         if world == 1 and not args.no_extras:
             # whole-MEX rate (reported separately, not the judged value): census x2 + cost fill
-            # + 5x5 box + 8-path aggregation + WTA/sub-pixel/vz for the same 32 resident frames, on the
+            # + 5x5 box + 8-path aggregation + WTA/sub-pixel/vz for the same resident frames, on the
             # survey's timing maps (Pd0 = (x+1, y+1), direction (-1, 0), offset 200) and on a direction field
             # with a random component per pixel (every lane of the census gather in its own cache line: the
             # worst case for the cost fill); this overwrites the synthetic volumes, so it runs last

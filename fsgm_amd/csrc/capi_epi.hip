@@ -65,7 +65,8 @@ struct fsgm_epi_plan {
     int lanes = 2;                       // frame lanes of the sweeps (FSGM_EPI_LANES, 1..3)
     std::vector<int> cmax;               // per frame: upper bound of the cost values in dC
     bool vz_valid = false;
-    int agg_mode = 0;                    // 0 auto, 1 per-direction line kernels, 2 fused sweeps (if eligible)
+    int agg_mode = 0;                    // 0 auto, 1 per-direction line kernels, 2 fused sweeps (if eligible), 3 parallel sweeps, 4 band sweeps
+    int cus = 256;                       // compute units of the device (band sweeps: one workgroup per frame, two per CU)
     int kernel_kind = AGG_GENERIC;
     bool packed = false;
     // The fused-sweep stage is ~100 launches on three streams; FSGM_EPI_GRAPH=1 replays it as one HIP graph
@@ -81,8 +82,21 @@ struct fsgm_epi_plan {
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 static int par_min_batch() { static const int v = env_int("FSGM_EPI_PAR_MIN", 5); return v; }
 static int par_max_batch() { static const int v = env_int("FSGM_EPI_PAR_MAX", 18); return v; }
-// band sweeps (all four paths of a pass in one sweep, one workgroup per frame): from this many frames in auto mode
-static int band_min_batch() { static const int v = env_int("FSGM_EPI_BAND_MIN", 1 << 30); return v; }
+// Band sweeps (all four paths of a pass in one sweep, one workgroup per frame, two workgroups per CU) in auto mode: a launch
+// takes as long as its slowest CU -- measured at 1242x375x128, 8 paths, 256 CUs: 25.2 ms with one workgroup per CU (up to
+// 256 frames), 42.8 ms with two (up to 512) -- while the block sweeps take 0.107 ms per frame whatever the count.  In units of
+// the block sweeps' time per frame a round of the band kernel costs 0.92 x CUs (half filled) or 0.785 x 2 CUs (full): auto
+// mode takes the band sweeps where that is less than the batch (256 frames, 402..512, 638..768, ...).
+// FSGM_EPI_BAND_MIN: never below this many frames (0: never at all).
+static int band_min_batch() { static const int v = env_int("FSGM_EPI_BAND_MIN", 64); return v; }
+// (4 paths, against the pair pipeline's 0.09 ms per frame: 17.0 / 29.0 ms per round -> 0.74 x CUs / 0.63 x 2 CUs)
+static bool band_pays(int batch, int cus, int paths) {
+    if (band_min_batch() <= 0 || batch < band_min_batch()) return false;
+    const double half = paths == 8 ? 0.92 : 0.74, whole = paths == 8 ? 0.785 : 0.63;
+    const int slots = 2 * cus, full = batch / slots, tail = batch % slots;
+    const double cost = full * whole * slots + (tail == 0 ? 0.0 : (tail <= cus ? half * cus : whole * slots));
+    return cost < (double)batch;
+}
 static int pairs_min_batch() { static const int v = env_int("FSGM_EPI_PAIRS_MIN", 9); return v; }   // 4 paths: line kernels -> pair pipeline
 
 static void select_kernel(fsgm_epi_plan* p) {
@@ -114,7 +128,7 @@ static void select_kernel(fsgm_epi_plan* p) {
     // the excess sum of a pair fits a byte)
     if (fusable && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
     // very large batches (or mode 4): the band sweeps
-    if (fusable && band_ok(p->D, p->prm.paths, p->P1, p->P2, cm) && (p->agg_mode == 4 || (p->agg_mode == 0 && p->batch >= band_min_batch()))) {
+    if (fusable && band_ok(p->D, p->prm.paths, p->P1, p->P2, cm) && (p->agg_mode == 4 || (p->agg_mode == 0 && band_pays(p->batch, p->cus, p->prm.paths)))) {
         p->kernel_kind = AGG_BAND;
         p->sweep_par = false;
     }
@@ -230,6 +244,7 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
 
     fsgm_epi_plan* p = new fsgm_epi_plan;
     p->W = W; p->H = H; p->D = D; p->batch = batch; p->prm = pr;
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, pr.device) == hipSuccess && n > 0) p->cus = n; }
     p->NP = (size_t)W * H; p->N = p->NP * D;
     p->cmax.assign(batch, 24);           // census 5x5: 24 informative bits
     const size_t B = batch;

@@ -26,6 +26,7 @@ LEGS="${LEGS:-default paths4 batch8 pyramid3 pyramid3_ng}"
 for leg in $LEGS; do
     case $leg in
         default)     A="--steps 2 --warmup 1 --no-cpu-baseline" ;;
+        default40)   A="--steps 2 --warmup 1 --no-cpu-baseline --frames-per-gpu 40" ;;
         paths4)      A="--steps 2 --warmup 1 --no-cpu-baseline --paths 4" ;;
         batch8)      A="--steps 2 --warmup 1 --no-cpu-baseline --frames-per-gpu 8" ;;
         batch1)      A="--steps 2 --warmup 1 --no-cpu-baseline --frames-per-gpu 1" ;;
