@@ -33,7 +33,7 @@ secondary)
     cut -c1-300 gpurun_out/r03_bench_$n.json
   done ;;
 crossover)
-  timeout -k 10 600 python3 scratch_dbg/r03_crossover.py 1,2,4,8,16,40 > gpurun_out/r03_crossover.txt 2>&1 || tail -5 gpurun_out/r03_crossover.txt
+  timeout -k 10 600 python3 tools/crossover.py 1,2,4,8,16,40 > gpurun_out/r03_crossover.txt 2>&1 || tail -5 gpurun_out/r03_crossover.txt
   cat gpurun_out/r03_crossover.txt ;;
 esac
 done
