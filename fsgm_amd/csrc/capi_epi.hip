@@ -80,7 +80,7 @@ struct fsgm_epi_plan {
 // batch sizes at which auto mode moves from the line kernels to the parallel sweeps and on to the full sweep pipeline
 // (8 paths; measured at 1242x375x128); FSGM_EPI_PAR_MIN / FSGM_EPI_PAR_MAX override them
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
-static int par_min_batch() { static const int v = env_int("FSGM_EPI_PAR_MIN", 5); return v; }
+static int par_min_batch() { static const int v = env_int("FSGM_EPI_PAR_MIN", 4); return v; }
 static int par_max_batch() { static const int v = env_int("FSGM_EPI_PAR_MAX", 18); return v; }
 // Band sweeps (all four paths of a pass in one sweep, one workgroup per frame, two workgroups per CU) in auto mode: a launch
 // takes as long as its slowest CU -- measured at 1242x375x128, 8 paths, 256 CUs: 25.2 ms with one workgroup per CU (up to
@@ -398,6 +398,19 @@ static int pairs_x_fine(const fsgm_epi_plan* p) {
     return env == 1 || p->batch < 16 ? 1 : 0;
 }
 
+// Parallel sweeps (8 paths, 5..17 frames): what the batch waits for are serial chains -- the along-x pair's 3 x W steps and
+// the sweeps' H / 16 launches.  FSGM_EPI_PAR_FINE / FSGM_EPI_PAR_TALL = 0 / 1 force the two shortenings off / on (A/B).
+static int par_pair_fine(const fsgm_epi_plan* p) {
+    static const int env = env_int("FSGM_EPI_PAR_FINE", -1);
+    if (!pair_x_fine_ok(p->D) || env == 0) return 0;
+    return env == 1 || p->batch <= 10 ? 1 : 0;       // 8 frames 1.46 -> 1.32 ms with both; from 12 frames neither pays
+}
+static int par_tall(const fsgm_epi_plan* p) {
+    static const int env = env_int("FSGM_EPI_PAR_TALL", -1);
+    if (env >= 0) return env != 0;
+    return p->batch <= 10 ? 1 : 0;
+}
+
 static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
     if (p->dCkptV) return FSGM_OK;
     const size_t B = p->batch;
@@ -540,7 +553,9 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         h.C = p->dC; h.c_frame_stride = p->N; h.X = p->dLh; h.x_frame_stride = p->N;
         h.ckpt = p->dCkpt; h.ckpt_frame_stride = ckb;
         h.W = p->W; h.H = p->H; h.D = p->D; h.P1 = p->P1; h.P2 = p->P2;
-        launch_pair(p->stream_h, h, p->batch, 0, false);
+        // small batches wait for the pair's serial chain (3 x W steps): 8 costs a lane shorten it (Y_h then in natural d order)
+        if (par_pair_fine(p)) launch_pair_x_fine(p->stream_h, h, p->batch);
+        else                  launch_pair(p->stream_h, h, p->batch, 0, false);
         FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
         SweepArgs w;
         w.C = p->dC; w.c_frame_stride = p->N;
@@ -548,9 +563,10 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         w.Lh = nullptr; w.lh_frame_stride = 0; w.rec = nullptr; w.s0 = nullptr;
         w.state_in = w.state_out = p->dState; w.state_frame_stride = p->state_stride;
         w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
-        launch_sweep(p->stream, w, p->batch, 0);                      // pass-0 paths from above -> Y_dn
+        const int tall = par_tall(p);                                 // 8-wave workgroups: half the launches of a sweep
+        launch_sweep(p->stream, w, p->batch, 0, tall);                // pass-0 paths from above -> Y_dn
         w.X = p->dXupAll; w.state_in = w.state_out = p->dStateUp;
-        launch_sweep(p->stream_b, w, p->batch, 1);                    // pass-1 paths -> Y_up
+        launch_sweep(p->stream_b, w, p->batch, 1, tall);              // pass-1 paths -> Y_up
         FSGM_HIP(hipEventRecord(p->ev_b, p->stream_b));
         FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_h, 0));
         FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_b, 0));
@@ -670,7 +686,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp && !p->prm.fb_check;
         SweepSumArgs q;
         q.C = p->dC; q.Xdn = p->dX; q.Xup = p->dXupAll; q.v_frame_stride = p->N;
-        q.Lh = p->dLh; q.lh_frame_stride = p->N; q.lh_natural = 0;
+        q.Lh = p->dLh; q.lh_frame_stride = p->N; q.lh_natural = par_pair_fine(p);
         q.nC = 8; q.P2 = p->P2; q.Sdbg = nullptr;
         launch_wta_sweep(p->stream, a, q, p->batch);
     } else if ((stages & FSGM_STAGE_WTA) && (p->kernel_kind == AGG_SWEEP || p->kernel_kind == AGG_PAIRS || p->kernel_kind == AGG_BAND)) {
@@ -834,7 +850,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
         SweepSumArgs q;
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX + (size_t)f * p->N; q.Xup = p->dXup; q.v_frame_stride = p->N;
-        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_natural = 0;
+        q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_natural = p->sweep_par ? par_pair_fine(p) : 0;
         q.nC = 8; q.P2 = p->P2; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());

@@ -152,7 +152,7 @@ void launch_aggregate(hipStream_t st, AggArgs a, int paths, int frames, int kern
 void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
 int    sweep_rows_per_launch(int D);
 size_t sweep_state_bytes(int W, int D);   // one state buffer of one frame
-void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode);   // 0 down, 1 up, 2 up + fused WTA
+void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode, int tall = 0);   // 0 down, 1 up, 2 up + fused WTA; tall: 8-wave workgroups (modes 0, 1)
 int    strip_count(int W, int H, int D);                    // strips of skewed columns per frame
 size_t strip_edge_uint4s(int W, int H, int D);              // hand-off buffer per frame, in uint4
 void launch_strips(hipStream_t st, const StripArgs& a, int mode);               // same modes, one launch per sweep

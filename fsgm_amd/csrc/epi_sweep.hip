@@ -1094,9 +1094,8 @@ static int sweep_gpw() {
     return v;
 }
 
-template <int LPP, int GPW>
+template <int LPP, int GPW, int NWV>
 static void launch_sweep_g(hipStream_t st, SweepArgs a, int frames, int mode) {
-    constexpr int NWV = FSGM_SWEEP_WAVES;
     constexpr int STRIP = NWV * GPW * (64 / LPP), T = (NWV / 2) * (64 / LPP);
     dim3 grid((a.W + STRIP - 1) / STRIP, frames);
     uint8_t* const buf0 = a.state_out;                     // caller passes the base of 2 x frames x state buffers
@@ -1113,19 +1112,23 @@ static void launch_sweep_g(hipStream_t st, SweepArgs a, int frames, int mode) {
     }
 }
 
+// tall = 1: workgroups of 8 waves (64-column strips, 32 rows per launch at D = 128) for the non-final modes -- half the
+// launches of a sweep.  A sweep of a small batch is a chain of launches that no other work hides (parallel sweeps, mode 3):
+// fewer, longer launches shorten it; large batches keep the 4-wave form (more workgroups per CU, round 1's measurement).
 template <int LPP>
-static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode) {
-    if (sweep_gpw() == 2) launch_sweep_g<LPP, 2>(st, a, frames, mode);
-    else launch_sweep_g<LPP, 1>(st, a, frames, mode);
+static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode, int tall) {
+    if (tall && mode != 2) launch_sweep_g<LPP, 1, 8>(st, a, frames, mode);
+    else if (sweep_gpw() == 2) launch_sweep_g<LPP, 2, FSGM_SWEEP_WAVES>(st, a, frames, mode);
+    else launch_sweep_g<LPP, 1, FSGM_SWEEP_WAVES>(st, a, frames, mode);
 }
 
-void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode) {
+void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode, int tall) {
     switch (agg_packed_lpp(a.D)) {
-        case 1: launch_sweep_t<1>(st, a, frames, mode); break;
-        case 2: launch_sweep_t<2>(st, a, frames, mode); break;
-        case 4: launch_sweep_t<4>(st, a, frames, mode); break;
-        case 8: launch_sweep_t<8>(st, a, frames, mode); break;
-        case 16: launch_sweep_t<16>(st, a, frames, mode); break;
+        case 1: launch_sweep_t<1>(st, a, frames, mode, tall); break;
+        case 2: launch_sweep_t<2>(st, a, frames, mode, tall); break;
+        case 4: launch_sweep_t<4>(st, a, frames, mode, tall); break;
+        case 8: launch_sweep_t<8>(st, a, frames, mode, tall); break;
+        case 16: launch_sweep_t<16>(st, a, frames, mode, tall); break;
         default: break;
     }
 }

@@ -247,7 +247,7 @@ def test_cost_volume_kitti_shape_general_field(gpu_lib, oracle):
         np.testing.assert_array_equal(plan.download_cost(0), want)
 
 
-@pytest.mark.parametrize("paths,n", [(8, 18), (4, 9), (8, 5), (8, 3)])  # auto mode, 8 paths: line kernels / parallel sweeps from 5 frames / full sweeps from 18; 4 paths: pairs from 9
+@pytest.mark.parametrize("paths,n", [(8, 18), (4, 9), (8, 5), (8, 3)])  # auto mode, 8 paths: line kernels / parallel sweeps from 4 frames / full sweeps from 18; 4 paths: pairs from 9
 def test_batch_matches_single_frames(gpu_lib, oracle, paths, n):
     W, H, D = 96, 64, 64
     frames = []
@@ -447,10 +447,12 @@ def test_parallel_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, subpixel)
 
 
 def test_auto_mode_by_batch_size(gpu_lib):
-    """8 paths, no-wrap penalties: line kernels below 5 frames, parallel sweeps below 18, the full sweep pipeline from there;
-    4 paths: line kernels below 9 frames, then the pair kernels."""
-    for paths, B, name in [(8, 4, "packed16/nowrap"), (8, 5, "sweep16par/nowrap"), (8, 17, "sweep16par/nowrap"), (8, 18, "sweep16/nowrap"),
-                           (4, 8, "packed16/nowrap"), (4, 9, "pairs16/nowrap")]:
+    """8 paths, no-wrap penalties: line kernels below 4 frames, parallel sweeps below 18, the full sweep pipeline from there,
+    the band sweeps where a round of one workgroup per frame pays (256 frames, 402..512, ...; plans are created lazily, so a
+    512-frame plan of this small shape costs nothing); 4 paths: line kernels below 9 frames, then the pair kernels, then bands."""
+    for paths, B, name in [(8, 3, "packed16/nowrap"), (8, 4, "sweep16par/nowrap"), (8, 17, "sweep16par/nowrap"), (8, 18, "sweep16/nowrap"),
+                           (8, 200, "sweep16/nowrap"), (8, 256, "band16/nowrap"), (8, 300, "sweep16/nowrap"), (8, 512, "band16/nowrap"),
+                           (4, 8, "packed16/nowrap"), (4, 9, "pairs16/nowrap"), (4, 512, "band16/nowrap")]:
         with EpiPlan(32, 16, 64, B, paths=paths) as plan:
             plan.set_penalties(6, 64, 0.3)
             assert plan.kernel_name == name, (paths, B)
