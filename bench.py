@@ -131,6 +131,14 @@ def pyramid3(args):
         finally:
             for pl in plans:
                 pl.close()
+    # a batch of pairs resident in one plan: every kernel of a level covers all of them
+    batched = {}
+    for Bn in (4, 8, 16):
+        with PyramidPlan(W, H, 3, 3, batch=Bn) as plan:
+            for f in range(Bn):
+                plan.upload(np.roll(I0, 13 * f, axis=2), np.roll(I1, 13 * f, axis=2), frame=f)
+            ms = plan.time(1, max(2, iters // 2))
+        batched[str(Bn)] = {"ms_per_batch": ms, "ms_per_pair": ms / Bn, "pairs_per_s": Bn / (ms * 1e-3), "speedup_vs_sequential": total * Bn / ms}
     levels = []
     for (w, h) in sizes:                                      # coarse to fine, stage by stage
         with PydPlan(w, h, w, h, 5, 5, 2, 1) as lp:
@@ -143,7 +151,7 @@ def pyramid3(args):
     print(json.dumps({"metric": "pyramidal_sgm (3-level calc_pyd_cost_sgm pyramid), device time per image pair", "value": total, "unit": "ms",
                       "higher_is_better": False, "n_gpus": 1, "dtype": "u8", "data": "synthetic",
                       "config": {"workload": "pyramid 1242x375 / 621x188 / 311x94 RGB, 11x11 window (D=121), 8 paths, 2 passes"},
-                      "voxel_paths_per_s": vp / (total * 1e-3), "host_call_ms": host_ms, "plans_in_flight": in_flight, "levels": levels}), flush=True)
+                      "voxel_paths_per_s": vp / (total * 1e-3), "host_call_ms": host_ms, "plans_in_flight": in_flight, "batched": batched, "levels": levels}), flush=True)
 
 
 def pyramid3_ng(args):

@@ -13,7 +13,7 @@
 using namespace fsgm;
 
 struct fsgm_pyramid_plan {
-    int W = 0, H = 0, channels = 1, device = 0;
+    int W = 0, H = 0, channels = 1, device = 0, batch = 1;
     fsgm_pyramid_params prm{};
     std::vector<int> Ws, Hs;                         // level l (0-based) size
     std::vector<fsgm_pyd_plan*> lv;                  // one calc_pyd_cost_sgm plan per level
@@ -54,8 +54,16 @@ void fsgm_pyramid_plan_destroy(fsgm_pyramid_plan* p) {
 
 fsgm_status fsgm_pyramid_plan_create(fsgm_pyramid_plan** out, int32_t W, int32_t H, int32_t channels,
                                      const fsgm_pyramid_params* prm) {
+    return fsgm_pyramid_plan_create_batch(out, W, H, channels, prm, 1);
+}
+
+// `batch` image pairs resident in one plan: every kernel of a level covers all of them (the level loop stays a
+// sequence -- a level needs the level above -- but each of its launches has batch times the work)
+fsgm_status fsgm_pyramid_plan_create_batch(fsgm_pyramid_plan** out, int32_t W, int32_t H, int32_t channels,
+                                           const fsgm_pyramid_params* prm, int32_t batch) {
     FSGM_REQUIRE(out, "fsgm_pyramid_plan_create: null plan pointer");
     *out = nullptr;
+    FSGM_REQUIRE(batch >= 1 && batch <= 4096, "batch must be in 1..4096 (got %d)", batch);
     FSGM_REQUIRE(prm, "fsgm_pyramid_plan_create: null parameters");
     FSGM_REQUIRE(W >= 1 && H >= 1, "width/height must be >= 1 (got %d x %d)", W, H);
     FSGM_REQUIRE(channels == 1 || channels == 3, "channels must be 1 (gray) or 3 (RGB planes), got %d", channels);
@@ -66,7 +74,7 @@ fsgm_status fsgm_pyramid_plan_create(fsgm_pyramid_plan** out, int32_t W, int32_t
     FSGM_REQUIRE(prm->device >= 0 && prm->device < ndev, "device %d out of range (have %d)", prm->device, ndev);
     FSGM_HIP(hipSetDevice(prm->device));
     fsgm_pyramid_plan* p = new fsgm_pyramid_plan;
-    p->W = W; p->H = H; p->channels = channels; p->device = prm->device; p->prm = *prm;
+    p->W = W; p->H = H; p->channels = channels; p->device = prm->device; p->prm = *prm; p->batch = batch;
     const int n = prm->numPyd;
     p->Ws.resize(n); p->Hs.resize(n);
     p->Ws[0] = W; p->Hs[0] = H;
@@ -81,7 +89,7 @@ fsgm_status fsgm_pyramid_plan_create(fsgm_pyramid_plan** out, int32_t W, int32_t
         // 2*imresize(mv, 2, 'nearest') of the level above, twice that level's size (:72)
         const int mvW = l == n - 1 ? p->Ws[l] : 2 * p->Ws[l + 1], mvH = l == n - 1 ? p->Hs[l] : 2 * p->Hs[l + 1];
         st = fsgm_pyd_plan_create(&p->lv[l], p->Ws[l], p->Hs[l], mvW, mvH, prm->horSearchHalfWinSize,
-                                  prm->verSearchHalfWinSize, prm->aggHalfWinSize, 1, prm->device);
+                                  prm->verSearchHalfWinSize, prm->aggHalfWinSize, batch, prm->device);
         if (st != FSGM_OK) break;
         fsgm_pyd_plan* q = p->lv[l];
         (void)hipStreamDestroy(q->stream);           // all levels run on the pyramid's stream, in order
@@ -89,13 +97,13 @@ fsgm_status fsgm_pyramid_plan_create(fsgm_pyramid_plan** out, int32_t W, int32_t
         st = fsgm_pyd_plan_set_params(q, prm->P1, prm->P2, prm->enableDiagonal, prm->totalPass, prm->adaptiveP2, l == 0);   // :49
         const size_t np = (size_t)p->Ws[l] * p->Hs[l];
         if (channels == 3) {
-            e = hipMalloc((void**)&p->dP0[l], 3 * np);
-            if (e == hipSuccess) e = hipMalloc((void**)&p->dP1[l], 3 * np);
+            e = hipMalloc((void**)&p->dP0[l], (size_t)batch * 3 * np);
+            if (e == hipSuccess) e = hipMalloc((void**)&p->dP1[l], (size_t)batch * 3 * np);
         }
-        if (e == hipSuccess) e = hipMalloc((void**)&p->dFlow[l], 2 * np * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->dFlow[l], (size_t)batch * 2 * np * sizeof(double));
     }
     if (st == FSGM_OK && e == hipSuccess)
-        e = hipMemset(p->lv[n - 1]->dMv, 0, 2 * p->lv[n - 1]->MV * sizeof(double));                      // :34
+        e = hipMemset(p->lv[n - 1]->dMv, 0, (size_t)batch * 2 * p->lv[n - 1]->MV * sizeof(double));      // :34
     if (st != FSGM_OK || e != hipSuccess) {
         char msg[512];
         snprintf(msg, sizeof msg, "%s", st != FSGM_OK ? fsgm_last_error() : hipGetErrorString(e));
@@ -114,11 +122,16 @@ fsgm_status fsgm_pyramid_plan_level_size(fsgm_pyramid_plan* p, int32_t level, in
 }
 
 fsgm_status fsgm_pyramid_plan_upload(fsgm_pyramid_plan* p, const uint8_t* I0, const uint8_t* I1) {
+    return fsgm_pyramid_plan_upload_frame(p, 0, I0, I1);
+}
+
+fsgm_status fsgm_pyramid_plan_upload_frame(fsgm_pyramid_plan* p, int32_t frame, const uint8_t* I0, const uint8_t* I1) {
     FSGM_REQUIRE(p && I0 && I1, "fsgm_pyramid_plan_upload: null argument");
+    FSGM_REQUIRE(frame >= 0 && frame < p->batch, "frame %d out of range (batch %d)", frame, p->batch);
     FSGM_HIP(hipSetDevice(p->device));
     const size_t n = (size_t)p->channels * p->W * p->H;
-    uint8_t* d0 = p->channels == 3 ? p->dP0[0] : p->lv[0]->dI1;
-    uint8_t* d1 = p->channels == 3 ? p->dP1[0] : p->lv[0]->dI2;
+    uint8_t* d0 = (p->channels == 3 ? p->dP0[0] : p->lv[0]->dI1) + (size_t)frame * n;
+    uint8_t* d1 = (p->channels == 3 ? p->dP1[0] : p->lv[0]->dI2) + (size_t)frame * n;
     StreamGuard guard(p->stream);   // an early exit drains the stream: queued copies use the caller's memory
     FSGM_HIP(hipMemcpyAsync(d0, I0, n, hipMemcpyHostToDevice, p->stream));
     FSGM_HIP(hipMemcpyAsync(d1, I1, n, hipMemcpyHostToDevice, p->stream));
@@ -132,13 +145,13 @@ static void pyramid_enqueue_images(fsgm_pyramid_plan* p) {
     for (int l = 1; l < n; l++) {                                                // :28-31
         const uint8_t* s0 = ch == 3 ? p->dP0[l - 1] : p->lv[l - 1]->dI1;
         const uint8_t* s1 = ch == 3 ? p->dP1[l - 1] : p->lv[l - 1]->dI2;
-        launch_pyr_reduce(p->stream, s0, ch == 3 ? p->dP0[l] : p->lv[l]->dI1, p->Ws[l - 1], p->Hs[l - 1], ch);
-        launch_pyr_reduce(p->stream, s1, ch == 3 ? p->dP1[l] : p->lv[l]->dI2, p->Ws[l - 1], p->Hs[l - 1], ch);
+        launch_pyr_reduce(p->stream, s0, ch == 3 ? p->dP0[l] : p->lv[l]->dI1, p->Ws[l - 1], p->Hs[l - 1], ch * p->batch);
+        launch_pyr_reduce(p->stream, s1, ch == 3 ? p->dP1[l] : p->lv[l]->dI2, p->Ws[l - 1], p->Hs[l - 1], ch * p->batch);
     }
     if (ch == 3)
         for (int l = 0; l < n; l++) {                                            // :44-45
-            launch_pyr_gray(p->stream, p->dP0[l], p->lv[l]->dI1, p->Ws[l], p->Hs[l]);
-            launch_pyr_gray(p->stream, p->dP1[l], p->lv[l]->dI2, p->Ws[l], p->Hs[l]);
+            launch_pyr_gray(p->stream, p->dP0[l], p->lv[l]->dI1, p->Ws[l], p->Hs[l], p->batch);
+            launch_pyr_gray(p->stream, p->dP1[l], p->lv[l]->dI2, p->Ws[l], p->Hs[l], p->batch);
         }
 }
 
@@ -152,9 +165,10 @@ static fsgm_status pyramid_enqueue(fsgm_pyramid_plan* p) {
         PyrFlowArgs a;
         a.bestD = q->dBestD; a.mvSub = q->dMvSub; a.mvPre = q->dMv; a.flow = p->dFlow[l];
         a.next = l > 0 ? p->lv[l - 1]->dMv : nullptr;
+        a.next_frame_stride = l > 0 ? 2 * p->lv[l - 1]->MV : 0;
         a.W = q->W; a.H = q->H; a.mvW = q->mvW; a.mvH = q->mvH;
         a.Sy = q->Sy; a.hor = p->prm.horSearchHalfWinSize; a.ver = p->prm.verSearchHalfWinSize;
-        launch_pyr_flow(p->stream, a);                                           // :57-72
+        launch_pyr_flow(p->stream, a, p->batch);                                 // :57-72
     }
     FSGM_HIP(hipGetLastError());
     return FSGM_OK;
@@ -182,14 +196,19 @@ fsgm_status fsgm_pyramid_plan_run_images(fsgm_pyramid_plan* p) {
 }
 
 fsgm_status fsgm_pyramid_plan_download(fsgm_pyramid_plan* p, int32_t level, double* mv, uint32_t* minC) {
+    return fsgm_pyramid_plan_download_frame(p, 0, level, mv, minC);
+}
+
+fsgm_status fsgm_pyramid_plan_download_frame(fsgm_pyramid_plan* p, int32_t frame, int32_t level, double* mv, uint32_t* minC) {
     FSGM_REQUIRE(p, "null plan");
+    FSGM_REQUIRE(frame >= 0 && frame < p->batch, "frame %d out of range (batch %d)", frame, p->batch);
     FSGM_REQUIRE(level >= 1 && level <= p->prm.numPyd, "level %d out of range 1..%d", level, p->prm.numPyd);
     FSGM_HIP(hipSetDevice(p->device));
     FSGM_HIP(hipStreamSynchronize(p->stream));
     const int l = level - 1;
     const size_t np = (size_t)p->Ws[l] * p->Hs[l];
-    if (mv) FSGM_HIP(hipMemcpy(mv, p->dFlow[l], 2 * np * sizeof(double), hipMemcpyDeviceToHost));
-    if (minC) FSGM_HIP(hipMemcpy(minC, p->lv[l]->dMinC, np * 4, hipMemcpyDeviceToHost));
+    if (mv) FSGM_HIP(hipMemcpy(mv, p->dFlow[l] + (size_t)frame * 2 * np, 2 * np * sizeof(double), hipMemcpyDeviceToHost));
+    if (minC) FSGM_HIP(hipMemcpy(minC, p->lv[l]->dMinC + (size_t)frame * np, np * 4, hipMemcpyDeviceToHost));
     return FSGM_OK;
 }
 
@@ -237,7 +256,7 @@ fsgm_status fsgm_pyramidal_sgm_host(const uint8_t* I0, const uint8_t* I1, int32_
     std::lock_guard<std::mutex> lk(g_pyr_mu);
     fsgm_pyramid_plan* p = nullptr;
     for (fsgm_pyramid_plan* q : g_pyr_cache)
-        if (q->W == width && q->H == height && q->channels == channels && memcmp(&q->prm, prm, sizeof *prm) == 0) p = q;
+        if (q->W == width && q->H == height && q->channels == channels && q->batch == 1 && memcmp(&q->prm, prm, sizeof *prm) == 0) p = q;
     fsgm_status st;
     if (!p) {
         if ((st = fsgm_pyramid_plan_create(&p, width, height, channels, prm)) != FSGM_OK) return st;

@@ -109,22 +109,44 @@ __device__ __forceinline__ void epi_rawcost_px_body(const EpiCostArgs& a, uint8_
     const uint32_t W4 = 4u * (uint32_t)W;
     uint8_t* const myrow = tilew + lane * RC_PAD;
     uint8_t* const outw = a.Craw + f * (size_t)NP * D + (size_t)pw * D;
+    // byte offsets of the 8 census words chunk (d0 + c) of this pixel samples: the reference's fp64 sequence per voxel
+    auto sample_offsets = [&](const int dbase, uint32_t (&boff)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double s = __dmul_rn(off, vzt[dbase + k]);                                  // offset * vzInd
+            const double ox = __dmul_rn(s, ux), oy = __dmul_rn(s, uy);                        // :365-366
+            const double vx = __dadd_rn(bx, ox), vy = __dadd_rn(by, oy);
+            const int x2 = SMALL ? round_clamp_small(vx, xhi) : clamp0(round_to_i32_x86(vx), xhi);   // :371, :374
+            const int y2 = SMALL ? round_clamp_small(vy, yhi) : clamp0(round_to_i32_x86(vy), yhi);   // :372, :375
+            boff[k] = __umul24((uint32_t)y2, W4) + ((uint32_t)x2 << 2);                       // 4W, H < 2^24 (launcher)
+        }
+    };
     for (int d0 = 0; d0 < D; d0 += RC_SEG) {
         const int sb = min(RC_SEG, D - d0);
+        // Software pipeline over the chunks of 8 d: the gathered census words of chunk c are requested before the
+        // arithmetic of chunk c+1 (some 200 instructions) and consumed after it, so the gather's latency -- L2 hits, a
+        // few hundred cycles -- no longer parks the wave once per chunk (round 3 counters: 29 % of the wave time in
+        // s_waitcnt with the loads waited for where they were issued).
+        uint32_t boff[8], word[8];
+        sample_offsets(d0, boff);
+#pragma unroll
+        for (int k = 0; k < 8; k++) word[k] = *(const uint32_t*)(cen2 + boff[k]);
         for (int c = 0; c < sb; c += 8) {
+            uint32_t nword[8];
+            if (c + 8 < sb) {                                                                 // wave-uniform
+                sample_offsets(d0 + c + 8, boff);
+#pragma unroll
+                for (int k = 0; k < 8; k++) nword[k] = *(const uint32_t*)(cen2 + boff[k]);
+            }
             uint32_t packed[2] = {0, 0};
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const double s = __dmul_rn(off, vzt[d0 + c + k]);                             // offset * vzInd
-                const double ox = __dmul_rn(s, ux), oy = __dmul_rn(s, uy);                    // :365-366
-                const double vx = __dadd_rn(bx, ox), vy = __dadd_rn(by, oy);
-                const int x2 = SMALL ? round_clamp_small(vx, xhi) : clamp0(round_to_i32_x86(vx), xhi);   // :371, :374
-                const int y2 = SMALL ? round_clamp_small(vy, yhi) : clamp0(round_to_i32_x86(vy), yhi);   // :372, :375
-                const uint32_t boff = __umul24((uint32_t)y2, W4) + ((uint32_t)x2 << 2);       // 4W, H < 2^24 (launcher)
-                const uint32_t cost = __popc(c1 ^ *(const uint32_t*)(cen2 + boff));           // :377-378
+                const uint32_t cost = __popc(c1 ^ word[k]);                                   // :377-378
                 asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(packed[k >> 2]) : "v"(cost), "n"(8 * (k & 3)));
             }
             *(uint2*)(myrow + c) = make_uint2(packed[0], packed[1]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) word[k] = nword[k];
         }
         __builtin_amdgcn_wave_barrier();
         for (uint32_t e = lane * 8u; e < 64u * (uint32_t)sb; e += 512u) {                     // tile -> HBM, whole lines

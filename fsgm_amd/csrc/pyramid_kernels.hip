@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void pyr_reduce_kernel(const uint8_t* __restri
 __global__ __launch_bounds__(256) void pyr_gray_kernel(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    rgb += (size_t)blockIdx.y * 3 * n;                       // frame
+    out += (size_t)blockIdx.y * n;
     const double v = __dadd_rn(__dadd_rn(__dmul_rn(0.298936021293775, (double)rgb[i]), __dmul_rn(0.587043074451121, (double)rgb[n + i])),
                                __dmul_rn(0.114020904255103, (double)rgb[2 * (size_t)n + i]));
     out[i] = (uint8_t)(int)floor(__dadd_rn(v, 0.5));
@@ -52,6 +54,9 @@ __global__ __launch_bounds__(256) void pyr_flow_kernel(PyrFlowArgs a) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.W || y >= a.H) return;
     const size_t n = (size_t)a.W * a.H, i = (size_t)y * a.W + x, ip = (size_t)y * a.mvW + x, nm = (size_t)a.mvW * a.mvH;
+    const size_t f = blockIdx.z;                             // frame
+    a.bestD += f * n; a.mvSub += f * 2 * n; a.mvPre += f * 2 * nm; a.flow += f * 2 * n;
+    if (a.next) a.next += f * a.next_frame_stride;
     const uint32_t best = a.bestD[i];
     const int sx = (int)(best / (uint32_t)a.Sy), sy = (int)(best % (uint32_t)a.Sy);
     const double vx = __dadd_rn(__dadd_rn((double)(sx - a.hor), a.mvPre[ip]), a.mvSub[i]);               // :59,:64
@@ -74,13 +79,13 @@ void launch_pyr_reduce(hipStream_t st, const uint8_t* in, uint8_t* out, int W, i
     hipLaunchKernelGGL(pyr_reduce_kernel, grid, dim3(256), 0, st, in, out, W, H, W2, H2);
 }
 
-void launch_pyr_gray(hipStream_t st, const uint8_t* rgb, uint8_t* out, int W, int H) {
+void launch_pyr_gray(hipStream_t st, const uint8_t* rgb, uint8_t* out, int W, int H, int frames) {
     const int n = W * H;
-    hipLaunchKernelGGL(pyr_gray_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rgb, out, n);
+    hipLaunchKernelGGL(pyr_gray_kernel, dim3((n + 255) / 256, frames), dim3(256), 0, st, rgb, out, n);
 }
 
-void launch_pyr_flow(hipStream_t st, const PyrFlowArgs& a) {
-    dim3 grid((a.W + 63) / 64, (a.H + 3) / 4);
+void launch_pyr_flow(hipStream_t st, const PyrFlowArgs& a, int frames) {
+    dim3 grid((a.W + 63) / 64, (a.H + 3) / 4, frames);
     hipLaunchKernelGGL(pyr_flow_kernel, grid, dim3(256), 0, st, a);
 }
 

@@ -23,6 +23,9 @@ def _bind(lib):
     lib.fsgm_pyramid_params_default.restype = PyramidParams
     lib.fsgm_pyramidal_sgm_host.argtypes = [vp, vp, i32, i32, i32, C.POINTER(PyramidParams), vp, vp, vp]
     lib.fsgm_pyramid_plan_create.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(PyramidParams)]
+    lib.fsgm_pyramid_plan_create_batch.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(PyramidParams), i32]
+    lib.fsgm_pyramid_plan_upload_frame.argtypes = [vp, i32, vp, vp]
+    lib.fsgm_pyramid_plan_download_frame.argtypes = [vp, i32, i32, vp, vp]
     lib.fsgm_pyramid_plan_destroy.argtypes = [vp]
     lib.fsgm_pyramid_plan_destroy.restype = None
     lib.fsgm_pyramid_plan_level_size.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -78,13 +81,13 @@ def pyramidal_sgm(I0, I1, numPyd=5, *, device=0, **overrides):
 class PyramidPlan:
     """Device-resident pyramid for one image shape: upload a pair, run, download any level."""
 
-    def __init__(self, width, height, channels=1, numPyd=5, *, device=0, **overrides):
+    def __init__(self, width, height, channels=1, numPyd=5, *, device=0, batch=1, **overrides):
         self.lib = _lib.load()
         _bind(self.lib)
         self.prm = _params(self.lib, numPyd, device, overrides)
-        self.W, self.H, self.channels = int(width), int(height), int(channels)
+        self.W, self.H, self.channels, self.batch = int(width), int(height), int(channels), int(batch)
         self._h = C.c_void_p()
-        check(self.lib.fsgm_pyramid_plan_create(C.byref(self._h), self.W, self.H, self.channels, C.byref(self.prm)))
+        check(self.lib.fsgm_pyramid_plan_create_batch(C.byref(self._h), self.W, self.H, self.channels, C.byref(self.prm), self.batch))
 
     def close(self):
         if self._h:
@@ -108,11 +111,11 @@ class PyramidPlan:
         check(self.lib.fsgm_pyramid_plan_level_size(self._h, int(level), C.byref(w), C.byref(h)))
         return w.value, h.value
 
-    def upload(self, I0, I1):
+    def upload(self, I0, I1, frame=0):
         I0, I1, ch = _check_images(I0, I1)
         if ch != self.channels or I0.shape[-2:] != (self.H, self.W):
             raise ValueError("shape mismatch with the plan")
-        check(self.lib.fsgm_pyramid_plan_upload(self._h, ptr(I0), ptr(I1)))
+        check(self.lib.fsgm_pyramid_plan_upload_frame(self._h, int(frame), ptr(I0), ptr(I1)))
 
     def run(self):
         check(self.lib.fsgm_pyramid_plan_run(self._h))
@@ -125,11 +128,11 @@ class PyramidPlan:
         """Only impyramid / rgb2gray (the level images), no matching."""
         check(self.lib.fsgm_pyramid_plan_run_images(self._h))
 
-    def download(self, level=1):
+    def download(self, level=1, frame=0):
         w, h = self.level_size(level)
         mv = np.empty((2, h, w), np.float64)
         minC = np.empty((h, w), np.uint32)
-        check(self.lib.fsgm_pyramid_plan_download(self._h, int(level), ptr(mv), ptr(minC)))
+        check(self.lib.fsgm_pyramid_plan_download_frame(self._h, int(frame), int(level), ptr(mv), ptr(minC)))
         return mv, minC
 
     def download_gray(self, level=1):

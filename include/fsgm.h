@@ -287,6 +287,12 @@ fsgm_status fsgm_pyramidal_sgm_host(const uint8_t* I0, const uint8_t* I1, int32_
 typedef struct fsgm_pyramid_plan fsgm_pyramid_plan;
 fsgm_status fsgm_pyramid_plan_create(fsgm_pyramid_plan** plan, int32_t width, int32_t height,
                                      int32_t channels, const fsgm_pyramid_params* prm);
+/* the same with `batch` image pairs resident: every kernel of a level covers all of them (frames are independent; a level
+ * still needs the level above).  upload_frame / download_frame address one pair; upload / download are frame 0. */
+fsgm_status fsgm_pyramid_plan_create_batch(fsgm_pyramid_plan** plan, int32_t width, int32_t height, int32_t channels,
+                                           const fsgm_pyramid_params* params, int32_t batch);
+fsgm_status fsgm_pyramid_plan_upload_frame(fsgm_pyramid_plan* plan, int32_t frame, const uint8_t* I0, const uint8_t* I1);
+fsgm_status fsgm_pyramid_plan_download_frame(fsgm_pyramid_plan* plan, int32_t frame, int32_t level, double* mv, uint32_t* minC);
 void        fsgm_pyramid_plan_destroy(fsgm_pyramid_plan* plan);
 /* size of pyramid level `level` (1 = full resolution) */
 fsgm_status fsgm_pyramid_plan_level_size(fsgm_pyramid_plan* plan, int32_t level, int32_t* width, int32_t* height);

@@ -196,3 +196,22 @@ def test_ng_pyramid_batch_matches_single_pairs(gpu_lib, oracle):
         for li in range(3):
             np.testing.assert_array_equal(got[f][li][0], flows[li], err_msg=f"frame {f} level {3 - li}")
         np.testing.assert_array_equal(got[f][2][1], minC, err_msg=f"frame {f}")
+
+
+def test_pyramid_batch_matches_single_pairs(gpu_lib, oracle):
+    """A batch of image pairs through one PyramidPlan (every kernel of a level covers all frames: fsgm_pyramid_plan_create_batch)
+    = the same pairs one at a time = the oracle's pyramidal_sgm (pyramidal_sgm.m:24-76), all levels, RGB and gray."""
+    W, H, B = 83, 61, 5
+    for ch in (3, 1):
+        pairs = [_pair(W, H, ch, seed=21 + f) for f in range(B)]
+        with PyramidPlan(W, H, ch, 3, batch=B) as plan:
+            for f, (a, b) in enumerate(pairs):
+                plan.upload(a, b, frame=f)
+            for _ in range(2):                                  # twice: buffers are reused
+                plan.run()
+            got = [[plan.download(l, frame=f) for l in (1, 2, 3)] for f in range(B)]
+        for f, (a, b) in enumerate(pairs):
+            want_mv, want_minC, want_lv = oracle.pyramidal_sgm(a, b, 3)
+            for l in (1, 2, 3):
+                np.testing.assert_array_equal(got[f][l - 1][0], want_lv[l - 1], err_msg=f"{ch} channels, frame {f}, level {l}")
+            np.testing.assert_array_equal(got[f][0][1], want_minC, err_msg=f"{ch} channels, frame {f}")

@@ -2,6 +2,7 @@
 //   calib_valu_pk      8 waves per SIMD issuing nothing but independent v_pk_maximum3_f16: the VALU issue ceiling for the
 //                      packed instructions the SGM step is made of ("VALU busy" of a saturated SIMD)
 //   calib_valu_vop2    the same with v_and_b32 (32-bit encoding)
+//   calib_valu_f64     the same with v_mul_f64, calib_valu_cvt64 with v_cvt_i32_f64 (the cost fill's instruction classes)
 //   calib_lds_b128     every lane reads and writes 16 contiguous bytes (lane * 16): the conflict-free ds_read_b128 /
 //                      ds_write_b128 pattern of the sweeps' diagonal states -- what SQ_LDS_BANK_CONFLICT reads for it
 //   calib_lds_conf32   ds_write_b32 with a 128-byte lane stride: every lane of a group on one bank (32-way conflict)
@@ -29,6 +30,28 @@ __global__ __launch_bounds__(256) void calib_valu_vop2(uint32_t* out, uint32_t s
         for (int i = 0; i < 8; i++) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
     uint32_t s = 0;
     for (int i = 0; i < 8; i++) s += a[i];
+    if (s == 0x12345678u) out[0] = s;
+}
+// the cost fill's instruction classes: fp64 multiply / add and the fp64 -> integer conversion
+__global__ __launch_bounds__(256) void calib_valu_f64(double* out, double seed, int iters) {
+    double a[8], b = seed + threadIdx.x * 1e-3;
+    for (int i = 0; i < 8; i++) a[i] = seed * (i + 3) + threadIdx.x;
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+    double s = 0;
+    for (int i = 0; i < 8; i++) s += a[i];
+    if (s == 0.12345) out[0] = s;
+}
+__global__ __launch_bounds__(256) void calib_valu_cvt64(uint32_t* out, double seed, int iters) {
+    double a[8];
+    uint32_t r[8];
+    for (int i = 0; i < 8; i++) { a[i] = seed * (i + 3) + threadIdx.x; r[i] = 0; }
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(r[i]) : "v"(a[i]));
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s += r[i];
     if (s == 0x12345678u) out[0] = s;
 }
 __global__ __launch_bounds__(256) void calib_lds_b128(uint32_t* out, int iters) {
@@ -78,6 +101,8 @@ int main() {
     for (int rep = 0; rep < 3; rep++) {
         hipLaunchKernelGGL(calib_valu_pk, dim3(256 * 8), dim3(256), 0, 0, d, 12345u, 4096);
         hipLaunchKernelGGL(calib_valu_vop2, dim3(256 * 8), dim3(256), 0, 0, d, 12345u, 4096);
+        hipLaunchKernelGGL(calib_valu_f64, dim3(256 * 8), dim3(256), 0, 0, (double*)d, 1.000001, 2048);
+        hipLaunchKernelGGL(calib_valu_cvt64, dim3(256 * 8), dim3(256), 0, 0, d, 1.5, 2048);
         hipLaunchKernelGGL(calib_lds_b128, dim3(256 * 4), dim3(256), 0, 0, d, 4096);
         hipLaunchKernelGGL(calib_lds_conf32, dim3(256 * 2), dim3(256), 0, 0, d, 1024);
         hipLaunchKernelGGL(calib_lds_row8, dim3(256 * 4), dim3(256), 0, 0, d, 2048);
