@@ -45,6 +45,11 @@ struct fsgm_epi_plan {
     // band sweeps (epi_band.hip): the first pass's 9th bits, the hand-off between the bands of a frame; dX, dRec, dS0 as above
     uint32_t* dBits = nullptr;
     uint4* dBandEdge = nullptr;
+    size_t band_edge_maps = 0;           // hand-off maps per frame the buffer holds (1: bands in sequence; bands - 1: chained)
+    uint32_t *dBandTicket = nullptr, *dBandErr = nullptr;   // chained band sweeps: work counter, give-up flag of the bounded waits
+    uint32_t band_salt = 0;              // launch sequence number of the chained form (hand-off tags)
+    bool band_chain = false;             // AGG_BAND only: one workgroup per (band, frame) instead of one per frame
+    bool band_edge_untagged = false;     // the hand-off maps hold words without this scheme's tags (sequential form, S tap): refill before a chained launch
     // epipolar driver (fsgm_epipolar_sgm_of_host): rotation flow, composed flow, RGB staging
     double *dRflow = nullptr, *dFlow = nullptr;
     uint8_t* dRgb = nullptr;
@@ -128,9 +133,12 @@ static void select_kernel(fsgm_epi_plan* p) {
     // the excess sum of a pair fits a byte)
     if (fusable && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
     // very large batches (or mode 4): the band sweeps
-    if (fusable && band_ok(p->D, p->prm.paths, p->P1, p->P2, cm) && (p->agg_mode == 4 || (p->agg_mode == 0 && band_pays(p->batch, p->cus, p->prm.paths)))) {
+    p->band_chain = false;
+    if (fusable && band_ok(p->D, p->prm.paths, p->P1, p->P2, cm) &&
+        (p->agg_mode == 4 || p->agg_mode == 5 || (p->agg_mode == 0 && band_pays(p->batch, p->cus, p->prm.paths)))) {
         p->kernel_kind = AGG_BAND;
         p->sweep_par = false;
+        p->band_chain = p->agg_mode == 5;                    // mode 5: the bands of a frame as workgroups of their own (chained)
     }
 }
 
@@ -207,7 +215,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dXupAll, p->dStateUp, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dEdge, p->dTicket, p->dErr, p->dBits, p->dBandEdge};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dXupAll, p->dStateUp, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dEdge, p->dTicket, p->dErr, p->dBits, p->dBandEdge, p->dBandTicket, p->dBandErr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -476,17 +484,29 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
 }
 
 static fsgm_status ensure_band_buffers(fsgm_epi_plan* p) {
-    if (p->dBandEdge && p->dX && p->dRec && p->dS0) return FSGM_OK;
+    const int R = band_rows(p->D);
+    const size_t nbands = R ? (size_t)(p->H + R - 1) / R : 1;
+    const size_t maps = p->band_chain ? (nbands > 1 ? nbands - 1 : 1) : 1;
+    if (p->dBandEdge && p->band_edge_maps >= maps && p->dX && p->dRec && p->dS0 && (!p->band_chain || p->dBandTicket)) return FSGM_OK;
     const size_t B = p->batch;
     LazySet ls;
-    uint8_t* x = p->dX; uint4 *rec = p->dRec, *edge = p->dBandEdge; uint16_t* s0 = p->dS0; uint32_t* bits = p->dBits;
+    uint8_t* x = p->dX; uint4 *rec = p->dRec, *edge = p->dBandEdge; uint16_t* s0 = p->dS0; uint32_t *bits = p->dBits, *ticket = p->dBandTicket, *err = p->dBandErr;
+    const bool new_edge = !edge || p->band_edge_maps < maps;
+    const size_t edge_bytes = B * maps * band_edge_uint4s(p->W, p->D, 8) * sizeof(uint4);
     if (!x) ls.alloc(&x, B * p->N);
     if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint4));
     if (!s0) ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
-    if (!edge) ls.alloc(&edge, B * band_edge_uint4s(p->W, p->D, 8) * sizeof(uint4));
+    if (new_edge) ls.alloc(&edge, edge_bytes);
     if (!bits && p->prm.paths == 8) ls.alloc(&bits, B * band_bits_u32s(p->W, p->H, p->D) * sizeof(uint32_t));
+    if (p->band_chain && !ticket) { ls.alloc(&ticket, sizeof(uint32_t)); ls.alloc(&err, sizeof(uint32_t)); }
+    // chained form: hand-off dwords carry a launch tag in their bytes' top bits; all ones = "older than any launch"
+    if (ls.err == hipSuccess && new_edge && p->band_chain) ls.err = hipMemsetAsync(edge, 0xFF, edge_bytes, p->stream);
+    if (ls.err == hipSuccess && p->band_chain && !p->dBandErr) ls.err = hipMemsetAsync(err, 0, sizeof(uint32_t), p->stream);
     if (ls.err != hipSuccess) return lazy_fail(ls, "band pipeline buffers");
-    p->dX = x; p->dRec = rec; p->dS0 = s0; p->dBandEdge = edge; p->dBits = bits;
+    if (new_edge && p->dBandEdge) { (void)hipStreamSynchronize(p->stream); (void)hipFree(p->dBandEdge); }
+    if (new_edge) p->band_salt = 0;
+    p->dX = x; p->dRec = rec; p->dS0 = s0; p->dBandEdge = edge; p->band_edge_maps = new_edge ? maps : p->band_edge_maps; p->dBits = bits;
+    p->dBandTicket = ticket; p->dBandErr = err;
     return FSGM_OK;
 }
 
@@ -640,15 +660,30 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         }
     } else if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_BAND) {
         // all four paths of a raster pass in one sweep, one workgroup per frame: first pass -> Y (+ 9th bits), second pass + WTA
-        BandArgs b;
+        BandArgs b{};
         b.C = p->dC; b.c_frame_stride = p->N;
         b.Y = p->dX; b.y_frame_stride = p->N;
         b.Yb = p->dBits; b.yb_frame_stride = band_bits_u32s(p->W, p->H, p->D);
-        b.edge = p->dBandEdge; b.edge_frame_stride = band_edge_uint4s(p->W, p->D, 8);
+        b.edge = p->dBandEdge; b.edge_frame_stride = p->band_edge_maps * band_edge_uint4s(p->W, p->D, 8);
         b.rec = p->dRec; b.s0 = p->dS0; b.Sdbg = nullptr;
         b.W = p->W; b.H = p->H; b.D = p->D; b.P1 = p->P1; b.P2 = p->P2;
-        launch_band(p->stream, b, p->batch, p->prm.paths, 0);
-        launch_band(p->stream, b, p->batch, p->prm.paths, 2);
+        b.chain = p->band_chain ? 1 : 0;
+        b.frames = p->batch; b.nbands = (p->H + band_rows(p->D) - 1) / band_rows(p->D);
+        { static const int g = env_int("FSGM_BAND_GROUP", 0); b.group = g > 0 ? std::min(g, p->batch) : p->batch; }   // frames whose bands are dealt band-major (A/B knob)
+        b.ticket = p->dBandTicket; b.err = p->dBandErr;
+        if (b.chain && p->band_edge_untagged) {              // words of the sequential form / the S tap could pass for tag 0: all ones is never a tag
+            FSGM_HIP(hipMemsetAsync(p->dBandEdge, 0xFF, (size_t)p->batch * b.edge_frame_stride * sizeof(uint4), p->stream));
+            p->band_edge_untagged = false;
+        }
+        if (!b.chain) p->band_edge_untagged = true;
+        for (int mode = 0; mode <= 2; mode += 2) {
+            if (b.chain) {                                   // the work counter restarts on the stream ahead of every launch; a fresh hand-off tag
+                const uint32_t t = p->band_salt++ % 15u;     // 0..14: the all-ones pattern of the initial fill is never a valid tag
+                b.tag = ((t & 1u) << 7) | ((t & 2u) << 14) | ((t & 4u) << 21) | ((t & 8u) << 28);
+                FSGM_HIP(hipMemsetAsync(b.ticket, 0, sizeof(uint32_t), p->stream));
+            }
+            launch_band(p->stream, b, p->batch, p->prm.paths, mode);
+        }
     } else if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_PAIRS) {
         // 4 paths: the horizontal pair -> X_h on stream_h while the vertical pair's checkpoint pass runs
         // here; then the vertical sum pass adds X_h + 4*C and does the WTA (7.5 B per voxel, S never in HBM)
@@ -759,7 +794,7 @@ fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* p, int32_t stages) {
 
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* p, int32_t mode) {
     FSGM_REQUIRE(p, "null plan");
-    FSGM_REQUIRE(mode >= 0 && mode <= 4, "agg mode must be 0 (auto), 1 (per-direction kernels), 2 (fused sweeps), 3 (parallel sweeps) or 4 (band sweeps)");
+    FSGM_REQUIRE(mode >= 0 && mode <= 5, "agg mode must be 0 (auto), 1 (per-direction kernels), 2 (fused sweeps), 3 (parallel sweeps), 4 (band sweeps) or 5 (chained band sweeps)");
     p->agg_mode = mode;
     select_kernel(p);
     return FSGM_OK;
@@ -767,6 +802,14 @@ fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* p, int32_t mode) {
 
 // the strip sweeps' bounded hand-off waits raise a device flag instead of hanging: surface it after a sync
 static fsgm_status check_handoff(fsgm_epi_plan* p) {
+    if (p->band_chain && p->dBandErr) {                          // chained band sweeps: bounded waits between the bands of a frame
+        uint32_t e = 0;
+        FSGM_HIP(hipMemcpy(&e, p->dBandErr, sizeof(e), hipMemcpyDeviceToHost));
+        if (e != 0) {
+            (void)hipMemset(p->dBandErr, 0, sizeof(e));
+            return fail(FSGM_ERR_HIP, "band sweep: a hand-off between the bands of a frame timed out (results of this run are invalid)");
+        }
+    }
     if (!p->strips || !p->dErr) return FSGM_OK;                  // only the strip sweeps wait inside a kernel
     uint32_t e = 0;
     FSGM_HIP(hipMemcpy(&e, p->dErr, sizeof(e), hipMemcpyDeviceToHost));
@@ -893,17 +936,18 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         fsgm_status es = ensure_band_buffers(p);
         if (es != FSGM_OK) return es;
         if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
-        BandArgs b;
+        BandArgs b{};
         const size_t fs = (size_t)f;
         b.C = p->dC + fs * p->N; b.c_frame_stride = p->N;
         b.Y = p->dX + fs * p->N; b.y_frame_stride = p->N;
         b.yb_frame_stride = band_bits_u32s(p->W, p->H, p->D);
         b.Yb = p->dBits ? p->dBits + fs * b.yb_frame_stride : nullptr;
-        b.edge_frame_stride = band_edge_uint4s(p->W, p->D, 8);
+        b.edge_frame_stride = p->band_edge_maps * band_edge_uint4s(p->W, p->D, 8);
         b.edge = p->dBandEdge + fs * b.edge_frame_stride;
         b.rec = p->dRec + fs * p->NP; b.s0 = p->dS0 + fs * p->NP; b.Sdbg = p->dS;
         b.W = p->W; b.H = p->H; b.D = p->D; b.P1 = p->P1; b.P2 = p->P2;
         launch_band(p->stream, b, 1, p->prm.paths, 2);
+        p->band_edge_untagged = true;
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));
         FSGM_HIP(hipMemcpy(S, p->dS, p->N * 4, hipMemcpyDeviceToHost));
@@ -948,7 +992,7 @@ const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* p) {
         case AGG_PACKED_WRAP: return "packed16/wrap";
         case AGG_SWEEP: return p->sweep_par ? "sweep16par/nowrap" : "sweep16/nowrap";
         case AGG_PAIRS: return "pairs16/nowrap";
-        case AGG_BAND: return "band16/nowrap";
+        case AGG_BAND: return p->band_chain ? "band16chain/nowrap" : "band16/nowrap";
         default: return "generic";
     }
 }

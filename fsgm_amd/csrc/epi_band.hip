@@ -55,6 +55,9 @@ namespace fsgm {
 #ifndef FSGM_BAND_PF4
 #define FSGM_BAND_PF4 3         // the same for both passes of the 4-path form (A/B knob; 1 / 2 / 3 / 4: 31.5 / 30.0 / 28.9 / 29.1 ms per 512 frames)
 #endif
+#ifndef FSGM_BAND_SLACK
+#define FSGM_BAND_SLACK 32      // chained form: columns of lead a band gives the band above before it starts (A/B knob)
+#endif
 #ifndef FSGM_BAND_WAVES
 #define FSGM_BAND_WAVES 8        // waves per band workgroup (8: 64-row bands at D = 128, two workgroups per CU)
 #endif
@@ -80,7 +83,7 @@ __device__ __forceinline__ void unpack_p9(const uint4 v, const uint32_t bits, ui
     }
 }
 
-template <int LPP, int MODE, int NWV, int PATHS, bool BITS, bool TAP>
+template <int LPP, int MODE, int NWV, int PATHS, bool BITS, bool TAP, bool CHAIN>
 __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs a) {
     constexpr bool UP = MODE != 0;
     constexpr bool P8 = PATHS == 8;
@@ -92,16 +95,33 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
     constexpr int PF = P8 ? (MODE == 2 ? FSGM_BAND_PF2 : FSGM_BAND_PF) : FSGM_BAND_PF4;   // 4 paths: half the registers, twice the bytes per instruction
     __shared__ uint4 sSt[2][NST][(R + 1) * LPP];              // [step parity][state][row slot (row + 1; slot 0 = the row above the band)][lane of pixel]
     __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 4];   // final pass: S of the wave's pixels (u16, two planes: epi_step.h)
+    __shared__ uint32_t sTicket;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPP, j = lane % LPP;
     const int r = wave * PXG + g;                              // row within the band
     const int W = a.W, H = a.H, NP = W * H;
-    const size_t f = blockIdx.x;
+    // CHAIN: this workgroup walks ONE band of one frame; the bands of a frame run at the same time as workgroups of their own
+    // and hand their last row's states over while they run (below).  (band, frame) come from a ticket counter, band-major
+    // within a group of frames, so the band above always holds an earlier ticket: it is running or done, whatever the dispatch
+    // order or placement.
+    int cband = 0;
+    size_t f = blockIdx.x;
+    if (CHAIN) {
+        if (tid == 0) sTicket = atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        const uint32_t t = __builtin_amdgcn_readfirstlane(sTicket);
+        const uint32_t per = (uint32_t)a.group * (uint32_t)a.nbands, grp = t / per, rem = t - grp * per;
+        const uint32_t fin = min((uint32_t)a.group, (uint32_t)a.frames - grp * (uint32_t)a.group);    // frames in this group
+        cband = (int)(rem / fin);
+        f = (size_t)grp * a.group + rem % fin;
+        if (cband >= a.nbands || f >= (size_t)a.frames) return;                                        // (never: the grid is frames x bands)
+    }
     const uint8_t* __restrict__ Cf = a.C + f * a.c_frame_stride;
     uint8_t* __restrict__ Yf = a.Y + f * a.y_frame_stride;
     uint8_t* __restrict__ Bf = BITS ? (uint8_t*)(a.Yb + f * a.yb_frame_stride) : nullptr;     // [NP][LPP] dwords
-    uint8_t* __restrict__ Ef = (uint8_t*)(a.edge + f * a.edge_frame_stride);                  // [W][NST][LPP] uint4
+    uint8_t* __restrict__ Ef = (uint8_t*)(a.edge + f * a.edge_frame_stride);                  // [W][NST][LPP] uint4 (CHAIN: one such map per band boundary)
+    const uint32_t tag = CHAIN ? a.tag : 0u;
     uint8_t* __restrict__ recb = MODE == 2 ? (uint8_t*)(a.rec + f * (size_t)NP) : nullptr;
     uint8_t* __restrict__ s0b = MODE == 2 ? (uint8_t*)(a.s0 + f * (size_t)NP) : nullptr;
     // every global access below is a wave-uniform base + a 32-bit byte offset per lane (no 64-bit address registers)
@@ -113,7 +133,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 
     auto pix_of = [&](int x, int y) -> int { const int p = y * W + x; return UP ? NP - 1 - p : p; };
 
-    for (int yb = 0; yb < H; yb += R) {                        // ---- one band ----
+    for (int yb = CHAIN ? cband * R : 0; yb < (CHAIN ? cband * R + 1 : H); yb += R) {   // ---- one band (CHAIN: this workgroup's only one) ----
         const int Rp = min(R, H - yb);
         const int y = yb + r, yc = min(y, H - 1);
         const bool row_ok = r < Rp;
@@ -137,18 +157,57 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             const int x = min(max(u - SKEW * r, 0), W - 1);
             return ((uint32_t)pix_of(x, yc) * LPP + (uint32_t)j) * 4u;
         };
-        auto edge_at = [&](int x) -> const uint8_t* { return Ef + ((uint32_t)min(max(x, 0), W - 1) * (NST * LPP) + (uint32_t)elane) * 16u; };
+        // hand-off maps of this band: the one it reads (written by the band above) and the one it writes
+        const uint32_t emap = (uint32_t)W * (NST * LPP) * 16u;
+        const uint8_t* __restrict__ Ein = CHAIN ? Ef + (uint32_t)max(cband - 1, 0) * emap : Ef;
+        uint8_t* __restrict__ Eout = CHAIN ? Ef + (uint32_t)cband * emap : Ef;
+        auto edge_at = [&](int x) -> const uint8_t* { return Ein + ((uint32_t)min(max(x, 0), W - 1) * (NST * LPP) + (uint32_t)elane) * 16u; };
+        // CHAIN: a hand-off word is this launch's when every dword carries the launch's tag in its bytes' top bits (states are
+        // below 128); the band above may not have got there yet: poll, bounded, and raise a.err instead of hanging
+        bool gave_up = false;                                  // (wave 0) a hand-off wait timed out: results are invalid, finish without waiting
+        auto fresh = [&](const uint4 v) -> bool { return (((v.x ^ tag) | (v.y ^ tag) | (v.z ^ tag) | (v.w ^ tag)) & 0x80808080u) == 0u; };
+        auto eload = [&](const uint8_t* q) -> uint4 { return CHAIN ? edge_load((const uint4*)q) : load_nt(q); };
+        auto settle = [&](uint4 v, const uint8_t* q, const bool mine) -> uint4 {       // mine: this lane takes part in the hand-off
+            if (CHAIN) {
+                // a wait of 2^18 polls (a good fraction of a second; the longest legitimate one is a few milliseconds: the band
+                // above is 2R columns ahead by construction) gives up for good -- this workgroup and, through a.err, every other
+                for (uint32_t spins = 0; !gave_up && !__all(!mine || fresh(v)); spins++) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (mine) v = edge_load((const uint4*)q);
+                    if (spins > (1u << 18) || ((spins & 1023u) == 1023u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        if (lane == 0) atomicOr(a.err, 1u);
+                        gave_up = true;
+                    }
+                }
+                v.x &= 0x7F7F7F7Fu; v.y &= 0x7F7F7F7Fu; v.z &= 0x7F7F7F7Fu; v.w &= 0x7F7F7F7Fu;
+            }
+            return v;
+        };
 
         uint32_t FS[8];                                        // from the left: stays in these lanes
 #pragma unroll
         for (int i = 0; i < 8; i++) FS[i] = P2pk;
         // from above / from above-left of the row above, read one / two steps before they are used
         uint4 hU = startP, hD1 = startP, hD2 = startP;
-        if (P8 && have_above && r == 0) {                      // row 0: column 0 of the band above ("read at step -1")
-            hU = load_nt(Ef + (uint32_t)(0 * LPP + j) * 16u);
-            hD1 = load_nt(Ef + (uint32_t)(1 * LPP + j) * 16u);
+        if (P8 && have_above && wave == 0) {                   // row 0: column 0 of the band above ("read at step -1"); wave-uniform
+            const bool mine = r == 0;
+            const uint8_t* q0 = Ein + (uint32_t)(0 * LPP + j) * 16u;
+            const uint8_t* q1 = Ein + (uint32_t)(1 * LPP + j) * 16u;
+            const uint4 v0 = settle(mine ? eload(q0) : startP, q0, mine), v1 = settle(mine ? eload(q1) : startP, q1, mine);
+            if (mine) { hU = v0; hD1 = v1; }
         }
-        if (loader) sSt[1][elane / LPP][elane % LPP] = load_nt(edge_at(SKEW - 1));     // what row 0 reads at step 0
+        if (CHAIN && wave == 0 && have_above) {
+            // Start only once the band above is FSGM_BAND_SLACK columns further than the first step needs: both bands then
+            // advance at the same rate with that much slack between them, and a step's hand-off words are there when they are
+            // asked for (without it the two run in lock step and every hiccup of the band above is a poll down here).
+            const uint8_t* q = edge_at(min(SKEW + FSGM_BAND_SLACK, W - 1));
+            (void)settle(loader ? eload(q) : startP, q, loader);
+        }
+        if (wave == 0 && have_above) {                         // what row 0 reads at step 0
+            const uint8_t* q = edge_at(SKEW - 1);
+            const uint4 v = settle(loader ? eload(q) : startP, q, loader);
+            if (loader) sSt[1][elane / LPP][elane % LPP] = v;
+        }
         uint4 ringC[PF], ringY[MODE == 2 ? PF : 1];
         uint4 nextE = startP;                                  // wave 0: the band above's states for the next step (one step ahead: L2 / MALL resident)
         uint32_t ringB[MODE == 2 && BITS ? PF : 1];
@@ -158,7 +217,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             ringC[i] = *(const uint4*)(Cf + off);
             if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = *(const uint32_t*)(Bf + bit_off(i)); }
         }
-        if (loader) nextE = load_nt(edge_at(SKEW));
+        if (loader) nextE = eload(edge_at(SKEW));
         __syncthreads();
 
         // one step of this wave's rows.  EDGE: a pixel of the wave is at / outside an image border or in row 0, or a row
@@ -243,9 +302,17 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             }
             // the band's last row hands its states to the band below, by image column
             if (!last_band && r == R - 1 && inside) {
-                uint8_t* o = Ef + ((uint32_t)xc * (NST * LPP) + (uint32_t)j) * 16u;
-                *(uint4*)o = newU;
-                if constexpr (P8) { *(uint4*)(o + LPP * 16) = newD; *(uint4*)(o + 2 * LPP * 16) = newR; }
+                uint8_t* o = Eout + ((uint32_t)xc * (NST * LPP) + (uint32_t)j) * 16u;
+                if (CHAIN) {                                   // read while this band runs: tagged words, past the L1, coherent across the XCDs
+                    edge_store((uint4*)o, make_uint4(newU.x | tag, newU.y | tag, newU.z | tag, newU.w | tag));
+                    if constexpr (P8) {
+                        edge_store((uint4*)(o + LPP * 16), make_uint4(newD.x | tag, newD.y | tag, newD.z | tag, newD.w | tag));
+                        edge_store((uint4*)(o + 2 * LPP * 16), make_uint4(newR.x | tag, newR.y | tag, newR.z | tag, newR.w | tag));
+                    }
+                } else {
+                    *(uint4*)o = newU;
+                    if constexpr (P8) { *(uint4*)(o + LPP * 16) = newD; *(uint4*)(o + 2 * LPP * 16) = newR; }
+                }
             }
             if (MODE != 2) {
                 // the sum of this pass's y (:227-232): low bytes + 9th bits
@@ -268,9 +335,12 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             }
         };
         auto step = [&](const int u, const uint4 cw, const uint4 cy, const uint32_t cb) {
-            if (wave == 0 && loader) {                                                // "row -1" of step u: column u + SKEW of the band above
-                sSt[u & 1][elane / LPP][elane % LPP] = nextE;
-                nextE = load_nt(edge_at(u + 1 + SKEW));
+            if (wave == 0 && have_above) {                                            // "row -1" of step u: column u + SKEW of the band above
+                const uint4 v = settle(nextE, edge_at(u + SKEW), loader);
+                if (loader) {
+                    sSt[u & 1][elane / LPP][elane % LPP] = v;
+                    nextE = eload(edge_at(u + 1 + SKEW));
+                }
             }
             if (wave_rows && u >= act_lo && u <= act_hi) {                            // wave-uniform
                 if (wave_plain_rows && u >= pl_lo && u <= pl_hi) do_step(u, cw, cy, cb, std::false_type{});
@@ -298,16 +368,17 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 #pragma unroll
         for (int i = 0; i < PF - 1; i++)
             if (u0 + i < nsteps) step(u0 + i, ringC[i], ringY[MODE == 2 ? i : 0], ringB[MODE == 2 && BITS ? i : 0]);   // workgroup-uniform
-        // the band below reads what the last row stored: stores done before anyone goes on
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!CHAIN) {                                          // the band below reads what the last row stored: stores done before anyone goes on
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-size_t band_edge_uint4s(int W, int D, int paths) { const int lpp = agg_packed_lpp(D); return (size_t)W * (paths == 8 ? 3 : 1) * lpp; }   // per frame
+size_t band_edge_uint4s(int W, int D, int paths) { const int lpp = agg_packed_lpp(D); return (size_t)W * (paths == 8 ? 3 : 1) * lpp; }   // per frame and band boundary
 size_t band_bits_u32s(int W, int H, int D) { return (size_t)W * H * agg_packed_lpp(D); }                                                 // per frame
 // the first pass's sum of four (y + P1) needs a 9th bit above 255
 bool band_needs_bits(int paths, int P1, int P2) { return paths == 8 && 4 * (P1 + P2) > 255; }
@@ -321,17 +392,25 @@ template <int LPP, int MODE>
 static void launch_band_t(hipStream_t st, const BandArgs& a, int frames, int paths) {
     constexpr int NWV = FSGM_BAND_WAVES;
     const bool bits = band_needs_bits(paths, a.P1, a.P2);
-    dim3 grid((unsigned)frames), block(NWV * 64);
+    dim3 grid((unsigned)(a.chain ? frames * a.nbands : frames)), block(NWV * 64);
     if (MODE == 2 && a.Sdbg) {                               // the S debug tap: instantiations of their own, none of it in the product kernels
-        if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false, MODE == 2>), grid, block, 0, st, a);
-        else if (!bits)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, false, MODE == 2>), grid, block, 0, st, a);
-        else             hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, true, MODE == 2>), grid, block, 0, st, a);
+        if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false, MODE == 2, false>), grid, block, 0, st, a);
+        else if (!bits)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, false, MODE == 2, false>), grid, block, 0, st, a);
+        else             hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, true, MODE == 2, false>), grid, block, 0, st, a);
         return;
     }
-    if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false, false>), grid, block, 0, st, a);
-    else if (!bits)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, false, false>), grid, block, 0, st, a);
-    else             hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, true, false>), grid, block, 0, st, a);
+    if (a.chain) {
+        if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false, false, true>), grid, block, 0, st, a);
+        else if (!bits)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, false, false, true>), grid, block, 0, st, a);
+        else             hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, true, false, true>), grid, block, 0, st, a);
+        return;
+    }
+    if (paths == 4)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 4, false, false, false>), grid, block, 0, st, a);
+    else if (!bits)  hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, false, false, false>), grid, block, 0, st, a);
+    else             hipLaunchKernelGGL((band_kernel<LPP, MODE, NWV, 8, true, false, false>), grid, block, 0, st, a);
 }
+
+int band_rows(int D) { const int lpp = agg_packed_lpp(D); return lpp ? FSGM_BAND_WAVES * (64 / lpp) : 0; }   // rows per band
 
 // One whole pass of `frames` frames: mode 0 = first pass -> Y (+ bit plane), mode 2 = second pass + WTA records
 void launch_band(hipStream_t st, const BandArgs& a, int frames, int paths, int mode) {

@@ -96,6 +96,12 @@ struct BandArgs {
     uint4* rec;               // mode 2: [frames][NP] {best, minC, S[best-1], S[best+1]}
     uint16_t* s0;             // mode 2: [frames][NP] S[0] of every pixel
     uint32_t* Sdbg;           // mode 2, optional: natural-order u32 dump of S [frames][NP][D] (debug tap)
+    // chained form: one workgroup per (band, frame), the bands of a frame handing over while they run
+    int chain;                // 0: one workgroup per frame, band after band (edge: one map per frame, reused in place)
+    uint32_t* ticket;         // work counter, zero at launch
+    uint32_t tag;             // 4-bit launch sequence number spread over the top bits of a dword's bytes
+    uint32_t* err;            // set to non-zero when a hand-off wait gave up
+    int frames, nbands, group; // group: frames whose bands are dealt band-major (tickets)
     int W, H, D;
     int P1, P2;
 };
@@ -160,7 +166,8 @@ size_t pair_ckpt_bytes(int W, int H, int D, int axis);      // per frame; axis 0
 void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase = 0);
 bool pair_x_fine_ok(int D);                                                        // the along-x pair with 8 costs a lane exists for this D
 void launch_pair_x_fine(hipStream_t st, const PairArgs& a, int frames);            // checkpoint + sum pass, Y in natural d order
-size_t band_edge_uint4s(int W, int D, int paths);           // hand-off buffer between the bands of one frame, in uint4
+size_t band_edge_uint4s(int W, int D, int paths);           // one hand-off map between two bands of one frame, in uint4
+int    band_rows(int D);                                    // rows per band
 size_t band_bits_u32s(int W, int H, int D);                 // bit plane of one frame, in dwords
 bool   band_needs_bits(int paths, int P1, int P2);
 bool   band_ok(int D, int paths, int P1, int P2, int cmax);

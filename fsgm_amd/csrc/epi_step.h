@@ -170,6 +170,20 @@ __device__ __forceinline__ void step_b(uint32_t (&S)[8], const uint32_t (&CB)[8]
     for (int i = 0; i < 8; i++) S[i] = pk_subs(p2m, N[i]);
 }
 
+// hand-off words between workgroups that run at the same time (strip sweeps, chained band sweeps): written and read past
+// the L1 and coherently across the XCDs' L2s, 8 bytes at a time; every dword carries its launch's tag in its bytes' top bits
+__device__ __forceinline__ uint4 edge_load(const uint4* p) {
+    // two 8-byte agent-scope loads: served past the L1 and coherent across the XCDs' L2s
+    const unsigned long long lo = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ void edge_store(uint4* p, const uint4 v) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((unsigned long long*)p + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
 // Per-pixel WTA of the final passes: S (packed u16, register layout of the header) of the LPP lanes of a pixel -> one
 // record {best, minC, S[best-1], S[best+1]} + S[0] (calc_cost_sgm.cpp:263-271; the parabola runs in
 // sweep_finish_kernel).  First minimum over d: inside a lane as packed u16 keys S*16 + (index in the

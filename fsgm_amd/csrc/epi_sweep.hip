@@ -364,17 +364,6 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
 // Columns outside the image hold the path-start state (s = P2), so a diagonal that enters the image starts as the
 // reference's does (:156-180); waves whose columns are all at least 3 columns outside do nothing.
 // =============================================================================================
-__device__ __forceinline__ uint4 edge_load(const uint4* p) {
-    // two 8-byte agent-scope loads: served past the L1 and coherent across the XCDs' L2s
-    const unsigned long long lo = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-}
-__device__ __forceinline__ void edge_store(uint4* p, const uint4 v) {
-    __hip_atomic_store((unsigned long long*)p, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store((unsigned long long*)p + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <int LPP, int MODE>
 __global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
     constexpr bool UP = MODE != 0;

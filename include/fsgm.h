@@ -115,7 +115,8 @@ fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t
  * P1 <= P2 and 3*P2 <= 255; the shipped 4 paths: the pair kernels -- 2*P2 <= 255), 3 = 8 paths only: the down and the
  * up sweep side by side and a WTA kernel over the three sums (half the latency of 2, 3 B per voxel more traffic),
  * 4 = the band sweeps (epi_band.hip: all four paths of a raster pass in one sweep, one workgroup per frame, for batches of
- * hundreds of frames; D = 16<<k, no-wrap penalties with P1 <= P2 <= 127).
+ * hundreds of frames; D = 16<<k, no-wrap penalties with P1 <= P2, P1 + P2 <= 127), 5 = the band sweeps with the bands of a
+ * frame as workgroups of their own that hand their last row over while they run ("band16chain/nowrap").
  * Auto, 8 paths: line kernels below 5 frames, 3 below 18, 2 from there; 4 paths: line kernels below 9 frames, then 2
  * (the measured crossovers at 1242x375x128).  Results are identical. */
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* plan, int32_t mode);

@@ -157,3 +157,67 @@ def test_band_sweeps_kitti_shape_against_the_line_kernels_and_the_oracle(gpu_lib
             bd, mc = oracle.epi_wta(S, W, H, D, 1)
             np.testing.assert_array_equal(plan.download(0)[1], mc)
             np.testing.assert_array_equal(plan.download(0)[0], oracle.epi_vz_to_disp(bd, off, 0.3, D + 1))
+
+
+CHAIN_SHAPES = [(130, 150, 128, 3), (29, 65, 128, 2), (37, 64, 128, 1), (300, 200, 128, 2), (45, 70, 256, 2), (70, 260, 64, 1), (1, 140, 128, 1), (9, 1, 128, 2)]
+
+
+@pytest.mark.parametrize("paths", [8, 4])
+@pytest.mark.parametrize("W,H,D,B", CHAIN_SHAPES)
+def test_chained_band_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, paths):
+    """Mode 5: the bands of a frame as workgroups of their own that hand their last row's states over while they run
+    (tagged words, ticket order, bounded polls).  Several runs in a row (the hand-off tag changes from launch to launch),
+    the S tap in between (it leaves untagged words in a hand-off map), and a switch to the sequential form and back."""
+    vols = [synth.cost_volume(W, H, D, seed=W + 7 * H + f, cmax=24) for f in range(B)]
+    for v in vols:
+        v[:, ::5, :] = 0
+    _, _, off = synth.epi_maps(W, H, "general", seed=3)
+    with EpiPlan(W, H, D, B, paths=paths) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        for f in range(B):
+            plan.upload_cost(f, vols[f])
+            plan.upload_offset(f, off)
+        plan.set_agg_mode(5)
+        assert plan.kernel_name == "band16chain/nowrap"
+        for _ in range(3):
+            plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        _check(oracle, plan, vols, off, 6, 64, paths, W, H, D, taps=(0,))
+        for _ in range(17):                                  # through every tag value and around
+            plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        _check(oracle, plan, vols, off, 6, 64, paths, W, H, D, taps=())
+        plan.set_agg_mode(4)
+        plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        plan.set_agg_mode(5)
+        plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        _check(oracle, plan, vols, off, 6, 64, paths, W, H, D, taps=(B - 1,))
+        plan.sync()                                          # surfaces a timed-out hand-off, if any
+
+
+def test_chained_band_sweeps_kitti_shape(gpu_lib, oracle):
+    """1242x375x128, 6 bands per frame, 40 frames (240 workgroups in flight, the bands of every frame waiting on one another):
+    every frame against the sequential band sweeps, frame 0 against the oracle."""
+    W, H, D, B = 1242, 375, 128, 40
+    _, _, off = synth.epi_maps(W, H, "axis")
+    base = synth.cost_volume(W, H, D, seed=77, cmax=24)
+    for paths in (8, 4):
+        with EpiPlan(W, H, D, B, paths=paths) as plan:
+            plan.set_penalties(6, 64, 0.3)
+            plan.upload_cost(0, base)
+            plan.upload_offset(0, off)
+            for f in range(1, B):
+                plan.copy_cost(f, 0, 29 * f)
+                plan.upload_offset(f, off)
+            plan.set_agg_mode(4)
+            plan.run(STAGE_AGGREGATE | STAGE_WTA)
+            want = [plan.download(f) for f in range(B)]
+            plan.set_agg_mode(5)
+            for _ in range(2):
+                plan.run(STAGE_AGGREGATE | STAGE_WTA)
+            plan.sync()
+            for f in range(B):
+                got = plan.download(f)
+                np.testing.assert_array_equal(got[1], want[f][1], err_msg=f"{paths} paths, frame {f} minC")
+                np.testing.assert_array_equal(got[0], want[f][0], err_msg=f"{paths} paths, frame {f} bestD")
+            S = oracle.epi_aggregate(base, 6, 64, paths)
+            bd, mc = oracle.epi_wta(S, W, H, D, 1)
+            np.testing.assert_array_equal(want[0][1], mc)
