@@ -94,13 +94,20 @@ static int par_max_batch() { static const int v = env_int("FSGM_EPI_PAR_MAX", 18
 // mode takes the band sweeps where that is less than the batch (256 frames, 402..512, 638..768, ...).
 // FSGM_EPI_BAND_MIN: never below this many frames (0: never at all).
 static int band_min_batch() { static const int v = env_int("FSGM_EPI_BAND_MIN", 64); return v; }
-// (4 paths, against the pair pipeline's 0.09 ms per frame: 17.0 / 29.0 ms per round -> 0.74 x CUs / 0.63 x 2 CUs)
-static bool band_pays(int batch, int cus, int paths) {
-    if (band_min_batch() <= 0 || batch < band_min_batch()) return false;
+// (4 paths, against the pair pipeline's 0.084 ms per frame: 17.0 / 29.0 ms per round -> 0.74 x CUs / 0.63 x 2 CUs)
+// The chained form (one workgroup per band and frame, mode 5) has no rounds: measured 7 ms + 0.076 ms per frame at 8 paths
+// (profiles/r03_band_chain.txt: 96 .. 512 frames) = 0.26 x CUs + 0.71 per frame in the same units (4 paths: 0.23 x CUs + 0.68);
+// it takes the batches between the sequential form's rounds (257 .. ~470 frames, 513 .. ~700, ...).
+// Returns 0: neither pays, 1: sequential band sweeps, 2: chained.
+static int band_choice(int batch, int cus, int paths) {
+    if (band_min_batch() <= 0 || batch < band_min_batch()) return 0;
     const double half = paths == 8 ? 0.92 : 0.74, whole = paths == 8 ? 0.785 : 0.63;
     const int slots = 2 * cus, full = batch / slots, tail = batch % slots;
-    const double cost = full * whole * slots + (tail == 0 ? 0.0 : (tail <= cus ? half * cus : whole * slots));
-    return cost < (double)batch;
+    const double seq = full * whole * slots + (tail == 0 ? 0.0 : (tail <= cus ? half * cus : whole * slots));
+    static const int chain_ok = env_int("FSGM_EPI_BAND_CHAIN", 1);                      // 0: auto mode never takes the chained form
+    const double chain = chain_ok ? (paths == 8 ? 0.26 : 0.23) * cus + (paths == 8 ? 0.71 : 0.68) * batch : 1e30;
+    if (std::min(seq, chain) >= (double)batch) return 0;
+    return seq <= chain ? 1 : 2;
 }
 static int pairs_min_batch() { static const int v = env_int("FSGM_EPI_PAIRS_MIN", 9); return v; }   // 4 paths: line kernels -> pair pipeline
 
@@ -135,10 +142,11 @@ static void select_kernel(fsgm_epi_plan* p) {
     // very large batches (or mode 4): the band sweeps
     p->band_chain = false;
     if (fusable && band_ok(p->D, p->prm.paths, p->P1, p->P2, cm) &&
-        (p->agg_mode == 4 || p->agg_mode == 5 || (p->agg_mode == 0 && band_pays(p->batch, p->cus, p->prm.paths)))) {
+        (p->agg_mode == 4 || p->agg_mode == 5 || (p->agg_mode == 0 && band_choice(p->batch, p->cus, p->prm.paths) != 0))) {
         p->kernel_kind = AGG_BAND;
         p->sweep_par = false;
-        p->band_chain = p->agg_mode == 5;                    // mode 5: the bands of a frame as workgroups of their own (chained)
+        // mode 5 / auto between the sequential form's rounds: the bands of a frame as workgroups of their own (chained)
+        p->band_chain = p->agg_mode == 5 || (p->agg_mode == 0 && band_choice(p->batch, p->cus, p->prm.paths) == 2);
     }
 }
 

@@ -55,6 +55,12 @@ namespace fsgm {
 #ifndef FSGM_BAND_PF4
 #define FSGM_BAND_PF4 3         // the same for both passes of the 4-path form (A/B knob; 1 / 2 / 3 / 4: 31.5 / 30.0 / 28.9 / 29.1 ms per 512 frames)
 #endif
+#ifndef FSGM_BAND_PFE
+#define FSGM_BAND_PFE 4         // chained form: steps of hand-off words in flight, first pass (A/B knob)
+#endif
+#ifndef FSGM_BAND_PFE2
+#define FSGM_BAND_PFE2 2        // the same, second pass (registers)
+#endif
 #ifndef FSGM_BAND_SLACK
 #define FSGM_BAND_SLACK 32      // chained form: columns of lead a band gives the band above before it starts (A/B knob)
 #endif
@@ -209,7 +215,13 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             if (loader) sSt[1][elane / LPP][elane % LPP] = v;
         }
         uint4 ringC[PF], ringY[MODE == 2 ? PF : 1];
-        uint4 nextE = startP;                                  // wave 0: the band above's states for the next step (one step ahead: L2 / MALL resident)
+        // wave 0: the band above's states for the coming steps.  Sequential form: one step ahead (the lines were written a band
+        // earlier: L2 / Infinity Cache).  Chained form: the words were written moments ago by another CU with write-through stores
+        // and come from beyond the L2 -- a round trip of about a step's time -- so several steps are kept in flight.
+        constexpr int PFE = CHAIN ? (MODE == 2 ? FSGM_BAND_PFE2 : FSGM_BAND_PFE) : 1;
+        uint4 ringE[PFE];
+#pragma unroll
+        for (int i = 0; i < PFE; i++) ringE[i] = startP;
         uint32_t ringB[MODE == 2 && BITS ? PF : 1];
 #pragma unroll
         for (int i = 0; i < PF; i++) {
@@ -217,7 +229,10 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             ringC[i] = *(const uint4*)(Cf + off);
             if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = *(const uint32_t*)(Bf + bit_off(i)); }
         }
-        if (loader) nextE = eload(edge_at(SKEW));
+        if (loader) {
+#pragma unroll
+            for (int i = 0; i < PFE; i++) ringE[i] = eload(edge_at(SKEW + i));
+        }
         __syncthreads();
 
         // one step of this wave's rows.  EDGE: a pixel of the wave is at / outside an image border or in row 0, or a row
@@ -336,10 +351,12 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
         };
         auto step = [&](const int u, const uint4 cw, const uint4 cy, const uint32_t cb) {
             if (wave == 0 && have_above) {                                            // "row -1" of step u: column u + SKEW of the band above
-                const uint4 v = settle(nextE, edge_at(u + SKEW), loader);
+                const uint4 v = settle(ringE[0], edge_at(u + SKEW), loader);
+#pragma unroll
+                for (int i = 0; i + 1 < PFE; i++) ringE[i] = ringE[i + 1];       // (wave 0 only)
                 if (loader) {
                     sSt[u & 1][elane / LPP][elane % LPP] = v;
-                    nextE = eload(edge_at(u + 1 + SKEW));
+                    ringE[PFE - 1] = eload(edge_at(u + PFE + SKEW));
                 }
             }
             if (wave_rows && u >= act_lo && u <= act_hi) {                            // wave-uniform

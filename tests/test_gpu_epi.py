@@ -448,10 +448,10 @@ def test_parallel_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, subpixel)
 
 def test_auto_mode_by_batch_size(gpu_lib):
     """8 paths, no-wrap penalties: line kernels below 4 frames, parallel sweeps below 18, the full sweep pipeline from there,
-    the band sweeps where a round of one workgroup per frame pays (256 frames, 402..512, ...; plans are created lazily, so a
-    512-frame plan of this small shape costs nothing); 4 paths: line kernels below 9 frames, then the pair kernels, then bands."""
+    the band sweeps from 230 frames -- one workgroup per frame where a round of those pays (238..256 frames, 473..512), the
+    chained form (one workgroup per band and frame) between the rounds; 4 paths: line kernels below 9 frames, then the pair kernels, then bands."""
     for paths, B, name in [(8, 3, "packed16/nowrap"), (8, 4, "sweep16par/nowrap"), (8, 17, "sweep16par/nowrap"), (8, 18, "sweep16/nowrap"),
-                           (8, 200, "sweep16/nowrap"), (8, 256, "band16/nowrap"), (8, 300, "sweep16/nowrap"), (8, 512, "band16/nowrap"),
+                           (8, 200, "sweep16/nowrap"), (8, 256, "band16/nowrap"), (8, 300, "band16chain/nowrap"), (8, 512, "band16/nowrap"),
                            (4, 8, "packed16/nowrap"), (4, 9, "pairs16/nowrap"), (4, 512, "band16/nowrap")]:
         with EpiPlan(32, 16, 64, B, paths=paths) as plan:
             plan.set_penalties(6, 64, 0.3)
