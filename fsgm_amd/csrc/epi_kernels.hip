@@ -279,6 +279,62 @@ __global__ __launch_bounds__(256) void box5x5_sliding_kernel(const uint8_t* __re
 }
 
 // =============================================================================================
+// The same sliding window with 16 bytes per lane (D % 16 == 0): one thread = one pixel column x 16 consecutive d, D/16
+// adjacent lanes a pixel -- every access a 16-byte one, a wave's load 64/(D/16) whole pixels (the dword form above moves
+// 4 bytes a lane and reaches 3.5 TB/s; 16-byte accesses are what this chip's memory pipeline is built for).
+// =============================================================================================
+__global__ __launch_bounds__(256) void box5x5_sliding16_kernel(const uint8_t* __restrict__ Craw,
+                                                               uint8_t* __restrict__ C, int W, int H, int D) {
+    const int Dq = D >> 4;                                   // lanes per pixel
+    const int cols = 256 / Dq;                               // pixel columns per block (Dq <= 64 here)
+    const int q = threadIdx.x % Dq, xi = threadIdx.x / Dq;
+    const int x = blockIdx.x * cols + xi;
+    if (xi >= cols || x >= W) return;
+    const int y0 = blockIdx.y * BOX_ROWS, y1 = min(y0 + BOX_ROWS, H);
+    const size_t NP = (size_t)W * H;
+    const uint8_t* raw = Craw + (size_t)blockIdx.z * NP * D + 16 * q;
+    uint8_t* out = C + (size_t)blockIdx.z * NP * D + 16 * q;
+    uint32_t xo[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) xo[k] = (uint32_t)clampi(x + k - 2, 0, W - 1) * (uint32_t)D;
+    struct Sum { uint32_t e[4], o[4]; };                     // even / odd bytes of the 4 dwords in 16-bit fields
+    auto hsum = [&](int y, Sum& h) {                         // horizontal 5-sum of row clamp(y)
+        const uint8_t* r = raw + (size_t)clampi(y, 0, H - 1) * W * D;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { h.e[i] = 0; h.o[i] = 0; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const uint4 v = *(const uint4*)(r + xo[k]);       // neighbouring lanes re-read these lines: through the L1
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) { h.e[i] += w[i] & 0x00FF00FFu; h.o[i] += (w[i] >> 8) & 0x00FF00FFu; }
+        }
+    };
+    Sum ring[5];                                             // rows y-2 .. y+2 around the output row
+#pragma unroll
+    for (int k = 0; k < 4; k++) hsum(y0 - 2 + k, ring[k]);
+    for (int yb = y0; yb < y1; yb += 5) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {                        // static ring slot = (k + 4) % 5
+            const int y = yb + k;
+            if (y < y1) {
+                hsum(y + 2, ring[(k + 4) % 5]);
+                uint32_t o4[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t se = ring[0].e[i] + ring[1].e[i] + ring[2].e[i] + ring[3].e[i] + ring[4].e[i];
+                    const uint32_t so = ring[0].o[i] + ring[1].o[i] + ring[2].o[i] + ring[3].o[i] + ring[4].o[i];
+                    const uint32_t b0 = (2 * (se & 0xFFFF) + 25) / 50, b2 = (2 * (se >> 16) + 25) / 50;
+                    const uint32_t b1 = (2 * (so & 0xFFFF) + 25) / 50, b3 = (2 * (so >> 16) + 25) / 50;
+                    o4[i] = (b0 & 0xFF) | ((b1 & 0xFF) << 8) | ((b2 & 0xFF) << 16) | ((b3 & 0xFF) << 24);
+                }
+                *(uint4*)(out + ((size_t)y * W + x) * D) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // Path aggregation, packed kernel  (calc_cost_sgm.cpp:33-66 sgm_step, :86-257 sgm).
 //
 // One launch covers every path direction of every frame.  A path direction r has lines
@@ -774,7 +830,12 @@ void launch_epi_cost(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frame
         hipLaunchKernelGGL(epi_rawcost_px_kernel, dim3((unsigned)(((long long)a.W * a.H + 255) / 256), frames), dim3(256), 0, st, a);
     } else if ((a.D & 3) == 0) hipLaunchKernelGGL(epi_rawcost_kernel<true>, grid, dim3(256), 0, st, a);
     else                       hipLaunchKernelGGL(epi_rawcost_kernel<false>, grid, dim3(256), 0, st, a);
-    if ((a.D & 3) == 0 && a.D <= 1024) {
+    static const bool box16 = [] { const char* e = getenv("FSGM_BOX16"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (box16 && (a.D & 15) == 0 && a.D <= 1024) {
+        const int cols = 256 / (a.D >> 4);
+        dim3 g2((a.W + cols - 1) / cols, (a.H + BOX_ROWS - 1) / BOX_ROWS, frames);
+        hipLaunchKernelGGL(box5x5_sliding16_kernel, g2, dim3(256), 0, st, (const uint8_t*)a.Craw, C, a.W, a.H, a.D);
+    } else if ((a.D & 3) == 0 && a.D <= 1024) {
         const int cols = 256 / (a.D >> 2);
         dim3 g2((a.W + cols - 1) / cols, (a.H + BOX_ROWS - 1) / BOX_ROWS, frames);
         hipLaunchKernelGGL(box5x5_sliding_kernel, g2, dim3(256), 0, st, (const uint8_t*)a.Craw, C, a.W, a.H, a.D);
