@@ -61,6 +61,9 @@ namespace fsgm {
 #ifndef FSGM_BAND_PFE2
 #define FSGM_BAND_PFE2 2        // the same, second pass (registers)
 #endif
+#ifndef FSGM_BAND_R16
+#define FSGM_BAND_R16 1         // first pass: the from-above-right state as 2 x u16 in LDS (A/B knob)
+#endif
 #ifndef FSGM_BAND_SLACK
 #define FSGM_BAND_SLACK 32      // chained form: columns of lead a band gives the band above before it starts (A/B knob)
 #endif
@@ -99,7 +102,13 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
     constexpr int SKEW = P8 ? 2 : 1;         // u = x + SKEW * (row in band)
     constexpr int NST = P8 ? 3 : 1;          // states that cross rows: 0 from above, 1 from above-left, 2 from above-right
     constexpr int PF = P8 ? (MODE == 2 ? FSGM_BAND_PF2 : FSGM_BAND_PF) : FSGM_BAND_PF4;   // 4 paths: half the registers, twice the bytes per instruction
-    __shared__ uint4 sSt[2][NST][(R + 1) * LPP];              // [step parity][state][row slot (row + 1; slot 0 = the row above the band)][lane of pixel]
+    // first pass, 8 paths: the from-above-right state -- written and read every step, never held -- crosses rows as the registers
+    // hold it (2 x u16 per dword, two planes of 16 bytes per lane): no pack on the way in, no unpack on the way out, for 17 KB
+    // more LDS (67 KB: still two workgroups per CU; the second pass needs that room for its WTA rows)
+    constexpr bool R16 = P8 && MODE == 0 && !CHAIN && FSGM_BAND_R16 != 0;   // (the chained form has no registers to spare for it)
+    constexpr int NSL = R16 ? 2 : NST;                       // states that cross rows as packed bytes
+    __shared__ uint4 sR16[R16 ? 2 : 1][2][R16 ? (R + 1) * LPP : 1];   // [step parity][plane: registers 0-3 / 4-7][row slot][lane of pixel]
+    __shared__ uint4 sSt[2][NSL][(R + 1) * LPP];              // [step parity][state][row slot (row + 1; slot 0 = the row above the band)][lane of pixel]
     __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 4];   // final pass: S of the wave's pixels (u16, two planes: epi_step.h)
     __shared__ uint32_t sTicket;
 
@@ -171,6 +180,17 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
         // CHAIN: a hand-off word is this launch's when every dword carries the launch's tag in its bytes' top bits (states are
         // below 128); the band above may not have got there yet: poll, bounded, and raise a.err instead of hanging
         bool gave_up = false;                                  // (wave 0) a hand-off wait timed out: results are invalid, finish without waiting
+        // wave 0 as "row -1": the band above's three states of one column into row slot 0 of buffer `par`
+        auto put_above = [&](const int par, const uint4 v) {
+            if (R16 && elane / LPP == 2) {
+                uint32_t S[8];
+                unpack_p(v, S);
+                sR16[par][0][elane % LPP] = make_uint4(S[0], S[1], S[2], S[3]);
+                sR16[par][1][elane % LPP] = make_uint4(S[4], S[5], S[6], S[7]);
+            } else {
+                sSt[par][elane / LPP][elane % LPP] = v;
+            }
+        };
         auto fresh = [&](const uint4 v) -> bool { return (((v.x ^ tag) | (v.y ^ tag) | (v.z ^ tag) | (v.w ^ tag)) & 0x80808080u) == 0u; };
         auto eload = [&](const uint8_t* q) -> uint4 { return CHAIN ? edge_load((const uint4*)q) : load_nt(q); };
         auto settle = [&](uint4 v, const uint8_t* q, const bool mine) -> uint4 {       // mine: this lane takes part in the hand-off
@@ -212,7 +232,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
         if (wave == 0 && have_above) {                         // what row 0 reads at step 0
             const uint8_t* q = edge_at(SKEW - 1);
             const uint4 v = settle(loader ? eload(q) : startP, q, loader);
-            if (loader) sSt[1][elane / LPP][elane % LPP] = v;
+            if (loader) put_above(1, v);
         }
         uint4 ringC[PF], ringY[MODE == 2 ? PF : 1];
         // wave 0: the band above's states for the coming steps.  Sequential form: one step ahead (the lines were written a band
@@ -245,7 +265,9 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             const int xc = EDGE ? min(max(x, 0), W - 1) : x;
             // the row above's states of the previous step (pixel x+1 there): the from-above-right predecessor now (4 paths:
             // the from-above one); the other two are for the coming steps and are read further down, when registers are free
-            const uint4 nNow = sSt[par ^ 1][P8 ? 2 : 0][r * LPP + j];
+            uint4 nNow, nLo, nHi;
+            if constexpr (R16) { nLo = sR16[par ^ 1][0][r * LPP + j]; nHi = sR16[par ^ 1][1][r * LPP + j]; }
+            else nNow = sSt[par ^ 1][P8 ? 2 : 0][r * LPP + j];
             uint32_t CP[8], Y[8], YS[8], S[8];
             unpack_cb(cw, CP, Bpk);
             const bool top = EDGE && y == 0;                   // row 0 of the frame: every path from above starts (:152-180)
@@ -303,14 +325,21 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
                 // from above-right (+1,-1): :215-225
                 {
                     const bool st = top || (EDGE && x >= W - 1);
-                    unpack_p(nNow, S);
+                    if (R16) { S[0] = nLo.x; S[1] = nLo.y; S[2] = nLo.z; S[3] = nLo.w; S[4] = nHi.x; S[5] = nHi.y; S[6] = nHi.z; S[7] = nHi.w; }
+                    else unpack_p(nNow, S);
                     if (st) {
 #pragma unroll
                         for (int i = 0; i < 8; i++) S[i] = P2pk;
                     }
                     step_b<LPP, EDGE>(S, CP, Y, P1pk, P2, sel, st ? 0u : 0xFFFFu);
-                    newR = pack_p(S);
-                    sSt[par][2][(r + 1) * LPP + j] = newR;
+                    if constexpr (R16) {
+                        sR16[par][0][(r + 1) * LPP + j] = make_uint4(S[0], S[1], S[2], S[3]);
+                        sR16[par][1][(r + 1) * LPP + j] = make_uint4(S[4], S[5], S[6], S[7]);
+                        if (!last_band && r == R - 1) newR = pack_p(S);      // only the band's last row hands it on as bytes
+                    } else {
+                        newR = pack_p(S);
+                        sSt[par][2][(r + 1) * LPP + j] = newR;
+                    }
 #pragma unroll
                     for (int i = 0; i < 8; i++) YS[i] += Y[i];
                 }
@@ -355,7 +384,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 #pragma unroll
                 for (int i = 0; i + 1 < PFE; i++) ringE[i] = ringE[i + 1];       // (wave 0 only)
                 if (loader) {
-                    sSt[u & 1][elane / LPP][elane % LPP] = v;
+                    put_above(u & 1, v);
                     ringE[PFE - 1] = eload(edge_at(u + PFE + SKEW));
                 }
             }

@@ -227,7 +227,7 @@ __device__ __forceinline__ void wta_row_record_at(const uint32_t (&ST)[8], uint3
         const uint32_t c_1 = best > 0 ? srow[srow_index<NT>(tid, best - 1)] : 0u;
         const uint32_t c1 = best + 1 < (uint32_t)D ? srow[srow_index<NT>(tid, best + 1)] : 0u;   // best == D-1: the finish kernel takes the next pixel's S[0]
         *(uint4*)(recb + pix * 16u) = make_uint4(best, minc, c_1, c1);
-        *(uint16_t*)(s0b + pix * 2u) = (uint16_t)srow[srow_index<NT>(tid, 0)];
+        *(uint16_t*)(s0b + pix * 2u) = (uint16_t)ST[0];        // S[0]: register 0, low half of the pixel's first lane (this one)
     }
 }
 
