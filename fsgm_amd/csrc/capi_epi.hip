@@ -55,13 +55,6 @@ struct fsgm_epi_plan {
     uint8_t* dRgb = nullptr;
     uint4* dRec = nullptr;
     uint16_t* dS0 = nullptr;
-    // strip sweeps (epi_sweep.hip, strip_kernel): hand-off buffer between neighbouring strips, one work counter per
-    // frame lane and the value it holds (each launch takes exactly strips x frames tickets), launch sequence numbers
-    // for the hand-off tags, the give-up flag of the bounded waits
-    uint4* dEdge = nullptr;
-    uint32_t *dTicket = nullptr, *dErr = nullptr;
-    uint32_t salt[3] = {0, 0, 0};
-    bool strips = false;                 // FSGM_EPI_STRIPS=1: the strip sweeps (one launch per sweep, no halo) instead of the block sweeps
     size_t state_stride = 0;
     hipStream_t stream_h = nullptr, stream_b = nullptr, stream_c = nullptr;
     hipEvent_t ev_fork = nullptr, ev_h = nullptr, ev_b = nullptr, ev_c = nullptr;
@@ -223,7 +216,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dXupAll, p->dStateUp, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dEdge, p->dTicket, p->dErr, p->dBits, p->dBandEdge, p->dBandTicket, p->dBandErr};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dXupAll, p->dStateUp, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dBits, p->dBandEdge, p->dBandTicket, p->dBandErr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -427,19 +420,22 @@ static int par_tall(const fsgm_epi_plan* p) {
     return p->batch <= 10 ? 1 : 0;
 }
 
+// (the pipelines share some buffers -- records, S[0] words, Y volumes, the pair's stream -- and a plan may be switched from
+// one to another: each set creates only what is still missing)
 static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
-    if (p->dCkptV) return FSGM_OK;
+    if (p->dCkptV && p->dLh && p->dCkpt && p->dRec && p->dS0 && p->stream_h) return FSGM_OK;
     const size_t B = p->batch;
     LazySet ls;
-    uint8_t *lh, *ck, *ckv; uint4* rec; uint16_t* s0; hipStream_t sh; hipEvent_t ef, eh;
-    ls.alloc(&lh, B * p->N);
-    ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
-    ls.alloc(&ckv, B * pair_ckpt_bytes(p->W, p->H, p->D, 1));
-    ls.alloc(&rec, B * p->NP * sizeof(uint4));
-    ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
-    ls.stream(&sh);
-    ls.event(&ef);
-    ls.event(&eh);
+    uint8_t *lh = p->dLh, *ck = p->dCkpt, *ckv = p->dCkptV; uint4* rec = p->dRec; uint16_t* s0 = p->dS0;
+    hipStream_t sh = p->stream_h; hipEvent_t ef = p->ev_fork, eh = p->ev_h;
+    if (!lh) ls.alloc(&lh, B * p->N);
+    if (!ck) ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
+    if (!ckv) ls.alloc(&ckv, B * pair_ckpt_bytes(p->W, p->H, p->D, 1));
+    if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint4));
+    if (!s0) ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
+    if (!sh) ls.stream(&sh);
+    if (!ef) ls.event(&ef);
+    if (!eh) ls.event(&eh);
     if (ls.err != hipSuccess) return lazy_fail(ls, "pair pipeline buffers");
     p->dLh = lh; p->dCkpt = ck; p->dCkptV = ckv; p->dRec = rec; p->dS0 = s0;
     p->stream_h = sh; p->ev_fork = ef; p->ev_h = eh;
@@ -447,40 +443,28 @@ static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
 }
 
 static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
-    if (p->dX) return FSGM_OK;
+    if (p->dState) return FSGM_OK;                               // the set's own marker: created last
     const size_t B = p->batch;
     const size_t state_stride = sweep_state_bytes(p->W, p->D);
     LazySet ls;
-    uint8_t *lh, *ck = nullptr, *state, *x; uint4 *rec, *edge = nullptr; uint16_t* s0; uint32_t *ticket = nullptr, *err = nullptr;
-    hipStream_t sh, sb, sc; hipEvent_t ef, eh, eb, ec, ehl[3];
-    // Block sweeps by default: the strip sweeps execute 19 % fewer instructions and need no state buffers, but measured
-    // 5-10 % slower at 32 frames; FSGM_EPI_STRIPS=1 selects them -- only then do their hand-off buffer
-    // (7.3 MB per 1242x375x128 frame), work counters and give-up flag exist.
-    bool strips = false;
-    { const char* e = getenv("FSGM_EPI_STRIPS"); strips = e && *e && atoi(e) != 0; }
-    const size_t edge_bytes = B * strip_edge_uint4s(p->W, p->H, p->D) * sizeof(uint4);
-    ls.alloc(&lh, B * p->N);
-    ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
+    uint8_t *lh = p->dLh, *ck = p->dCkpt, *state = nullptr, *x = p->dX; uint4* rec = p->dRec; uint16_t* s0 = p->dS0;
+    hipStream_t sh = p->stream_h, sb = p->stream_b, sc = p->stream_c;
+    hipEvent_t ef = p->ev_fork, eh = p->ev_h, eb = p->ev_b, ec = p->ev_c, ehl[3] = {p->ev_hl[0], p->ev_hl[1], p->ev_hl[2]};
+    if (!lh) ls.alloc(&lh, B * p->N);
+    if (!ck) ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
+    if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint4));
+    if (!s0) ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
+    if (!x) ls.alloc(&x, B * p->N);
+    if (!sh) ls.stream(&sh);
+    if (!sb) ls.stream(&sb);
+    if (!sc) ls.stream(&sc);
+    if (!ef) ls.event(&ef);
+    if (!eh) ls.event(&eh);
+    if (!eb) ls.event(&eb);
+    if (!ec) ls.event(&ec);
+    for (int l = 0; l < 3; l++) if (!ehl[l]) ls.event(&ehl[l]);
     ls.alloc(&state, 2 * B * state_stride);
-    ls.alloc(&rec, B * p->NP * sizeof(uint4));
-    ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
-    ls.alloc(&x, B * p->N);
-    if (strips) {
-        ls.alloc(&edge, edge_bytes);
-        ls.alloc(&ticket, 4 * sizeof(uint32_t));
-        ls.alloc(&err, sizeof(uint32_t));
-    }
-    ls.stream(&sh); ls.stream(&sb); ls.stream(&sc);
-    ls.event(&ef); ls.event(&eh); ls.event(&eb); ls.event(&ec);
-    for (int l = 0; l < 3; l++) ls.event(&ehl[l]);
-    // hand-off dwords carry a launch tag in their bytes' top bits: all ones = "older than any launch"
-    if (strips && ls.err == hipSuccess) ls.err = hipMemsetAsync(edge, 0xFF, edge_bytes, p->stream);
-    if (strips && ls.err == hipSuccess) ls.err = hipMemsetAsync(ticket, 0, 4 * sizeof(uint32_t), p->stream);
-    if (strips && ls.err == hipSuccess) ls.err = hipMemsetAsync(err, 0, sizeof(uint32_t), p->stream);
     if (ls.err != hipSuccess) return lazy_fail(ls, "sweep pipeline buffers");
-    p->dEdge = edge; p->dTicket = ticket; p->dErr = err;
-    for (int l = 0; l < 3; l++) p->salt[l] = 0;
-    p->strips = strips;
     p->state_stride = state_stride;
     p->dLh = lh; p->dCkpt = ck; p->dState = state; p->dRec = rec; p->dS0 = s0; p->dX = x;
     p->stream_h = sh; p->stream_b = sb; p->stream_c = sc;
@@ -632,34 +616,9 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
             w.state_in = w.state_out = p->dState + (size_t)2 * f0 * p->state_stride;
             w.state_frame_stride = p->state_stride;
             w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
-            if (p->strips) {                                         // one launch per sweep, strips handing over while they run
-                StripArgs sa;
-                sa.C = w.C; sa.c_frame_stride = w.c_frame_stride; sa.X = w.X; sa.x_frame_stride = w.x_frame_stride;
-                sa.Lh = w.Lh; sa.lh_frame_stride = w.lh_frame_stride; sa.rec = w.rec; sa.s0 = w.s0;
-                sa.NS = strip_count(p->W, p->H, p->D);
-                sa.edge = p->dEdge + (size_t)f0 * strip_edge_uint4s(p->W, p->H, p->D);
-                sa.ticket = p->dTicket + lane; sa.err = p->dErr;
-                sa.W = p->W; sa.H = p->H; sa.D = p->D; sa.P1 = p->P1; sa.P2 = p->P2; sa.frames = nf;
-                // the work counter restarts at 0 on the lane's own stream ahead of every launch (no host mirror that a
-                // failed launch could leave out of step with the device); the hand-off tag only has to differ from the
-                // previous launches' of this lane
-                sa.ticket_base = 0;
-                auto next_tag = [&]() {
-                    const uint32_t t = p->salt[lane]++ & 15u;
-                    sa.tag = ((t & 1u) << 7) | ((t & 2u) << 14) | ((t & 4u) << 21) | ((t & 8u) << 28);
-                };
-                next_tag();
-                FSGM_HIP(hipMemsetAsync(sa.ticket, 0, sizeof(uint32_t), st));
-                launch_strips(st, sa, 0);                            // pass-0 paths from above -> Y_dn
-                FSGM_HIP(hipStreamWaitEvent(st, p->ev_hl[lane], 0));
-                next_tag();
-                FSGM_HIP(hipMemsetAsync(sa.ticket, 0, sizeof(uint32_t), st));
-                launch_strips(st, sa, 2);                            // pass-1 paths + everything else + WTA
-            } else {
-                launch_sweep(st, w, nf, 0);                          // pass-0 paths from above -> Y_dn
-                FSGM_HIP(hipStreamWaitEvent(st, p->ev_hl[lane], 0));
-                launch_sweep(st, w, nf, 2);                          // pass-1 paths + everything else + WTA
-            }
+            launch_sweep(st, w, nf, 0);                              // pass-0 paths from above -> Y_dn
+            FSGM_HIP(hipStreamWaitEvent(st, p->ev_hl[lane], 0));
+            launch_sweep(st, w, nf, 2);                              // pass-1 paths + everything else + WTA
             if (lane) {
                 FSGM_HIP(hipEventRecord(lane_done[lane], st));
                 FSGM_HIP(hipStreamWaitEvent(p->stream, lane_done[lane], 0));
@@ -772,8 +731,7 @@ static int env_graph() {
 static fsgm_status run_stages(fsgm_epi_plan* p, int stages) {
     fsgm_status st = prepare(p, stages);                         // kernel selection and allocations: before the graph decision, outside any capture
     if (st != FSGM_OK) return st;
-    const bool graphable = p->kernel_kind == AGG_SWEEP && !(stages & FSGM_STAGE_COST) && !p->prm.fb_check && env_graph() != 0 &&
-                           !p->strips;      // a strip launch's ticket base and hand-off tag change from launch to launch: not replayable
+    const bool graphable = p->kernel_kind == AGG_SWEEP && !(stages & FSGM_STAGE_COST) && !p->prm.fb_check && env_graph() != 0;
     if (!graphable) return enqueue(p, stages);
     fsgm_epi_plan::GraphSlot& g = p->graphs[stages & 7];
     if (!g.exec || g.epoch != p->epoch) {
@@ -808,7 +766,7 @@ fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* p, int32_t mode) {
     return FSGM_OK;
 }
 
-// the strip sweeps' bounded hand-off waits raise a device flag instead of hanging: surface it after a sync
+// the chained band sweeps' bounded hand-off waits raise a device flag instead of hanging: surface it after a sync
 static fsgm_status check_handoff(fsgm_epi_plan* p) {
     if (p->band_chain && p->dBandErr) {                          // chained band sweeps: bounded waits between the bands of a frame
         uint32_t e = 0;
@@ -818,12 +776,7 @@ static fsgm_status check_handoff(fsgm_epi_plan* p) {
             return fail(FSGM_ERR_HIP, "band sweep: a hand-off between the bands of a frame timed out (results of this run are invalid)");
         }
     }
-    if (!p->strips || !p->dErr) return FSGM_OK;                  // only the strip sweeps wait inside a kernel
-    uint32_t e = 0;
-    FSGM_HIP(hipMemcpy(&e, p->dErr, sizeof(e), hipMemcpyDeviceToHost));
-    if (e == 0) return FSGM_OK;
-    (void)hipMemset(p->dErr, 0, sizeof(e));
-    return fail(FSGM_ERR_HIP, "strip sweep: a hand-off between neighbouring strips timed out (results of this run are invalid)");
+    return FSGM_OK;
 }
 
 fsgm_status fsgm_epi_plan_sync(fsgm_epi_plan* p) {
@@ -916,9 +869,9 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         fsgm_status es = ensure_pairs_buffers(p);
         if (es != FSGM_OK) return es;
         if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
-        if (!p->dX) FSGM_HIP(hipMalloc((void**)&p->dX, p->N));
+        if (!p->dXup) FSGM_HIP(hipMalloc((void**)&p->dXup, p->N));          // one frame of scratch (dX is a whole-batch buffer of other pipelines)
         PairArgs v{};
-        v.C = p->dC + (size_t)f * p->N; v.c_frame_stride = p->N; v.X = p->dX; v.x_frame_stride = p->N;
+        v.C = p->dC + (size_t)f * p->N; v.c_frame_stride = p->N; v.X = p->dXup; v.x_frame_stride = p->N;
         v.ckpt = p->dCkptV; v.ckpt_frame_stride = pair_ckpt_bytes(p->W, p->H, p->D, 1);
         v.W = p->W; v.H = p->H; v.D = p->D; v.P1 = p->P1; v.P2 = p->P2;
         launch_pair(p->stream, v, 1, 1, false);
@@ -928,7 +881,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         a.W = p->W; a.H = p->H; a.D = p->D; a.ndirs = p->prm.paths;
         a.subpixel = p->prm.subpixel; a.vz_to_disp = p->prm.vz_to_disp;
         SweepSumArgs q;
-        q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX; q.Xup = nullptr; q.v_frame_stride = p->N;
+        q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dXup; q.Xup = nullptr; q.v_frame_stride = p->N;
         q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_natural = pairs_x_fine(p);
         q.nC = 4; q.P2 = p->P2; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);

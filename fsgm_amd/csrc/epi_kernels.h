@@ -63,26 +63,6 @@ struct SweepArgs {
     int y0, rows;             // rows [y0, y0+rows) of the sweep frame
 };
 
-// a whole sweep in one launch, strips of skewed columns handing their edge states over while they run (epi_sweep.hip)
-struct StripArgs {
-    const uint8_t* C;         // [frames] cost volumes
-    size_t c_frame_stride;
-    uint8_t* X;               // [frames] Y of this sweep: written by modes 0/1; mode 2 reads the down sweep's
-    size_t x_frame_stride;
-    const uint8_t* Lh;        // mode 2: [frames] Y_h
-    size_t lh_frame_stride;
-    uint4* rec;               // mode 2: [frames][NP] records
-    uint16_t* s0;             // mode 2: [frames][NP]
-    uint4* edge;              // [frames][NS][H][3][LPP] hand-off of path states between neighbouring strips
-    uint32_t* ticket;         // work counter of this stream of launches (never reset: ticket_base = its value at launch)
-    uint32_t ticket_base;
-    uint32_t tag;             // 4-bit launch sequence number spread over the top bits of a dword's bytes
-    uint32_t* err;            // set to non-zero when a hand-off wait gave up
-    int W, H, D;
-    int P1, P2;
-    int frames, NS;
-};
-
 // band sweeps: all four paths of a raster pass in one sweep, one workgroup per frame (epi_band.hip)
 struct BandArgs {
     const uint8_t* C;         // [frames] cost volumes
@@ -159,9 +139,6 @@ void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
 int    sweep_rows_per_launch(int D);
 size_t sweep_state_bytes(int W, int D);   // one state buffer of one frame
 void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode, int tall = 0);   // 0 down, 1 up, 2 up + fused WTA; tall: 8-wave workgroups (modes 0, 1)
-int    strip_count(int W, int H, int D);                    // strips of skewed columns per frame
-size_t strip_edge_uint4s(int W, int H, int D);              // hand-off buffer per frame, in uint4
-void launch_strips(hipStream_t st, const StripArgs& a, int mode);               // same modes, one launch per sweep
 size_t pair_ckpt_bytes(int W, int H, int D, int axis);      // per frame; axis 0 horizontal, 1 vertical
 void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase = 0);
 bool pair_x_fine_ok(int D);                                                        // the along-x pair with 8 costs a lane exists for this D

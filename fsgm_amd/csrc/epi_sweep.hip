@@ -346,207 +346,6 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
 }
 
 // =============================================================================================
-// strip kernel: a whole sweep (all rows) in ONE launch, without the halo.
-//
-// In the skewed column u = x + y all three paths of a sweep take their predecessor from the left or from the same
-// column: from above (x, y-1) is column u-1, from above-left (x-1, y-1) is u-2, from above-right (x+1, y-1) is u itself.
-// A workgroup owns a strip of 4*PXG skewed columns (a parallelogram that moves one image column to the left per row)
-// and walks down all the rows it crosses: the from-above-right states never leave their registers, the other two shift
-// through LDS (one barrier per row, as in the block sweeps), and the only thing a strip needs from outside is, per
-// row, three states of its LEFT neighbour's last two columns.  The left neighbour hands them over through global
-// memory while both run: 3 x 16*LPP bytes per row, written once (write-through) and read once.  The hand-off needs no
-// flag, fence or ordering: path states are <= P2 <= 127, so the top bit of every byte is free, and the four top bits
-// of each dword carry a tag that changes from launch to launch -- every dword says by itself whether it is this
-// launch's; the reader polls (agent-scope loads) until all of its dwords do.
-// Progress: a workgroup takes its (strip, frame) from a ticket counter, strips in ascending order, so the strip it
-// waits for always holds an earlier ticket -- it is running or done, whatever the dispatch order or placement; every
-// wait is bounded and raises a.err instead of hanging.
-// Columns outside the image hold the path-start state (s = P2), so a diagonal that enters the image starts as the
-// reference's does (:156-180); waves whose columns are all at least 3 columns outside do nothing.
-// =============================================================================================
-template <int LPP, int MODE>
-__global__ __launch_bounds__(256) void strip_kernel(StripArgs a) {
-    constexpr bool UP = MODE != 0;
-    constexpr int PXG = 64 / LPP;            // columns per wave
-    constexpr int D = LPP * 16;
-    constexpr int STRIP = 4 * PXG;           // skewed columns per workgroup
-    constexpr int NSLOT = STRIP + 2;         // LDS slots: local skewed column lu <-> slot lu + 2 (slots 0, 1: the left neighbour's last two)
-    constexpr int PF = MODE == 2 ? 2 : 3;    // rows of C in flight per lane
-    constexpr int MARGIN = 2;                // columns outside the image that still run (to settle on the start state)
-    __shared__ uint4 sD[2][2][NSLOT * LPP];  // [row parity][0: from-above states, 1: from-above-left states][slot][lane-of-pixel]
-    __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? 4 * 64 * 8 : 4];
-    __shared__ uint32_t sTicket;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane / LPP, j = lane % LPP;
-    const int W = a.W, H = a.H, NP = W * H;
-    if (tid == 0) sTicket = atomicAdd(a.ticket, 1u) - a.ticket_base;
-    __syncthreads();
-    const uint32_t ticket = __builtin_amdgcn_readfirstlane(sTicket);
-    const int k = (int)(ticket / (uint32_t)a.frames);           // strips in ascending order: the left neighbour (k-1, f) holds an earlier ticket
-    const size_t f = ticket % (uint32_t)a.frames;
-    if (k >= a.NS) return;
-    const int u0 = k * STRIP;
-    // rows in which the strip has a column within MARGIN of the image: x = u - y, u in [u0, u0 + STRIP)
-    const int y_lo = max(0, u0 - (W - 1 + MARGIN)), y_hi = min(H - 1, u0 + STRIP - 1 + MARGIN);
-    if (y_lo > y_hi) return;
-    const int p_lo = max(0, u0 - STRIP - (W - 1 + MARGIN)), p_hi = min(H - 1, u0 - 1 + MARGIN);   // the same for strip k-1
-
-    const uint8_t* __restrict__ Cf = a.C + f * a.c_frame_stride;
-    uint8_t* __restrict__ Xf = a.X + f * a.x_frame_stride;
-    const uint8_t* __restrict__ Lhf = MODE == 2 ? a.Lh + f * a.lh_frame_stride : nullptr;
-    uint4* __restrict__ edgeOut = a.edge + (f * a.NS + k) * (size_t)H * (3 * LPP);
-    const uint4* __restrict__ edgeIn = a.edge + (f * a.NS + (k > 0 ? k - 1 : 0)) * (size_t)H * (3 * LPP);
-    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
-    const uint4 startP = make_uint4(P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u, P2 * 0x01010101u);   // s = P2 everywhere: a path start
-    const uint32_t tag = a.tag;
-    const LaneSel sel = lane_sel<LPP>(j);
-    const int lu = wave * PXG + g;                               // local skewed column
-    const int ul = u0 + lu;
-
-    auto pix_of = [&](int x, int y) -> int { const int p = y * W + x; return UP ? NP - 1 - p : p; };
-    auto vox_off = [&](int x, int y) -> uint32_t { return (uint32_t)pix_of(x, y) * D + (uint32_t)j * 16; };
-    auto c_addr = [&](int y) -> const uint4* {                   // this lane's costs in row y (clamped into the image)
-        const int yc = min(y, H - 1);
-        return (const uint4*)(Cf + vox_off(min(max(ul - yc, 0), W - 1), yc));
-    };
-
-    // ---- prologue: every state is the start state ----
-    uint32_t VR[8];                                               // from-above-right path: stays in these lanes
-#pragma unroll
-    for (int i = 0; i < 8; i++) VR[i] = P2pk;
-    for (int i = tid; i < 2 * 2 * NSLOT * LPP; i += 256) (&sD[0][0][0])[i] = startP;
-    uint4 pubV = startP, pubD = startP;                           // wave 3: what the right neighbour reads (from-above / from-above-left of the last row done)
-    auto x_off = [&](int y) -> uint32_t { const int yc = min(y, H - 1); return vox_off(min(max(ul - yc, 0), W - 1), yc); };
-    uint4 ring[PF], ringX[MODE == 2 ? PF : 1], ringH[MODE == 2 ? PF : 1];    // C (and, MODE 2, Y_dn and Y_h) of the coming rows
-#pragma unroll
-    for (int i = 0; i < PF; i++) {
-        ring[i] = *c_addr(y_lo + i);
-        if (MODE == 2) { ringX[i] = *(const uint4*)(Xf + x_off(y_lo + i)); ringH[i] = *(const uint4*)(Lhf + x_off(y_lo + i)); }
-    }
-    // wave 0, lanes 0 .. 3*LPP-1: the left neighbour's hand-off for the coming row, requested one row ahead
-    const bool edge_lane = wave == 0 && lane < 3 * LPP;
-    auto edge_wanted = [&](int yprev) -> bool { return k > 0 && yprev >= p_lo && yprev <= p_hi; };
-    uint4 nextB = startP;
-    if (edge_lane && edge_wanted(y_lo - 1)) nextB = edge_load(edgeIn + (size_t)(y_lo - 1) * (3 * LPP) + lane);
-    __syncthreads();
-
-    auto fresh = [&](const uint4 v) -> bool { return (((v.x ^ tag) | (v.y ^ tag) | (v.z ^ tag) | (v.w ^ tag)) & 0x80808080u) == 0u; };
-
-    // one row of this wave's PXG columns; EDGE: row 0 or a column at / outside an image border (selects allowed, rare)
-    auto do_row = [&](const int y, const int par, const uint4 cw, const uint4 curX, const uint4 curH, auto edge_tag) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
-        const int x = ul - y;
-        const bool inside = !EDGE || (x >= 0 && x < W);
-        const int xc = EDGE ? min(max(x, 0), W - 1) : x;
-        uint32_t CP[8], Y[8], YS[8], S[8];
-        unpack_c(cw, CP, P2pk);
-        const uint32_t top = EDGE && y == 0 ? 0u : 0xFFFFu;      // row 0: every path starts (:152-180)
-        // from above-right (-1,+1): predecessor (x+1, y-1) = this column one row earlier                 :215-225
-        step_s<LPP>(VR, CP, YS, P1pk, P2, sel, EDGE && x == W - 1 ? 0u : top);
-        // from above (0,+1): predecessor skewed column u-1                                               :193-202
-        unpack_p(sD[par][0][(lu + 1) * LPP + j], S);
-        step_s<LPP>(S, CP, Y, P1pk, P2, sel, top);
-        if (EDGE && !inside) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) { S[i] = P2pk; VR[i] = P2pk; }
-        }
-        const uint4 sv = pack_p(S);
-        sD[par ^ 1][0][(lu + 2) * LPP + j] = sv;
-#pragma unroll
-        for (int i = 0; i < 8; i++) YS[i] += Y[i];
-        // from above-left (+1,+1): predecessor skewed column u-2                                         :205-213
-        unpack_p(sD[par][1][lu * LPP + j], S);
-        step_s<LPP>(S, CP, Y, P1pk, P2, sel, EDGE && x == 0 ? 0u : top);
-        if (EDGE && !inside) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) S[i] = P2pk;
-        }
-        const uint4 sd = pack_p(S);
-        sD[par ^ 1][1][(lu + 2) * LPP + j] = sd;
-#pragma unroll
-        for (int i = 0; i < 8; i++) YS[i] += Y[i];
-        pubV = sv; pubD = sd;
-        if (MODE != 2) {
-            if (inside) *(uint4*)(Xf + vox_off(xc, y)) = pack_p(YS);                                     // :227-232
-        } else {
-            uint32_t E2[8], ST[8];
-            unpack_p(curX, E2);
-#pragma unroll
-            for (int i = 0; i < 8; i++) YS[i] += E2[i];
-            unpack_p(curH, E2);
-#pragma unroll
-            for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], 0x00080008u, 0u), pk_add(YS[i], E2[i]));
-            wta_row_record<LPP, 256>(ST, sRow, tid, j, inside, a.rec, a.s0, f * (size_t)NP + pix_of(xc, y));
-        }
-    };
-
-    // one row of the workgroup: hand-off in (wave 0), the wave's columns, hand-off out (wave 3), barrier
-    // one row of the workgroup: hand-off in (wave 0), requests for the rows to come, the wave's columns, hand-off out
-    // (wave 3), barrier.  Order matters for the wait counters (vmcnt retires in order): the hand-off words requested a
-    // row ago are waited for BEFORE this row's ring requests are issued, so that wait never drains the ring.
-    auto poll = [&](const int yprev) -> uint4 {                   // slow path: the neighbour has not got there yet
-        uint4 b;
-        for (uint32_t spins = 0;; spins++) {
-            __builtin_amdgcn_s_sleep(1);
-            b = edge_load(edgeIn + (size_t)yprev * (3 * LPP) + lane);
-            if (__all(fresh(b))) break;                           // over the lanes that take part in the hand-off
-            if (spins > (1u << 20)) { if (lane == 0) atomicOr(a.err, 1u); break; }
-        }
-        // the words have arrived (the test above read them): say so to the compiler, or it drains every request in
-        // flight -- the ring included -- where this path joins the fast one
-        asm volatile("" : "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
-        return b;
-    };
-    auto row = [&](const int y, uint4& rC, uint4& rX, uint4& rH) {
-        const int par = (y - y_lo) & 1;
-        // ---- wave 0: the left neighbour's states of row y-1 into slots 0 and 1 ----
-        if (edge_lane) {
-            uint4 b = startP;
-            if (edge_wanted(y - 1)) {
-                b = nextB;
-                if (!__all(fresh(b))) b = poll(y - 1);
-                b.x &= 0x7F7F7F7Fu; b.y &= 0x7F7F7F7Fu; b.z &= 0x7F7F7F7Fu; b.w &= 0x7F7F7F7Fu;
-            }
-            // lane = s * LPP + jj: s = 0 from-above of the neighbour's last column, 1 / 2 from-above-left of its last but one / last
-            const int s_ = lane / LPP, jj = lane - s_ * LPP;
-            sD[par][s_ == 0 ? 0 : 1][(s_ == 1 ? 0 : 1) * LPP + jj] = b;
-            if (edge_wanted(y)) nextB = edge_load(edgeIn + (size_t)y * (3 * LPP) + lane);     // for the next row, in flight during this one
-        }
-        // ---- this row's operands (requested PF rows ago) out of the ring, the row PF ahead into it ----
-        const uint4 cw = rC, cX = rX, cH = rH;
-        rC = *c_addr(y + PF);
-        if (MODE == 2) { rX = *(const uint4*)(Xf + x_off(y + PF)); rH = *(const uint4*)(Lhf + x_off(y + PF)); }
-        const int xlo = u0 + wave * PXG - y, xhi = xlo + PXG - 1;   // this wave's image columns in row y
-        if (xhi >= -MARGIN && xlo <= W - 1 + MARGIN) {              // wave-uniform
-            if (y > 0 && xlo >= 1 && xhi <= W - 2) do_row(y, par, cw, cX, cH, std::false_type{});
-            else do_row(y, par, cw, cX, cH, std::true_type{});
-        }
-        // ---- wave 3: hand the last two columns' states of row y to the right neighbour ----
-        if (wave == 3 && g >= PXG - 2 && k + 1 < a.NS) {
-            uint4* o = edgeOut + (size_t)y * (3 * LPP);
-            if (g == PXG - 1) {
-                edge_store(o + 0 * LPP + j, make_uint4(pubV.x | tag, pubV.y | tag, pubV.z | tag, pubV.w | tag));
-                edge_store(o + 2 * LPP + j, make_uint4(pubD.x | tag, pubD.y | tag, pubD.z | tag, pubD.w | tag));
-            } else {
-                edge_store(o + 1 * LPP + j, make_uint4(pubD.x | tag, pubD.y | tag, pubD.z | tag, pubD.w | tag));
-            }
-        }
-        __syncthreads();                                            // states of row y visible to row y+1
-    };
-    // steady state: PF rows per trip with the ring slots named statically (no register shuffling, so no wait for the
-    // requests just issued); then the tail
-    int y = y_lo;
-    for (; y + PF - 1 <= y_hi; y += PF) {
-#pragma unroll
-        for (int i = 0; i < PF; i++) row(y + i, ring[i], ringX[MODE == 2 ? i : 0], ringH[MODE == 2 ? i : 0]);
-    }
-#pragma unroll
-    for (int i = 0; i < PF - 1; i++)
-        if (y + i <= y_hi) row(y + i, ring[i], ringX[MODE == 2 ? i : 0], ringH[MODE == 2 ? i : 0]);   // workgroup-uniform
-}
-
-// =============================================================================================
 // finish kernel for MODE 2: parabola + vz->disparity from the per-pixel records
 // (calc_cost_sgm.cpp:278-308, :414-426).  best == D-1 reads the next pixel's S[0] (:296).
 // =============================================================================================
@@ -1118,29 +917,6 @@ void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode, int 
         case 4: launch_sweep_t<4>(st, a, frames, mode, tall); break;
         case 8: launch_sweep_t<8>(st, a, frames, mode, tall); break;
         case 16: launch_sweep_t<16>(st, a, frames, mode, tall); break;
-        default: break;
-    }
-}
-
-// One whole sweep of `frames` frames as one strip_kernel launch (mode 0 down, 1 up, 2 up + WTA).
-int strip_count(int W, int H, int D) { const int lpp = agg_packed_lpp(D); return lpp ? (W + H - 1 + 4 * (64 / lpp) - 1) / (4 * (64 / lpp)) : 0; }
-size_t strip_edge_uint4s(int W, int H, int D) { return (size_t)strip_count(W, H, D) * H * 3 * agg_packed_lpp(D); }   // per frame
-
-template <int LPP>
-static void launch_strips_t(hipStream_t st, const StripArgs& a, int mode) {
-    dim3 grid((unsigned)(a.NS * a.frames));
-    if (mode == 0)      hipLaunchKernelGGL((strip_kernel<LPP, 0>), grid, dim3(256), 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((strip_kernel<LPP, 1>), grid, dim3(256), 0, st, a);
-    else                hipLaunchKernelGGL((strip_kernel<LPP, 2>), grid, dim3(256), 0, st, a);
-}
-
-void launch_strips(hipStream_t st, const StripArgs& a, int mode) {
-    switch (agg_packed_lpp(a.D)) {
-        case 1: launch_strips_t<1>(st, a, mode); break;
-        case 2: launch_strips_t<2>(st, a, mode); break;
-        case 4: launch_strips_t<4>(st, a, mode); break;
-        case 8: launch_strips_t<8>(st, a, mode); break;
-        case 16: launch_strips_t<16>(st, a, mode); break;
         default: break;
     }
 }

@@ -135,8 +135,8 @@ def test_pairs_pipeline_4_paths(gpu_lib, oracle, W, H, D, B):
                                    (320, 240, 64), (40, 300, 16), (60, 150, 32), (23, 40, 256),
                                    # widths around the horizontal pair's 8-column tiles (no / one / partial checkpoint)
                                    (1, 9, 64), (5, 20, 128), (8, 33, 128), (9, 20, 32), (16, 20, 128), (17, 40, 64), (1242, 17, 128)])
-def test_sweep_blocks_and_strips(gpu_lib, oracle, W, H, D):
-    """Fused sweeps across several row blocks and column strips (block / halo / state hand-over paths)."""
+def test_sweep_blocks_and_columns(gpu_lib, oracle, W, H, D):
+    """Fused sweeps across several row blocks and column strips of workgroups (block / halo / state hand-over paths)."""
     Cv = synth.cost_volume(W, H, D, seed=W + H, cmax=24)
     Cv[:, ::7, :] = 0                                        # strong structure so diagonals carry information far
     want = oracle.epi_aggregate(Cv, 6, 64, 8)[:-1].reshape(H, W, D)
@@ -385,34 +385,31 @@ def test_sweep_pipeline_is_deterministic_under_back_to_back_runs(gpu_lib, oracle
                 np.testing.assert_array_equal(gbd, want[f][0], err_msg=f"rep {rep} frame {f}")
 
 
-@pytest.mark.parametrize("W,H,D,B", [(150, 70, 128, 3), (97, 200, 64, 2), (1242, 40, 128, 1), (33, 375, 128, 2), (20, 9, 16, 1), (260, 31, 32, 2), (70, 50, 256, 1)])
-def test_strip_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, monkeypatch):
-    """The strip form of the sweeps (FSGM_EPI_STRIPS=1: one launch per sweep, skewed strips handing their edge states to the
-    right neighbour while both run, no halo) against the oracle: S through the debug tap's up sweep is the block form's,
-    so bestD / minC of the records are what is compared, over several back-to-back runs (the hand-off tags change per
-    launch)."""
-    monkeypatch.setenv("FSGM_EPI_STRIPS", "1")
-    vols = [synth.cost_volume(W, H, D, seed=W + H + f, cmax=24) for f in range(B)]
+def test_one_plan_through_every_pipeline(gpu_lib, oracle):
+    """The pipelines share buffers (records, Y volumes, the pair's stream) that are created on first use: one plan switched
+    through every aggregation mode in both orders must give the oracle's result each time (8 and 4 paths)."""
+    W, H, D, B = 96, 70, 128, 3
+    vols = [synth.cost_volume(W, H, D, seed=31 + f, cmax=24) for f in range(B)]
     _, _, off = synth.epi_maps(W, H, "general", seed=3)
-    want = []
-    for v in vols:
-        S = oracle.epi_aggregate(v, 6, 64, 8)
-        bd, mc = oracle.epi_wta(S, W, H, D, 1)
-        want.append((oracle.epi_vz_to_disp(bd, off, 0.3, D + 1), mc))
-    with EpiPlan(W, H, D, B, paths=8) as plan:
-        plan.set_penalties(6, 64, 0.3)
-        plan.set_agg_mode(2)
-        assert plan.kernel_name == "sweep16/nowrap"
-        for f in range(B):
-            plan.upload_cost(f, vols[f])
-            plan.upload_offset(f, off)
-        for rep in range(3):
-            for _ in range(1 + 8 * rep):                        # 1, 9, 17 launches: the 4-bit tags wrap
-                plan.run(STAGE_AGGREGATE | STAGE_WTA)
+    for paths, modes in ((8, (4, 2, 3, 5, 1, 5, 3, 2, 4)), (4, (4, 2, 5, 1, 2, 4))):
+        want = []
+        for v in vols:
+            S = oracle.epi_aggregate(v, 6, 64, paths)
+            bd, mc = oracle.epi_wta(S, W, H, D, 1)
+            want.append((oracle.epi_vz_to_disp(bd, off, 0.3, D + 1), mc, S[:-1].reshape(H, W, D)))
+        with EpiPlan(W, H, D, B, paths=paths) as plan:
+            plan.set_penalties(6, 64, 0.3)
             for f in range(B):
-                gbd, gmc = plan.download(f)
-                np.testing.assert_array_equal(gmc, want[f][1], err_msg=f"rep {rep} frame {f}")
-                np.testing.assert_array_equal(gbd, want[f][0], err_msg=f"rep {rep} frame {f}")
+                plan.upload_cost(f, vols[f])
+                plan.upload_offset(f, off)
+            for mode in modes:
+                plan.set_agg_mode(mode)
+                plan.run(STAGE_AGGREGATE | STAGE_WTA)
+                for f in range(B):
+                    gbd, gmc = plan.download(f)
+                    np.testing.assert_array_equal(gmc, want[f][1], err_msg=f"{paths} paths, mode {mode} ({plan.kernel_name}), frame {f}")
+                    np.testing.assert_array_equal(gbd, want[f][0], err_msg=f"{paths} paths, mode {mode} ({plan.kernel_name}), frame {f}")
+                np.testing.assert_array_equal(plan.download_sum(B - 1), want[B - 1][2], err_msg=f"{paths} paths, mode {mode}: S")
 
 
 @pytest.mark.parametrize("subpixel", [1, 0])

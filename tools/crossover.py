@@ -9,14 +9,13 @@ Bs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4
 for paths in (8, 4):
     for B in Bs:
         r = []
-        for strips in ("0", "1"):
-            os.environ["FSGM_EPI_STRIPS"] = strips
+        for strips in ("0",):
             plan = EpiPlan(W, H, D, B, paths=paths)
             plan.set_penalties(6, 64, 0.3)
             plan.upload_cost(0, base); plan.upload_offset(0, off)
             for f in range(1, B):
                 plan.copy_cost(f, 0, 11 * f); plan.upload_offset(f, off)
-            modes = ((1, 3, 2, 4) if paths == 8 else (1, 2, 4)) if strips == "0" else ((2,) if paths == 8 else ())
+            modes = (1, 3, 2, 4, 5) if paths == 8 else (1, 2, 4, 5)
             for mode in modes:
                 plan.set_agg_mode(mode)
                 r.append((plan.kernel_name + ("+strips" if strips == "1" else ""), plan.time(STAGE_AGGREGATE | STAGE_WTA, 2, 6)))
