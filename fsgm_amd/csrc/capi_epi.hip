@@ -122,7 +122,8 @@ static void select_kernel(fsgm_epi_plan* p) {
     // (P1 <= P2: the fused kernels' form of the step clamps path states at P2 first, epi_sweep.hip)
     const bool fusable = nowrap && p->P1 <= p->P2;
     p->sweep_par = false;
-    if (fusable && 3 * p->P2 <= 255 && p->prm.paths == 8 && want) {
+    // (the Y volumes hold y + P1 per path since round 3 -- step_b, epi_step.h -- so three / two of them must fit a byte with the bias)
+    if (fusable && 3 * (p->P1 + p->P2) <= 255 && p->prm.paths == 8 && want) {
         p->kernel_kind = AGG_SWEEP;
         // Between the line kernels and the full pipeline: the down and the up sweep side by side (H rows in sequence
         // instead of 2 H) with Y_up written out and a WTA kernel over C, Y_dn, Y_up, Y_h: 3 B per voxel more traffic,
@@ -131,7 +132,7 @@ static void select_kernel(fsgm_epi_plan* p) {
     }
     // the shipped 4-path configuration: both axes as pair kernels, the vertical one final (2*P2 <= 255:
     // the excess sum of a pair fits a byte)
-    if (fusable && 2 * p->P2 <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
+    if (fusable && 2 * (p->P1 + p->P2) <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
     // very large batches (or mode 4): the band sweeps
     p->band_chain = false;
     if (fusable && band_ok(p->D, p->prm.paths, p->P1, p->P2, cm) &&
@@ -689,7 +690,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         SweepSumArgs q;
         q.C = p->dC; q.Xdn = p->dX; q.Xup = p->dXupAll; q.v_frame_stride = p->N;
         q.Lh = p->dLh; q.lh_frame_stride = p->N; q.lh_natural = par_pair_fine(p);
-        q.nC = 8; q.P2 = p->P2; q.Sdbg = nullptr;
+        q.nC = 8; q.bias = p->P2 + p->P1; q.Sdbg = nullptr;
         launch_wta_sweep(p->stream, a, q, p->batch);
     } else if ((stages & FSGM_STAGE_WTA) && (p->kernel_kind == AGG_SWEEP || p->kernel_kind == AGG_PAIRS || p->kernel_kind == AGG_BAND)) {
         WtaArgs a;                                   // the argmin happened inside the final sweep / pair pass; finish the records
@@ -855,7 +856,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         SweepSumArgs q;
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX + (size_t)f * p->N; q.Xup = p->dXup; q.v_frame_stride = p->N;
         q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_natural = p->sweep_par ? par_pair_fine(p) : 0;
-        q.nC = 8; q.P2 = p->P2; q.Sdbg = p->dS;
+        q.nC = 8; q.bias = p->P2 + p->P1; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));
@@ -883,7 +884,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         SweepSumArgs q;
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dXup; q.Xup = nullptr; q.v_frame_stride = p->N;
         q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_natural = pairs_x_fine(p);
-        q.nC = 4; q.P2 = p->P2; q.Sdbg = p->dS;
+        q.nC = 4; q.bias = p->P2 + p->P1; q.Sdbg = p->dS;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));

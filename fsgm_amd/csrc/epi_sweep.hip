@@ -28,8 +28,10 @@
 // integers: the 3-input fp16 maximum / minimum of gfx950 are exact 3-input u16 maximum / minimum here
 // (probed on the device: tools/ubench/pk_rates.hip, and covered by every parity test).  A path start is the same
 // instruction stream with s = P2 (x = 0) and the stored minimum masked to 0.
-// What leaves the chip are the y of the paths, summed: Y_dn, Y_h (u8; 3*P2 <= 255), and S is rebuilt as
-// paths*(C + P2) - sum of y.
+// What leaves the chip are the y of the paths, summed: Y_dn, Y_h (u8), and S is rebuilt as paths*(C + P2) - sum of y.
+// Since round 3 the kernels run this step in the P1-biased form of epi_step.h (step_b: y + P1 = max3(s[d] + P1, s[d-1],
+// s[d+1]), costs biased by P2 + P1, plain 32-bit adds / subtracts where no packed form is needed): the volumes hold y + P1
+// per path (3*(P1+P2) <= 255 for the sweeps, 2*(P1+P2) <= 255 for a pair), and paths*(C + P2 + P1) - sum is the same S.
 //
 // Lane layout: LPP = D/16 adjacent lanes own a pixel, 16 consecutive d each.  Register i of a lane (i = 0..7) holds
 // d = 16j+i in its low and d = 16j+8+i in its high half (u16), so the d-1 / d+1 neighbours of a whole register are
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
     const uint8_t* __restrict__ StIn = a.state_in + f * a.state_frame_stride;    // [3][W][D] u8, written by the previous launch
     uint8_t* __restrict__ StOut = a.state_out + f * a.state_frame_stride;        // other buffer: no launch reads what it writes
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const uint32_t Bpk = (P2 + (uint32_t)a.P1) * 0x10001u;       // the costs' bias in the step's variable (epi_step.h, step_b): P2 + P1
     const int y0 = a.y0, rows = min(a.rows, H - y0);
     const bool first_block = y0 == 0;
     const LaneSel sel = lane_sel<LPP>(j);
@@ -242,16 +245,16 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
             uint32_t CP[8], Y[8], YS[8];
             LdsPair pdl, pdr;
             if (L16) { lds_issue(par, 0, gx - 1 - base0, pdl); lds_issue(par, 1, gx + 1 - base1, pdr); }    // in flight during the first step
-            unpack_c(cOwn[q], CP, P2pk);
+            unpack_cb(cOwn[q], CP, Bpk);
 
             // from above (0,+1)                                            calc_cost_sgm.cpp:193-202
-            step_s<LPP, MASKED>(VS[q], CP, YS, P1pk, P2, sel, tmask);
+            step_b<LPP, MASKED>(VS[q], CP, YS, P1pk, P2, sel, tmask);
 
             // from above-left (+1,+1): predecessor column gx-1                        :205-213
             {
                 uint32_t S[8];
                 if (L16) lds_take(pdl, S); else lds_get(par, 0, gx - 1 - base0, S);
-                step_s<LPP, MASKED>(S, CP, Y, P1pk, P2, sel, mask_dl[q] & tmask);
+                step_b<LPP, MASKED>(S, CP, Y, P1pk, P2, sel, mask_dl[q] & tmask);
                 if (own_ok) lds_put(par ^ 1, 0, gx - base0, S);
 #pragma unroll
                 for (int i = 0; i < 8; i++) YS[i] += Y[i];
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
             {
                 uint32_t S[8];
                 if (L16) lds_take(pdr, S); else lds_get(par, 1, gx + 1 - base1, S);
-                step_s<LPP, MASKED>(S, CP, Y, P1pk, P2, sel, mask_dr[q] & tmask);
+                step_b<LPP, MASKED>(S, CP, Y, P1pk, P2, sel, mask_dr[q] & tmask);
                 if (own_ok) lds_put(par ^ 1, 1, gx - base1, S);
 #pragma unroll
                 for (int i = 0; i < 8; i++) YS[i] += Y[i];
@@ -283,10 +286,10 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
         // halo unit: keeps the inward-flowing diagonal correct for the next rows
         if (k + hmin < rows) {                                   // wave-uniform
             uint32_t HP[8], S[8], Y[8];
-            unpack_c(cHalo, HP, P2pk);
+            unpack_cb(cHalo, HP, Bpk);
             const int px = hdir == 0 ? hx - 1 : hx + 1;
             lds_get(par, hdir, px - (hdir ? base1 : base0), S);
-            step_s<LPP, MASKED>(S, HP, Y, P1pk, P2, sel, mask_h & tmask);
+            step_b<LPP, MASKED>(S, HP, Y, P1pk, P2, sel, mask_h & tmask);
             if (halo_ok) lds_put(par ^ 1, hdir, hx - (hdir ? base1 : base0), S);
         }
         __syncthreads();                                         // diagonal states of row y visible to row y+1
@@ -384,9 +387,9 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
     const int p = valid ? gp : NP - 1;
     const size_t f = blockIdx.y;
     const size_t bo = (size_t)p * D + (size_t)j * 16;                    // byte offset in a u8 volume
-    const uint32_t P2pk = (uint32_t)q.P2 * 0x10001u, nC = (uint32_t)q.nC;
+    const uint32_t Bpk = (uint32_t)q.bias * 0x10001u, nC = (uint32_t)q.nC;     // bias = P2 + P1: the Y volumes hold y + P1 per path (step_b)
     uint32_t CP[8], YT[8], E2[8], ST[8];
-    unpack_c(wvol_load(q.C + f * q.v_frame_stride + bo), CP, P2pk);
+    unpack_cb(wvol_load(q.C + f * q.v_frame_stride + bo), CP, Bpk);
     unpack_p(wvol_load(q.Xdn + f * q.v_frame_stride + bo), YT);
     if (q.Xup) {
         unpack_p(wvol_load(q.Xup + f * q.v_frame_stride + bo), E2);
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
             else if (p + 1 < NP) {                                           // next pixel's d=0 (:296): byte 0 of its lane 0 in every volume
                 const size_t nb = f * q.v_frame_stride + (size_t)(p + 1) * D;
                 const size_t nh = f * q.lh_frame_stride + (size_t)(p + 1) * D;
-                c1 = nC * ((uint32_t)q.C[nb] + (uint32_t)q.P2) - ((uint32_t)q.Xdn[nb] + (q.Xup ? (uint32_t)q.Xup[nb] : 0u) + (uint32_t)q.Lh[nh]);
+                c1 = nC * ((uint32_t)q.C[nb] + (uint32_t)q.bias) - ((uint32_t)q.Xdn[nb] + (q.Xup ? (uint32_t)q.Xup[nb] : 0u) + (uint32_t)q.Lh[nh]);
             }
         }
         wta_finish(a, f, p, best, minc, c_1, c1);
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
     const uint8_t* __restrict__ Cl = a.C + f * a.c_frame_stride + (size_t)l * lstride + (size_t)j * 16;
     uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * (NT - 1)) * D + (size_t)j * 16;
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const uint32_t Bpk = (P2 + (uint32_t)a.P1) * 0x10001u;       // the costs' bias in the step's variable (epi_step.h, step_b): P2 + P1
     const LaneSel sel = lane_sel<LPP>(j);
     uint32_t S[8];
 #pragma unroll
@@ -490,8 +494,8 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
             const uint4 cw = ring[i];
             ring[i] = load_c(t - PF);
             uint32_t CP[8], Y[8];
-            unpack_c(cw, CP, P2pk);
-            step_s<LPP>(S, CP, Y, P1pk, P2, sel, t == len - 1 ? 0u : 0xFFFFu);
+            unpack_cb(cw, CP, Bpk);
+            step_b<LPP>(S, CP, Y, P1pk, P2, sel, t == len - 1 ? 0u : 0xFFFFu);
             // positions below `last` in the final group are computed but not needed; t >= 0 always holds there
             if (t >= last && (t % HP_TC) == 0) *(uint4*)(Kl + (size_t)(t / HP_TC - 1) * D) = pack_p(S);
         }
@@ -520,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
     const uint8_t* __restrict__ Ol = FINAL ? a.Xother + f * a.xo_frame_stride + lbase : nullptr;   // FINAL: the other pair's, in
     const uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * max(NT - 1, 1)) * D + (size_t)j * 16;
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const uint32_t Bpk = (P2 + (uint32_t)a.P1) * 0x10001u;       // the costs' bias in the step's variable (epi_step.h, step_b): P2 + P1
     const LaneSel sel = lane_sel<LPP>(j);
     uint32_t FS[8];                                               // forward state, carried across tiles
 #pragma unroll
@@ -546,14 +551,14 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
         for (int c = TC - 1; c >= 0; c--) {
             const int x = tb + c;
             uint32_t CP[8], Y[8];
-            unpack_c(cT[c], CP, P2pk);
+            unpack_cb(cT[c], CP, Bpk);
             uint32_t mmask = 0xFFFFu;
             if (EDGE && x >= len - 1) {                           // wave-uniform: the backward path starts here
 #pragma unroll
                 for (int i = 0; i < 8; i++) RS[i] = P2pk;
                 mmask = 0u;
             }
-            step_s<LPP>(RS, CP, Y, P1pk, P2, sel, mmask);
+            step_b<LPP>(RS, CP, Y, P1pk, P2, sel, mmask);
             exR[c] = pack_p(Y);
         }
         uint4 xo[TC];
@@ -566,8 +571,8 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
         for (int c = 0; c < TC; c++) {
             const int x = tb + c;
             uint32_t CP[8], Y[8];
-            unpack_c(cT[c], CP, P2pk);
-            step_s<LPP>(FS, CP, Y, P1pk, P2, sel, (EDGE && x == 0) ? 0u : 0xFFFFu);
+            unpack_cb(cT[c], CP, Bpk);
+            step_b<LPP>(FS, CP, Y, P1pk, P2, sel, (EDGE && x == 0) ? 0u : 0xFFFFu);
             if (!FINAL) {
                 // both y are <= P2 per byte and 2*P2 <= 255: the packed bytes add as plain words
                 if (!EDGE || x < len) pvol_store(Xl + (size_t)x * tstride, add4(pack_p(Y), exR[c]));
@@ -607,11 +612,11 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
 // Same passes, same checkpoint spacing; the checkpoint bytes and the Y of the tile stay in a private order of this
 // pair of kernels, the stored sum Y is in natural d order (PairArgs.xo_natural / SweepSumArgs.lh_natural tell its readers).
 // =============================================================================================
-__device__ __forceinline__ void unpack_c4(const uint2 w, uint32_t (&CP)[4], const uint32_t P2pk) {
-    CP[0] = pk_add(__builtin_amdgcn_perm(w.y, w.x, 0x0C040C00u), P2pk);
-    CP[1] = pk_add(__builtin_amdgcn_perm(w.y, w.x, 0x0C050C01u), P2pk);
-    CP[2] = pk_add(__builtin_amdgcn_perm(w.y, w.x, 0x0C060C02u), P2pk);
-    CP[3] = pk_add(__builtin_amdgcn_perm(w.y, w.x, 0x0C070C03u), P2pk);
+__device__ __forceinline__ void unpack_c4(const uint2 w, uint32_t (&CP)[4], const uint32_t biaspk) {     // bias = P2 + P1 (step_b's variable)
+    CP[0] = __builtin_amdgcn_perm(w.y, w.x, 0x0C040C00u) + biaspk;
+    CP[1] = __builtin_amdgcn_perm(w.y, w.x, 0x0C050C01u) + biaspk;
+    CP[2] = __builtin_amdgcn_perm(w.y, w.x, 0x0C060C02u) + biaspk;
+    CP[3] = __builtin_amdgcn_perm(w.y, w.x, 0x0C070C03u) + biaspk;
 }
 // private byte order of 4 registers: (R0.lo, R1.lo, R0.hi, R1.hi), (R2.lo, R3.lo, R2.hi, R3.hi)
 __device__ __forceinline__ uint2 pack_q(const uint32_t (&R)[4]) {
@@ -626,21 +631,17 @@ __device__ __forceinline__ uint2 natural_q(const uint2 v) {
     return make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x05040100u), __builtin_amdgcn_perm(v.y, v.x, 0x07060302u));
 }
 
-// step_s for 4 registers a lane, G lanes a pixel (G <= 16: one DPP row)
+// step_b (epi_step.h: the step in the P1-biased variable) for 4 registers a lane, G lanes a pixel (G <= 16: one DPP row)
 template <int G, bool MASKED = true>
-__device__ __forceinline__ void step_q(uint32_t (&S)[4], const uint32_t (&CP)[4], uint32_t (&Y)[4], const uint32_t P1pk,
+__device__ __forceinline__ void step_q(uint32_t (&S)[4], const uint32_t (&CB)[4], uint32_t (&YB)[4], const uint32_t P1pk,
                                        const uint32_t P2, const LaneSel sel, const uint32_t mmask) {
-    uint32_t T[4], N[4];
-    T[3] = pk_subs(S[3], P1pk);
-    T[0] = pk_subs(S[0], P1pk);
-    T[1] = pk_subs(S[1], P1pk);
-    T[2] = pk_subs(S[2], P1pk);
-    const uint32_t LT = __builtin_amdgcn_perm(T[3], (uint32_t)__builtin_amdgcn_mov_dpp((int)T[3], DPP_ROW_SHR1, 0xF, 0xF, true), sel.lo);
-    const uint32_t RT = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_mov_dpp((int)T[0], DPP_ROW_SHL1, 0xF, 0xF, true), T[0], sel.hi);
+    uint32_t N[4];
+    const uint32_t LT = __builtin_amdgcn_perm(S[3], (uint32_t)__builtin_amdgcn_mov_dpp((int)S[3], DPP_ROW_SHR1, 0xF, 0xF, true), sel.lo);
+    const uint32_t RT = __builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_mov_dpp((int)S[0], DPP_ROW_SHL1, 0xF, 0xF, true), S[0], sel.hi);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        Y[i] = pk_max3(S[i], i ? T[i - 1] : LT, i < 3 ? T[i + 1] : RT);
-        N[i] = pk_sub(CP[i], Y[i]);
+        YB[i] = pk_max3(S[i] + P1pk, i ? S[i - 1] : LT, i < 3 ? S[i + 1] : RT);
+        N[i] = CB[i] - YB[i];
     }
     const uint32_t mm = pk_min(N[0], pk_min3(N[1], N[2], N[3]));
     uint32_t mx = group_min_u32<G>(min_halves(mm));
@@ -665,6 +666,7 @@ __global__ __launch_bounds__(256) void pairx_ckpt_kernel(PairArgs a) {
     const uint8_t* __restrict__ Cl = a.C + f * a.c_frame_stride + (size_t)l * a.W * D + (size_t)j * 8;
     uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * (NT - 1)) * D + (size_t)j * 8;
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const uint32_t Bpk = (P2 + (uint32_t)a.P1) * 0x10001u;       // the costs' bias in the step's variable (epi_step.h, step_b): P2 + P1
     const LaneSel sel = lane_sel<G>(j);
     uint32_t S[4] = {P2pk, P2pk, P2pk, P2pk};                   // the path starts at the line's last position
     auto load_c = [&](int t) -> uint2 { return *(const uint2*)(Cl + (size_t)max(t, 0) * D); };
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(256) void pairx_ckpt_kernel(PairArgs a) {
             const uint2 cw = ring[i];
             ring[i] = load_c(t - PF);
             uint32_t CP[4], Y[4];
-            unpack_c4(cw, CP, P2pk);
+            unpack_c4(cw, CP, Bpk);
             step_q<G>(S, CP, Y, P1pk, P2, sel, t == len - 1 ? 0u : 0xFFFFu);
             if (t >= last && (t % HP_TC) == 0) *(uint2*)(Kl + (size_t)(t / HP_TC - 1) * D) = pack_q(S);
         }
@@ -702,6 +704,7 @@ __global__ __launch_bounds__(256) void pairx_sum_kernel(PairArgs a) {
     uint8_t* __restrict__ Xl = a.X + f * a.x_frame_stride + lbase;
     const uint8_t* __restrict__ Kl = a.ckpt + f * a.ckpt_frame_stride + ((size_t)l * max(NT - 1, 1)) * D + (size_t)j * 8;
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2 = (uint32_t)a.P2, P2pk = P2 * 0x10001u;
+    const uint32_t Bpk = (P2 + (uint32_t)a.P1) * 0x10001u;       // the costs' bias in the step's variable (epi_step.h, step_b): P2 + P1
     const LaneSel sel = lane_sel<G>(j);
     uint32_t FS[4] = {P2pk, P2pk, P2pk, P2pk};                  // position 0 starts the forward path
     auto load_c = [&](int t) -> uint2 { return *(const uint2*)(Cl + (size_t)min(t, len - 1) * D); };
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(256) void pairx_sum_kernel(PairArgs a) {
         for (int c = TC - 1; c >= 0; c--) {
             const int x = tb + c;
             uint32_t CP[4], Y[4];
-            unpack_c4(cT[c], CP, P2pk);
+            unpack_c4(cT[c], CP, Bpk);
             uint32_t mmask = 0xFFFFu;
             if (EDGE && x >= len - 1) {                           // wave-uniform: the backward path starts here
                 RS[0] = RS[1] = RS[2] = RS[3] = P2pk;
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(256) void pairx_sum_kernel(PairArgs a) {
         for (int c = 0; c < TC; c++) {
             const int x = tb + c;
             uint32_t CP[4], Y[4];
-            unpack_c4(cT[c], CP, P2pk);
+            unpack_c4(cT[c], CP, Bpk);
             step_q<G>(FS, CP, Y, P1pk, P2, sel, (EDGE && x == 0) ? 0u : 0xFFFFu);
             const uint2 yf = pack_q(Y);
             // both y are <= P2 per byte and 2*P2 <= 255: the packed bytes add as plain words

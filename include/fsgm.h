@@ -112,7 +112,7 @@ void        fsgm_epi_plan_destroy(fsgm_epi_plan* plan);
 fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t P2, double vMax);
 /* Aggregation strategy: 0 = auto, 1 = the per-direction line kernels, 2 = the fused pipeline whenever eligible
  * (8 paths: horizontal pair + down sweep + final up sweep with the WTA inside -- D = 16<<k, no-wrap penalties with
- * P1 <= P2 and 3*P2 <= 255; the shipped 4 paths: the pair kernels -- 2*P2 <= 255), 3 = 8 paths only: the down and the
+ * P1 <= P2 and 3*(P1+P2) <= 255; the shipped 4 paths: the pair kernels -- 2*(P1+P2) <= 255), 3 = 8 paths only: the down and the
  * up sweep side by side and a WTA kernel over the three sums (half the latency of 2, 3 B per voxel more traffic),
  * 4 = the band sweeps (epi_band.hip: all four paths of a raster pass in one sweep, one workgroup per frame, for batches of
  * hundreds of frames; D = 16<<k, no-wrap penalties with P1 <= P2, P1 + P2 <= 127), 5 = the band sweeps with the bands of a
