@@ -33,7 +33,7 @@ def test_epi_random_configs(gpu_lib, oracle, seed):
         for f in range(B):
             plan.upload_cost(f, vols[f])
             plan.upload_offset(f, off)
-        for mode in (1, 2):
+        for mode in (1, 2, 3, 4, 5):                         # a mode whose pipeline does not cover the configuration falls back
             plan.set_agg_mode(mode)
             plan.run(STAGE_AGGREGATE | STAGE_WTA)
             for f in range(B):
@@ -46,6 +46,43 @@ def test_epi_random_configs(gpu_lib, oracle, seed):
                 np.testing.assert_array_equal(gmc, mc, err_msg=msg)
                 np.testing.assert_array_equal(gbd, bd, err_msg=msg)
                 np.testing.assert_array_equal(plan.download_sum(f), S[:-1].reshape(H, W, D), err_msg=msg)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_epi_random_tall_configs(gpu_lib, oracle, seed):
+    """Tall narrow frames: several bands of the band sweeps (both forms), several row blocks of the block sweeps."""
+    r = _rng(500 + seed)
+    D = int(r.choice([16, 32, 64, 128, 128, 256]))
+    W, H = int(r.randint(1, 40)), int(r.randint(60, 330))
+    paths = int(r.choice([4, 8]))
+    P1 = int(r.randint(0, 30))
+    P2 = int(r.randint(P1, 100))                            # P1 <= P2; some beyond the fused kernels' byte budgets
+    sub, vz = int(r.rand() < 0.7), int(r.rand() < 0.5)
+    B = int(r.choice([1, 2, 3]))
+    vols = [synth.cost_volume(W, H, D, seed=seed * 10 + f, cmax=24) for f in range(B)]
+    for v in vols:
+        v[:, ::4, :] = 0
+    _, _, off = synth.epi_maps(W, H, "general", seed=seed)
+    want = []
+    for f in range(B):
+        S = oracle.epi_aggregate(vols[f], P1, P2, paths)
+        bd, mc = oracle.epi_wta(S, W, H, D, sub)
+        want.append((oracle.epi_vz_to_disp(bd, off, 0.3, D + 1) if vz else bd, mc, S[:-1].reshape(H, W, D)))
+    with EpiPlan(W, H, D, B, paths=paths, subpixel=sub, vz_to_disp=vz) as plan:
+        plan.set_penalties(P1, P2, 0.3)
+        for f in range(B):
+            plan.upload_cost(f, vols[f])
+            plan.upload_offset(f, off)
+        for mode in (4, 5, 2, 5, 4):
+            plan.set_agg_mode(mode)
+            plan.run(STAGE_AGGREGATE | STAGE_WTA)
+            for f in range(B):
+                gbd, gmc = plan.download(f)
+                msg = f"seed {seed} mode {mode} {plan.kernel_name} W{W} H{H} D{D} paths{paths} P{P1},{P2} frame {f}"
+                np.testing.assert_array_equal(gmc, want[f][1], err_msg=msg)
+                np.testing.assert_array_equal(gbd, want[f][0], err_msg=msg)
+            np.testing.assert_array_equal(plan.download_sum(B - 1), want[B - 1][2], err_msg=f"seed {seed} mode {mode} S")
+        plan.sync()
 
 
 @pytest.mark.parametrize("seed", range(12))
