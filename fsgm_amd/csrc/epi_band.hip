@@ -16,10 +16,11 @@
 //   final pass (MODE 2)  on the point-mirrored frame (pass 1, :114-123): its own four paths, then in registers
 //                        S = 8*(C + P2) - (Y_up + Y_dn) and the WTA; one 18-byte record per pixel (sweep_finish_kernel
 //                        does the parabola / vz conversion as for the block sweeps)
-//   4.3-4.6 B per voxel instead of 9.7, ~650 wave-instructions per 8 pixels instead of ~880.
+//   5.3 B per voxel through HBM (PMC counters, profiles/r03_pmc_traffic.json) instead of 9.7, ~650 wave-instructions per
+//   8 pixels instead of ~880.
 //
 // PATHS = 4 (the shipped configuration, :104): the two paths of a pass that remain (from the left, from above) need only
-// u = x + y; Y_dn <= 2*P2 fits a byte; 4 B per voxel instead of 7.5.
+// u = x + y; Y_dn <= 2*P2 fits a byte; 4.5 B per voxel (measured) instead of 7.5.
 //
 // Layout.  LPP = D/16 lanes own a pixel (16 costs each, register layout of epi_step.h); a wave owns 64/LPP consecutive
 // ROWS (lane group g <-> row), a workgroup of NWV waves a band of R = NWV*64/LPP rows; one workgroup walks one frame,

@@ -9,6 +9,7 @@
 // lines at a time, every lane moves its row as NW dwords.
 #include "pyd_kernels.h"
 #include "fsgm_device.h"
+#include <type_traits>
 
 namespace fsgm {
 
@@ -46,109 +47,183 @@ __device__ __forceinline__ uint32_t dup16(uint32_t v) { return v | (v << 16); }
 // The sample column depends on offx+ax only and the sample row on offy+ay only (:415-416), so the
 // (Sx+2r) x (Sy+2r) patch of image-2 census codes that all candidates and taps of a pixel touch is
 // staged in LDS once; lane ox then walks its Sy candidates with the patch column in registers:
-// (2r+1) x (Sy+2r) LDS reads per (2r+1)^2 x Sy taps, two VALU instructions per tap.  A wave whose
-// 4 pixels have a tap outside either image (constant cost 5, USE_CONST_COST :32,405-421) takes the
-// compare-and-select form of the same loop.
+// (2r+1) x (Sy+2r) LDS reads per (2r+1)^2 x Sy taps, two VALU instructions per tap.  A wave with a
+// sample outside image 2 (constant cost 5, USE_CONST_COST :32,405-421) takes a three-instruction
+// form of the same loop (masked xor), one with a tap outside image 1 a four-instruction form.
 // =============================================================================================
 constexpr int COST_PM = ROWS_MAXS + 4;                   // max patch side
-constexpr int COST_SLOT_DW = COST_PM * COST_PM + 25 + 2 * 16;   // patch, image-1 taps, column/row tables
+constexpr int COST_PPW = 8;                              // most pixels a wave takes
+// a pixel's LDS slot (dwords): patch [PY][PX] | image-1 taps [AW][AW] | column table [16] | row table [16] | x, y, hint (6)
+constexpr int COST_PATCH = 0, COST_C1 = COST_PM * COST_PM, COST_XT = COST_C1 + 25, COST_YT = COST_XT + 16, COST_HDR = COST_YT + 16;
+constexpr int COST_SLOT = COST_HDR + 6 + 11;             // 288 + 11 dwords: lane l of the wave reads bank l + const in the tap
+                                                         // loop of an 11-wide window (other widths: a few two-way conflicts)
+constexpr uint32_t ROWS_OUTSIDE2 = 0x7C000000u;          // a sample outside image 2: five bits where no census code has any
+
+// Sx lanes own a pixel (lane <-> candidate column ox), a wave takes 64 / Sx pixels (5 at the reference's 11 x 11 window:
+// 55 of 64 lanes busy in the tap loop, against 44 with one pixel per DPP row).
+__host__ __device__ inline int cost_ppw(int Sx) { return 64 / Sx < COST_PPW ? 64 / Sx : COST_PPW; }
+
+// k / n as a 24-bit multiply and a shift: exact while k < 2048 and k * n < 2^20 (magic * n - 2^20 <= n); here k <= 8 * 15 * 15
+// and n <= 15 * 15.  (The index splits of the fills were a third of the kernel's instructions as integer divisions.)
+__host__ __device__ inline uint32_t div_magic(int n) { return (1u << 20) / (uint32_t)n + 1u; }
+__device__ __forceinline__ int div_by(int k, uint32_t magic) { return (int)(__umul24((uint32_t)k, magic) >> 20); }
+// base[idx] with a 32-bit index: the address stays "uniform base + 32-bit lane offset"
+__device__ __forceinline__ uint32_t load_u32_at(const uint32_t* base, uint32_t idx) {
+    return *(const uint32_t*)((const char*)base + (size_t)(idx * 4u));
+}
 
 template <int NW>
 __global__ __launch_bounds__(256) void pyd_rows_cost_kernel(PydCostArgs a) {
-    __shared__ uint32_t sCost[4 * 4 * COST_SLOT_DW];
+    extern __shared__ uint32_t sCost[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 15, slot = lane >> 4;
     const int W = a.W, H = a.H, r = a.rAgg;
     const int NP = W * H;
     const int Sx = 2 * a.rX + 1, Sy = 2 * a.rY + 1;
-    const int PX = Sx + 2 * r, PY = Sy + 2 * r, AW = 2 * r + 1;
-    uint32_t* const patch = sCost + (wave * 4 + slot) * COST_SLOT_DW;   // [PY][PX]
-    uint32_t* const c1s = patch + COST_PM * COST_PM;                    // [AW][AW]
-    int* const x2tab = (int*)(c1s + 25);                                // [PX]
-    int* const y2tab = x2tab + 16;                                      // [PY]
-    int p = (blockIdx.x * 4 + wave) * 4 + slot;
-    const bool active = p < NP;
-    p = min(p, NP - 1);
-    const int y = p / W, x = p - y * W;
+    const int PX = Sx + 2 * r, PY = Sy + 2 * r, AW = 2 * r + 1, NA = AW * AW;
+    const int ppw = cost_ppw(Sx);
+    constexpr int SLOT = COST_SLOT;
+    const uint32_t magicAW = div_magic(AW), magicNA = div_magic(NA);
+    uint32_t* const wbase = sCost + wave * ppw * SLOT;
+    const int sraw = div_by(lane, div_magic(Sx));
+    const bool live = sraw < ppw;                          // lanes beyond the last whole pixel idle
+    const int slot = live ? sraw : 0, j = live ? lane - sraw * Sx : 0;
+    const int p0 = (blockIdx.x * 4 + wave) * ppw;          // the wave's first pixel
     const size_t f = blockIdx.y;
-    const double* mvxp = a.mv + f * 2 * (size_t)a.mvW * a.mvH;
-    const double* mvyp = mvxp + (size_t)a.mvW * a.mvH;
-    const double mvx = mvxp[(size_t)a.mvW * y + x], mvy = mvyp[(size_t)a.mvW * y + x];   // :388-389
     const uint32_t* __restrict__ cen1 = a.cen1 + f * (size_t)NP;
     const uint32_t* __restrict__ cen2 = a.cen2 + f * (size_t)NP;
-    bool outside = false;
-    if (j < PX) {                                        // k = (offx + rX) + (ax + r)  ->  offx + x1 = x + k - rX - r
-        const int x2 = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)(x + j - a.rX - r), mvx), 0.5));   // :416
-        x2tab[j] = (x2 >= 0 && x2 <= W - 1) ? x2 : -1;
+    if (lane < ppw) {                                      // pixel coordinates and hint, once per pixel
+        const int p = min(p0 + lane, NP - 1);
+        const int y = p / W, x = p - y * W;
+        const double* mvxp = a.mv + f * 2 * (size_t)a.mvW * a.mvH;
+        const double* mvyp = mvxp + (size_t)a.mvW * a.mvH;
+        uint32_t* h = wbase + lane * SLOT + COST_HDR;
+        h[0] = (uint32_t)x;
+        h[1] = (uint32_t)y;
+        const double mvx = mvxp[(size_t)a.mvW * y + x], mvy = mvyp[(size_t)a.mvW * y + x];             // :388-389
+        h[2] = (uint32_t)__double2loint(mvx); h[3] = (uint32_t)__double2hiint(mvx);
+        h[4] = (uint32_t)__double2loint(mvy); h[5] = (uint32_t)__double2hiint(mvy);
     }
-    if (j < PY) {
-        const int y2 = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)(y + j - a.rY - r), mvy), 0.5));   // :415
-        y2tab[j] = (y2 >= 0 && y2 <= H - 1) ? y2 : -1;
-    }
-    // Fills in two phases -- every address first, then all loads in flight together, then the LDS
-    // writes: as a plain loop each iteration waited for its own gathered load (~1 us), which made
-    // the fill, not the 3025 taps, the longest part of the kernel.
-    {
-        uint32_t v[2];
+    __builtin_amdgcn_wave_barrier();
+    bool outside1 = false;                                 // a tap outside image 1 / a sample outside image 2 (:405, :418)
+    uint32_t outside2 = 0;
 #pragma unroll
-        for (int it = 0; it < 2; it++) {                             // (2r+1)^2 <= 25 image-1 taps
-            const int k = j + 16 * it;
-            const int kc = min(k, AW * AW - 1);
-            const int y1 = y + kc / AW - r, x1 = x + kc % AW - r;
-            const bool in = y1 >= 0 && y1 <= H - 1 && x1 >= 0 && x1 <= W - 1;                        // :405
-            v[it] = in ? cen1[(size_t)W * (in ? y1 : 0) + (in ? x1 : 0)] : ROWS_OUTSIDE;
-            outside |= !in && k < AW * AW;
+    for (int it = 0; it < COST_PPW * 16 / 64; it++) {      // sample column / row tables: entry k of pixel es
+        const int e = lane + 64 * it, es = e >> 4, k = e & 15;
+        if (es < ppw) {
+            uint32_t* sl = wbase + es * SLOT;
+            const int x = (int)sl[COST_HDR], y = (int)sl[COST_HDR + 1];
+            const double mvx = __hiloint2double((int)sl[COST_HDR + 3], (int)sl[COST_HDR + 2]);
+            const double mvy = __hiloint2double((int)sl[COST_HDR + 5], (int)sl[COST_HDR + 4]);
+            // k = (offx + rX) + (ax + r)  ->  offx + x1 = x + k - rX - r
+            const int x2 = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)(x + k - a.rX - r), mvx), 0.5));   // :416
+            const int y2 = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)(y + k - a.rY - r), mvy), 0.5));   // :415
+            sl[COST_XT + k] = (x2 >= 0 && x2 <= W - 1) ? (uint32_t)x2 : 0x80000000u;
+            sl[COST_YT + k] = (y2 >= 0 && y2 <= H - 1) ? (uint32_t)(y2 * W) : 0x80000000u;
+        }
+    }
+    // Fills: every address first, then all loads in flight together, then the LDS writes (as a plain loop each
+    // iteration waited for its own gathered load).  Cells are dealt to the 64 lanes across the wave's pixels.
+    {
+        const int ncell = ppw * NA;                                  // (2r+1)^2 <= 25 image-1 taps per pixel
+        uint32_t v[4];
+        int dst[4];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int e = lane + 64 * it, ec = min(e, ncell - 1);
+            const int es = div_by(ec, magicNA), kc = ec - es * NA;
+            const int ky = div_by(kc, magicAW), kx = kc - ky * AW;
+            const uint32_t* sl = wbase + es * SLOT;
+            const int y1 = (int)sl[COST_HDR + 1] + ky - r, x1 = (int)sl[COST_HDR] + kx - r;
+            const bool in = y1 >= 0 && y1 <= H - 1 && x1 >= 0 && x1 <= W - 1;                            // :405
+            v[it] = load_u32_at(cen1, in ? (uint32_t)(W * y1 + x1) : 0u);
+            if (!in) v[it] = ROWS_OUTSIDE;
+            outside1 |= !in;
+            dst[it] = e < ncell ? es * SLOT + COST_C1 + kc : -1;
         }
 #pragma unroll
-        for (int it = 0; it < 2; it++)
-            if (j + 16 * it < AW * AW) c1s[j + 16 * it] = v[it];
+        for (int it = 0; it < 4; it++)
+            if (dst[it] >= 0) wbase[dst[it]] = v[it];
     }
     __builtin_amdgcn_wave_barrier();
     {
-        constexpr int NIT = (COST_PM * COST_PM + 15) / 16;           // 15 rounds cover the largest patch
-        uint32_t v[NIT];
+        // patch of image-2 census codes: lane (kr, kx) = (lane / 16, lane % 16) takes the cells (kr + 4 * rr, kx) of one
+        // pixel after the other -- no index arithmetic, the LDS offsets are immediates
+        const int kx = lane & 15, kr = lane >> 4;
+        int cell[4];
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int k = j + 16 * it;
-            const int kc = min(k, PX * PY - 1);
-            const int ky = kc / PX, kx = kc - ky * PX;
-            const int y2 = y2tab[ky], x2 = x2tab[kx];
-            const bool in = y2 >= 0 && x2 >= 0;                                                      // :418
-            v[it] = in ? cen2[(size_t)W * (in ? y2 : 0) + (in ? x2 : 0)] : ROWS_OUTSIDE;
-            outside |= !in && k < PX * PY;
+        for (int rr = 0; rr < 4; rr++) cell[rr] = (kx < PX && kr + 4 * rr < PY) ? (kr + 4 * rr) * PX + kx : -1;
+#pragma unroll
+        for (int es = 0; es < COST_PPW; es++) {
+            if (es >= ppw) continue;                                 // wave-uniform
+            uint32_t* sl = wbase + es * SLOT;
+            const uint32_t x2 = sl[COST_XT + kx];
+            uint32_t v[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const uint32_t t = sl[COST_YT + kr + 4 * rr] | x2;   // sign bit: row or column outside
+                const uint32_t yx = sl[COST_YT + kr + 4 * rr] + x2;
+                const bool in = (int)t >= 0;                                                             // :418
+                v[rr] = load_u32_at(cen2, in ? yx : 0u);
+                if (!in) v[rr] = ROWS_OUTSIDE2;
+                if (cell[rr] >= 0) outside2 |= t;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+                if (cell[rr] >= 0) sl[COST_PATCH + cell[rr]] = v[rr];
         }
-#pragma unroll
-        for (int it = 0; it < NIT; it++)
-            if (j + 16 * it < PX * PY) patch[j + 16 * it] = v[it];
     }
     __builtin_amdgcn_wave_barrier();
-    const bool any_outside = __builtin_amdgcn_ballot_w64(outside) != 0;       // wave-uniform
-    const int ox = min(j, Sx - 1);
+    const bool any1 = __builtin_amdgcn_ballot_w64(outside1) != 0;             // wave-uniform
+    const bool any2 = __builtin_amdgcn_ballot_w64((int)outside2 < 0) != 0;
+    const uint32_t* const patch = wbase + slot * SLOT + COST_PATCH + j;        // [PY][PX], this lane's column ox = j
+    const uint32_t* const c1s = wbase + slot * SLOT + COST_C1;                 // [AW][AW]
     uint32_t sum[4 * NW];
 #pragma unroll
     for (int i = 0; i < 4 * NW; i++) sum[i] = 0;
+    // The taps.  MODE 0: every sample inside both images, xor + popcount.  MODE 1: samples outside image 2 cost 5
+    // (USE_CONST_COST :32,:419): their patch word is ROWS_OUTSIDE2 and the image-1 code is masked away before the xor.
+    // MODE 2: image-1 taps outside as well (:406): those contribute nothing here and 5 per tap at the end.
+    // Patch rows past PY and taps past AW read other words of the slot: they only reach sums that are dropped (oy >= Sy).
+    auto taps = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        uint32_t extra = 0;
 #pragma unroll
-    for (int ax = 0; ax < 5; ax++) {
-        if (ax >= AW) continue;
-        uint32_t pc[4 * NW + 4];                           // patch column ox+ax, rows 0 .. Sy+2r-1
+        for (int ax = 0; ax < 5; ax++) {
+            if (ax >= AW) continue;
+            uint32_t pc[4 * NW + 4], pm[MODE ? 4 * NW + 4 : 1], u[5];      // patch column ox+ax, rows 0 .. Sy+2r-1
 #pragma unroll
-        for (int q = 0; q < 4 * NW + 4; q++) pc[q] = q < PY ? patch[q * PX + ox + ax] : 0u;
+            for (int q = 0; q < 4 * NW + 4; q++) pc[q] = patch[q * PX + ax];
 #pragma unroll
-        for (int ay = 0; ay < 5; ay++) {
-            if (ay >= AW) continue;
-            const uint32_t u = c1s[ay * AW + ax];
-            if (!any_outside) {
+            for (int ay = 0; ay < 5; ay++) u[ay] = c1s[ay * AW + ax];
+            if (MODE) {
 #pragma unroll
-                for (int oy = 0; oy < 4 * NW; oy++) sum[oy] += __popc(u ^ pc[oy + ay]);              // :427
-            } else {
+                for (int q = 0; q < 4 * NW + 4; q++) pm[q] = pc[q] == ROWS_OUTSIDE2 ? 0u : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int ay = 0; ay < 5; ay++) {
+                if (ay >= AW) continue;
+                uint32_t mu = 0xFFFFFFFFu;
+                if (MODE == 2) {
+                    const bool uin = u[ay] != ROWS_OUTSIDE;
+                    mu = uin ? 0xFFFFFFFFu : 0u;
+                    extra += uin ? 0u : 5u;
+                }
 #pragma unroll
                 for (int oy = 0; oy < 4 * NW; oy++) {
-                    const uint32_t v = pc[oy + ay];
-                    sum[oy] += (u == ROWS_OUTSIDE || v == ROWS_OUTSIDE) ? 5u : (uint32_t)__popc(u ^ v);   // :406,:419
+                    if (MODE == 0)      sum[oy] += __popc(u[ay] ^ pc[oy + ay]);                          // :427
+                    else if (MODE == 1) sum[oy] += __popc((u[ay] & pm[oy + ay]) ^ pc[oy + ay]);
+                    else                sum[oy] += __popc(((u[ay] & pm[oy + ay]) ^ pc[oy + ay]) & mu);
                 }
             }
         }
-    }
+        if (MODE == 2) {
+#pragma unroll
+            for (int oy = 0; oy < 4 * NW; oy++) sum[oy] += extra;
+        }
+    };
+    if (any1)      taps(std::integral_constant<int, 2>{});
+    else if (any2) taps(std::integral_constant<int, 1>{});
+    else           taps(std::integral_constant<int, 0>{});
     // (u8)(1.0*sum/win + 0.5) (:431) without the fp64 division: win = (2r+1)^2 is odd, so sum/win + 0.5
     // is never within 1/(2*win) of an integer and the truncation equals (2*sum + win) / (2*win) in
     // integers; that quotient by multiply-shift (exact for every sum up to 32*win, checked value by
@@ -166,8 +241,8 @@ __global__ __launch_bounds__(256) void pyd_rows_cost_kernel(PydCostArgs a) {
         }
         out[k] = w;
     }
-    if (active && j < Sx) {
-        uint32_t* dst = (uint32_t*)(a.C + (f * (size_t)NP + p) * a.PS + (size_t)j * a.RS);
+    if (live && p0 + slot < NP) {
+        uint32_t* dst = (uint32_t*)(a.C + (f * (size_t)NP + (size_t)(p0 + slot)) * a.PS + (size_t)j * a.RS);
 #pragma unroll
         for (int k = 0; k < NW; k++) dst[k] = out[k];
     }
@@ -429,9 +504,9 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
 #pragma unroll
             for (int k = 0; k < 2 * NL; k++) {
                 const uint32_t v = k < NL ? ME[k] : MO[k - NL];
-                const uint32_t t1 = dpp_shift0<DPP_ROW_SHR1>(v), t2 = dpp_shift0<DPP_ROW_SHL1>(v);
-                const uint32_t t3 = dpp_shift0<DPP_ROW_SHR2>(v), t4 = dpp_shift0<DPP_ROW_SHL2>(v);
-                const uint32_t h = pk_min(pk_min(v, t1), pk_min(pk_min(t2, t3), t4));
+                const uint32_t a2 = pk_min(v, dpp_shift0<DPP_ROW_SHL1>(v));         // lanes j, j+1
+                const uint32_t a4 = pk_min(a2, dpp_shift0<DPP_ROW_SHL2>(a2));       // lanes j .. j+3
+                const uint32_t h = pk_min(dpp_shift0<DPP_ROW_SHR2>(a4), dpp_shift0<DPP_ROW_SHL2>(v));   // j-2 .. j+1, j+2
                 if (k < NL) ME[k] = h; else MO[k - NL] = h;
             }
             if (__builtin_amdgcn_ballot_w64(nax != 0) != 0) {
@@ -536,12 +611,13 @@ __global__ __launch_bounds__(256) void pyd_rows_agg_kernel(PydAggArgs a) {
 
 // =============================================================================================
 // WTA + y/x parabola  (calc_pyd_cost_sgm.cpp:298-364).  4 pixels per wave; lane j sums the path
-// costs of candidate row j in packed u16 (weights: a third pass repeats the mirrored one), the
-// first minimum in candidate order is the minimum of (sum << 8 | index) keys.
+// costs of candidate row j (byte dot products over the directions), the first minimum in candidate
+// order is the minimum of (sum << 8 | index) keys.
 // =============================================================================================
 template <int NW>
 __global__ __launch_bounds__(256) void pyd_rows_wta_kernel(PydWtaArgs a) {
-    __shared__ uint16_t sSum[4][4][16][4 * NW];
+    constexpr int PIXDW = 16 * 2 * NW + 1;                 // LDS dwords per pixel: 16 candidate rows of 4*NW u16 sums; odd, so
+    __shared__ uint32_t sSum[4 * 4 * PIXDW];               // that the wave's four pixels sit in different banks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, slot4 = lane >> 4;
     const int NP = a.W * a.H, Sy = a.Sy, Sx = a.Sx, D = Sx * Sy;
@@ -557,45 +633,56 @@ __global__ __launch_bounds__(256) void pyd_rows_wta_kernel(PydWtaArgs a) {
     for (int r = 0; r < 8; r++)
 #pragma unroll
         for (int k = 0; k < NW; k++) v[r][k] = r < a.ndirs ? ((const uint32_t*)(Lp + r * vol))[k] : 0u;
-    uint32_t SE[NW], SO[NW];
+    // Sp += L (:227-232) as byte dot products: the four bytes of a dword are four sy, so the dwords of four directions are
+    // transposed (8 v_perm) into one dword per sy holding that sy of the four directions, and v_dot4_u32_u8 with the
+    // directions' weights as bytes (a third pass repeats the mirrored one) adds them up: 3 instructions per loaded dword.
+    const uint32_t wlo = a.weight[0] | (a.weight[1] << 8) | (a.weight[2] << 16) | (a.weight[3] << 24);
+    const uint32_t whi = a.weight[4] | (a.weight[5] << 8) | (a.weight[6] << 16) | (a.weight[7] << 24);
+    uint32_t S[4 * NW];
 #pragma unroll
-    for (int k = 0; k < NW; k++) { SE[k] = 0; SO[k] = 0; }
+    for (int k = 0; k < NW; k++) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint32_t w2 = dup16(a.weight[r]);
+        for (int b = 0; b < 4; b++) S[4 * k + b] = 0;
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            SE[k] = pk_mad(v[r][k] & 0x00FF00FFu, w2, SE[k]);                    // :227-232 Sp += L
-            SO[k] = pk_mad((v[r][k] >> 8) & 0x00FF00FFu, w2, SO[k]);
+        for (int g = 0; g < 2; g++) {
+            const uint32_t d0 = v[4 * g][k], d1 = v[4 * g + 1][k], d2 = v[4 * g + 2][k], d3 = v[4 * g + 3][k];
+            const uint32_t lo01 = __builtin_amdgcn_perm(d1, d0, 0x05010400u), hi01 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);
+            const uint32_t lo23 = __builtin_amdgcn_perm(d3, d2, 0x05010400u), hi23 = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
+            const uint32_t c0 = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u), c1 = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+            const uint32_t c2 = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u), c3 = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+            const uint32_t w = g ? whi : wlo;
+            S[4 * k + 0] = __builtin_amdgcn_udot4(c0, w, S[4 * k + 0], false);
+            S[4 * k + 1] = __builtin_amdgcn_udot4(c1, w, S[4 * k + 1], false);
+            S[4 * k + 2] = __builtin_amdgcn_udot4(c2, w, S[4 * k + 2], false);
+            S[4 * k + 3] = __builtin_amdgcn_udot4(c3, w, S[4 * k + 3], false);
         }
     }
+    uint32_t* const pixS = sSum + (wave * 4 + slot4) * PIXDW;
+#pragma unroll
+    for (int i = 0; i < 2 * NW; i++) pixS[j * 2 * NW + i] = S[2 * i] | (S[2 * i + 1] << 16);
     uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
     for (int s = 0; s < 4 * NW; s++) {
-        const uint32_t reg = (s & 1) ? SO[s >> 2] : SE[s >> 2];
-        const uint32_t val = (s & 2) ? reg >> 16 : reg & 0xFFFFu;
-        sSum[wave][slot4][j][s] = (uint16_t)val;
         if (s < Sy && j < Sx) {
-            key = min(key, (val << 8) | (uint32_t)(j * Sy + s));                 // :302-311 first strict minimum
-            if (a.S && active) a.S[(f * NP + p) * (size_t)D + j * Sy + s] = val;
+            key = min(key, (S[s] << 8) | (uint32_t)(j * Sy + s));                // :302-311 first strict minimum
+            if (a.S && active) a.S[(f * NP + p) * (size_t)D + j * Sy + s] = S[s];
         }
     }
     key = group_min_u32<16>(key);
     __builtin_amdgcn_wave_barrier();
-    if (j == 0 && active) {
+    if (j < 2 && active) {                                   // lane 0: outputs and the y parabola, lane 1: the x parabola
         const uint32_t gidx = key & 0xFFu, glo = key >> 8;
-        a.bestD[f * NP + p] = gidx;
-        a.minC[f * NP + p] = glo;
-        double subx = 0.0, suby = 0.0;
-        if (a.subpixel) {
-            const double c0 = (double)glo;
-            const int dx = gidx / Sy, dy = gidx % Sy;                            // :333-334
-            const uint16_t(*S)[4 * NW] = sSum[wave][slot4];
-            if (dy > 0 && dy < Sy - 1) suby = pyd_parabola((double)S[dx][dy - 1], c0, (double)S[dx][dy + 1]);
-            if (dx > 0 && dx < Sx - 1) subx = pyd_parabola((double)S[dx - 1][dy], c0, (double)S[dx + 1][dy]);
+        if (j == 0) {
+            a.bestD[f * NP + p] = gidx;
+            a.minC[f * NP + p] = glo;
         }
-        a.mvSub[f * 2 * (size_t)NP + p] = subx;              // zero when subpixel is off (:476 zero-init output)
-        a.mvSub[f * 2 * (size_t)NP + NP + p] = suby;
+        const int dx = (int)((gidx * ((1u << 20) / (uint32_t)Sy + 1u)) >> 20), dy = (int)gidx - dx * Sy;   // :333-334 (gidx / Sy)
+        const uint16_t* Sp = (const uint16_t*)pixS;          // [16][4 * NW]
+        const int at = dx * 4 * NW + dy, stride = j == 0 ? 1 : 4 * NW;
+        const bool inner = j == 0 ? (dy > 0 && dy < Sy - 1) : (dx > 0 && dx < Sx - 1);
+        double sub = 0.0;                                    // zero when subpixel is off (:476 zero-init output)
+        if (a.subpixel && inner) sub = pyd_parabola((double)Sp[at - stride], (double)glo, (double)Sp[at + stride]);
+        a.mvSub[f * 2 * (size_t)NP + (j == 0 ? NP : 0) + p] = sub;              // plane 0: x, plane 1: y
     }
 }
 
@@ -604,13 +691,16 @@ __global__ __launch_bounds__(256) void pyd_rows_wta_kernel(PydWtaArgs a) {
 // =============================================================================================
 bool pyd_rows_cost_ok(const PydCostArgs& a) {
     const int Sx = 2 * a.rX + 1, Sy = 2 * a.rY + 1;
-    return pyd_rows_layout(Sx, Sy) && a.RS == pyd_row_stride(Sx, Sy) && a.rAgg <= 2 && (long long)a.W * a.H < 2147483647LL;
+    return pyd_rows_layout(Sx, Sy) && a.RS == pyd_row_stride(Sx, Sy) && a.rAgg <= 2 && (long long)a.W * a.H < (1LL << 30);
 }
 
 bool pyd_rows_wta_ok(const PydWtaArgs& a) {
     uint32_t wsum = 0;
-    for (int r = 0; r < a.ndirs; r++) wsum += a.weight[r];
-    return pyd_rows_layout(a.Sx, a.Sy) && a.RS == pyd_row_stride(a.Sx, a.Sy) && wsum * 255u <= 65535u;
+    for (int r = 0; r < a.ndirs; r++) {
+        wsum += a.weight[r];
+        if (a.weight[r] > 255u) return false;
+    }
+    return pyd_rows_layout(a.Sx, a.Sy) && a.RS == pyd_row_stride(a.Sx, a.Sy) && wsum * 255u <= 65535u;   // weights are bytes, sums u16
 }
 
 #define FSGM_ROWS_DISPATCH(NWV, CALL)            \
@@ -621,8 +711,10 @@ bool pyd_rows_wta_ok(const PydWtaArgs& a) {
     } while (0)
 
 void launch_pyd_rows_cost(hipStream_t st, const PydCostArgs& a, int frames) {
-    dim3 grid((unsigned)((a.W * a.H + 15) / 16), frames);
-    FSGM_ROWS_DISPATCH(a.RS / 4, hipLaunchKernelGGL((pyd_rows_cost_kernel<NW>), grid, dim3(256), 0, st, a));
+    const int Sx = 2 * a.rX + 1, per_block = 4 * cost_ppw(Sx);
+    dim3 grid((unsigned)((a.W * a.H + per_block - 1) / per_block), frames);
+    const size_t lds = (size_t)4 * cost_ppw(Sx) * COST_SLOT * sizeof(uint32_t);
+    FSGM_ROWS_DISPATCH(a.RS / 4, hipLaunchKernelGGL((pyd_rows_cost_kernel<NW>), grid, dim3(256), lds, st, a));
 }
 
 void launch_pyd_rows_desc(hipStream_t st, const PydAggArgs& a, int frames) {
