@@ -167,11 +167,8 @@ static fsgm_status ng_pyramid_enqueue(fsgm_ng_pyramid_plan* p) {
     }
     if (ch == 3)
         for (int l = 0; l < n; l++) {                                            // :44-45
-            const size_t np = (size_t)p->Ws[l] * p->Hs[l];
-            for (int f = 0; f < B; f++) {
-                launch_pyr_gray(s, p->dP0[l] + f * 3 * np, p->dG0[l] + f * np, p->Ws[l], p->Hs[l]);
-                launch_pyr_gray(s, p->dP1[l] + f * 3 * np, p->dG1[l] + f * np, p->Ws[l], p->Hs[l]);
-            }
+            launch_pyr_gray(s, p->dP0[l], p->dG0[l], p->Ws[l], p->Hs[l], B);          // all frames in one launch
+            launch_pyr_gray(s, p->dP1[l], p->dG1[l], p->Ws[l], p->Hs[l], B);
         }
     for (int l = n - 1; l >= 0; l--) {                                           // :37
         const int w = p->Ws[l], h = p->Hs[l];
@@ -202,8 +199,7 @@ static fsgm_status ng_pyramid_enqueue(fsgm_ng_pyramid_plan* p) {
             launch_ng_subpixel(s, sa, B);
         }
         if (l > 0)                                                               // pyramidal_sgm.m:72
-            for (int f = 0; f < B; f++)
-                launch_pyr_upsample2(s, p->dFlow[l] + (size_t)f * 2 * w * h, p->dMv[l - 1] + (size_t)f * 2 * p->mvW[l - 1] * p->mvH[l - 1], w, h);
+            launch_pyr_upsample2(s, p->dFlow[l], p->dMv[l - 1], w, h, B, (size_t)2 * p->mvW[l - 1] * p->mvH[l - 1]);
     }
     FSGM_HIP(hipGetLastError());
     return FSGM_OK;

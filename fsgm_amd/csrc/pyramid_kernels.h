@@ -22,6 +22,7 @@ void launch_pyr_reduce(hipStream_t st, const uint8_t* in, uint8_t* out, int W, i
 void launch_pyr_gray(hipStream_t st, const uint8_t* rgb, uint8_t* out, int W, int H, int frames = 1);   // rgb [frames][3][H][W] -> [frames][H][W]
 void launch_pyr_flow(hipStream_t st, const PyrFlowArgs& a, int frames = 1);   // every array [frames][...]
 // next[2][2H][2W] = 2 * flow[2][H][W] at (y/2, x/2): 2*imresize(mv, 2, 'nearest') (pyramidal_sgm.m:72)
-void launch_pyr_upsample2(hipStream_t st, const double* flow, double* next, int W, int H);
+// (flow [frames][2][H][W]; frame f of `next` starts next_frame_stride doubles after frame f-1)
+void launch_pyr_upsample2(hipStream_t st, const double* flow, double* next, int W, int H, int frames = 1, size_t next_frame_stride = 0);
 
 }  // namespace fsgm

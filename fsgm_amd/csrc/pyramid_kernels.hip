@@ -89,18 +89,21 @@ void launch_pyr_flow(hipStream_t st, const PyrFlowArgs& a, int frames) {
     hipLaunchKernelGGL(pyr_flow_kernel, grid, dim3(256), 0, st, a);
 }
 
-__global__ __launch_bounds__(256) void pyr_upsample2_kernel(const double* __restrict__ flow, double* __restrict__ next, int W, int H) {
+__global__ __launch_bounds__(256) void pyr_upsample2_kernel(const double* __restrict__ flow, double* __restrict__ next, int W, int H,
+                                                            size_t next_frame_stride) {
     const int W2 = 2 * W, H2 = 2 * H;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= W2 * H2) return;
     const int y = i / W2, x = i - y * W2;
     const size_t src = (size_t)(y >> 1) * W + (x >> 1), np = (size_t)W * H, np2 = (size_t)W2 * H2;
+    flow += blockIdx.y * 2 * np;
+    next += blockIdx.y * next_frame_stride;
     next[i] = __dmul_rn(2.0, flow[src]);
     next[np2 + i] = __dmul_rn(2.0, flow[np + src]);
 }
 
-void launch_pyr_upsample2(hipStream_t st, const double* flow, double* next, int W, int H) {
-    hipLaunchKernelGGL(pyr_upsample2_kernel, dim3((4 * W * H + 255) / 256), dim3(256), 0, st, flow, next, W, H);
+void launch_pyr_upsample2(hipStream_t st, const double* flow, double* next, int W, int H, int frames, size_t next_frame_stride) {
+    hipLaunchKernelGGL(pyr_upsample2_kernel, dim3((4 * W * H + 255) / 256, frames), dim3(256), 0, st, flow, next, W, H, next_frame_stride);
 }
 
 }  // namespace fsgm
