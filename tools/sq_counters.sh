@@ -52,15 +52,28 @@ for leg in legs:
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(lambda: collections.Counter())
     dur = collections.defaultdict(list)
+    # a kernel launched with several grid sizes in one leg (the bench's whole-MEX extras run the cost stage on 1, 8 and
+    # 512 frames) gets one row per grid size: a mean over dispatches of different sizes says nothing
+    def grid_of(r):
+        if r.get("Grid_Size"): return int(r["Grid_Size"])
+        if r.get("Grid_Size_X"): return int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y") or 1) * int(r.get("Grid_Size_Z") or 1)
+        return 0
+    def base_of(r): return r["Kernel_Name"].split("(")[0].replace("void ", "").replace("fsgm::", "")[:64]
+    rows_c, rows_t, sizes = [], [], collections.defaultdict(set)
     for d in (f"{leg}_1", f"{leg}_2"):
         for f in glob.glob(f"gpurun_out/pmc_sq/{d}/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("fsgm::", "")[:64]
-                acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+                rows_c.append(r); sizes[base_of(r)].add(grid_of(r))
         for f in glob.glob(f"gpurun_out/pmc_sq/{d}/**/*kernel_trace.csv", recursive=True):
-            for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("fsgm::", "")[:64]
-                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            rows_t.extend(csv.DictReader(open(f)))
+    def key_of(r):
+        b = base_of(r)
+        return f"{b} [{grid_of(r) // 64} waves]" if len(sizes[b]) > 1 else b
+    for r in rows_c:
+        k = key_of(r)
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+    for r in rows_t:
+        dur[key_of(r)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     ks = [k for k in sorted(acc) if any(s in k for s in keep) and acc[k].get("SQ_WAVES")]
     if not ks:
         continue
