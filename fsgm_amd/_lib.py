@@ -80,6 +80,8 @@ def load():
     lib.fsgm_epi_plan_stream.restype = vp
     lib.fsgm_epi_plan_kernel_name.argtypes = [vp]
     lib.fsgm_epi_plan_kernel_name.restype = C.c_char_p
+    lib.fsgm_epi_auto_pipeline.argtypes = [i32] * 9
+    lib.fsgm_epi_auto_pipeline.restype = C.c_char_p
     lib.fsgm_measure_copy_bandwidth.argtypes = [i32, C.c_size_t, i32, C.POINTER(C.c_double)]
     lib.fsgm_measure_copy_bandwidth2.argtypes = [i32, C.c_size_t, i32, i32, C.POINTER(C.c_double)]
     _lib = lib

@@ -5,6 +5,7 @@
 #include "geometry_kernels.h"
 #include "pyramid_kernels.h"
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -78,8 +79,23 @@ struct fsgm_epi_plan {
 // batch sizes at which auto mode moves from the line kernels to the parallel sweeps and on to the full sweep pipeline
 // (8 paths; measured at 1242x375x128); FSGM_EPI_PAR_MIN / FSGM_EPI_PAR_MAX override them
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
-static int par_min_batch() { static const int v = env_int("FSGM_EPI_PAR_MIN", 4); return v; }
-static int par_max_batch() { static const int v = env_int("FSGM_EPI_PAR_MAX", 18); return v; }
+// The switch points were measured at 1242x375x128.  A fused pipeline's fixed latency goes with a linear dimension of the
+// frame and the line kernels' time per frame with its voxels, so the batch at which the two cross goes with
+// voxels^(-2/3): 320x240x64 (BASELINE configs[1], 1/12 of the voxels) measured ~26 / ~80 / ~48 frames for the three switches
+// against 4 / 18 / 9 at the KITTI shape (profiles/r03_crossover_320x240x64.txt); the scaled values are 21 / 95 / 47.
+// An environment override is taken as it stands.  FSGM_EPI_SHAPE_SCALE=0: the KITTI values for every shape.
+static int scaled_batch(int W, int H, int D, int at_kitti) {
+    static const int on = env_int("FSGM_EPI_SHAPE_SCALE", 1);
+    if (!on) return at_kitti;
+    const double s = std::pow(1242.0 * 375.0 * 128.0 / ((double)W * H * D), 2.0 / 3.0);
+    return std::max(1, (int)std::lround(at_kitti * s));
+}
+static int switch_batch(const char* env_name, int W, int H, int D, int at_kitti) {
+    const int e = env_int(env_name, -1);
+    return e >= 0 ? e : scaled_batch(W, H, D, at_kitti);
+}
+static int par_min_batch(int W, int H, int D) { return switch_batch("FSGM_EPI_PAR_MIN", W, H, D, 4); }
+static int par_max_batch(int W, int H, int D) { return switch_batch("FSGM_EPI_PAR_MAX", W, H, D, 18); }
 // Band sweeps (all four paths of a pass in one sweep, one workgroup per frame, two workgroups per CU) in auto mode: a launch
 // takes as long as its slowest CU -- measured at 1242x375x128, 8 paths, 256 CUs: 25.2 ms with one workgroup per CU (up to
 // 256 frames), 42.8 ms with two (up to 512) -- while the block sweeps take 0.107 ms per frame whatever the count.  In units of
@@ -92,56 +108,85 @@ static int band_min_batch() { static const int v = env_int("FSGM_EPI_BAND_MIN", 
 // (profiles/r03_band_chain.txt: 96 .. 512 frames) = 0.26 x CUs + 0.71 per frame in the same units (4 paths: 0.23 x CUs + 0.68);
 // it takes the batches between the sequential form's rounds (257 .. ~470 frames, 513 .. ~700, ...).
 // Returns 0: neither pays, 1: sequential band sweeps, 2: chained.
-static int band_choice(int batch, int cus, int paths) {
+// Other shapes: a band workgroup walks nbands x (W + skew x R) steps of R rows for H x W pixels (skew 2 with the diagonals,
+// 1 without), the block sweeps' time goes with H x W: the costs above are scaled by that ratio relative to the KITTI shape
+// (6 bands of 64 rows, 1242 columns).  320x240x64: a round measured 1.18 x 2 CUs (8 paths) and 0.90 x 2 CUs (4 paths) against
+// 0.785 / 0.63 at the KITTI shape; the ratio gives 1.33 / 0.88 -- the band sweeps never pay there at 8 paths, from 512 frames at 4.
+static double band_shape_cost(int W, int H, int D, int paths) {
+    const int skew = paths == 8 ? 2 : 1;
+    auto eff = [&](double w, double h, int R) { const int nb = ((int)h + R - 1) / R; return (h / (nb * R)) * (w / (w + skew * R)); };
+    return eff(1242.0, 375.0, 64) / eff((double)W, (double)H, band_rows(D));
+}
+static int band_choice(int batch, int cus, int paths, int W, int H, int D) {
     if (band_min_batch() <= 0 || batch < band_min_batch()) return 0;
-    const double half = paths == 8 ? 0.92 : 0.74, whole = paths == 8 ? 0.785 : 0.63;
+    const double g = band_shape_cost(W, H, D, paths);
+    const double half = g * (paths == 8 ? 0.92 : 0.74), whole = g * (paths == 8 ? 0.785 : 0.63);
     const int slots = 2 * cus, full = batch / slots, tail = batch % slots;
     const double seq = full * whole * slots + (tail == 0 ? 0.0 : (tail <= cus ? half * cus : whole * slots));
     static const int chain_ok = env_int("FSGM_EPI_BAND_CHAIN", 1);                      // 0: auto mode never takes the chained form
-    const double chain = chain_ok ? (paths == 8 ? 0.26 : 0.23) * cus + (paths == 8 ? 0.71 : 0.68) * batch : 1e30;
+    const double chain = chain_ok ? g * ((paths == 8 ? 0.26 : 0.23) * cus + (paths == 8 ? 0.71 : 0.68) * batch) : 1e30;
     if (std::min(seq, chain) >= (double)batch) return 0;
     return seq <= chain ? 1 : 2;
 }
-static int pairs_min_batch() { static const int v = env_int("FSGM_EPI_PAIRS_MIN", 9); return v; }   // 4 paths: line kernels -> pair pipeline
+static int pairs_min_batch(int W, int H, int D) { return switch_batch("FSGM_EPI_PAIRS_MIN", W, H, D, 9); }   // 4 paths: line kernels -> pair pipeline
 
-static void select_kernel(fsgm_epi_plan* p) {
-    p->epoch++;
-    p->packed = agg_packed_lpp(p->D) != 0;
-    if (!p->packed) { p->kernel_kind = AGG_GENERIC; return; }
-    const int cm = *std::max_element(p->cmax.begin(), p->cmax.end());
-    const bool nowrap = p->P1 >= 0 && p->P2 >= 0 && cm + p->P2 + std::max(p->P1, p->P2) <= 255;
-    p->kernel_kind = nowrap ? AGG_PACKED_NOWRAP : AGG_PACKED_WRAP;
+// What runs for a plan of this shape, batch and parameter set (cm: the largest cost in the volumes): a function of its
+// arguments and the FSGM_EPI_* environment only, so that fsgm_epi_auto_pipeline can answer without a plan.
+struct PipelineChoice { int kind; bool sweep_par, band_chain; };
+static PipelineChoice choose_pipeline(int W, int H, int D, int batch, int paths, int P1, int P2, int cm, int agg_mode, int cus) {
+    PipelineChoice c = {AGG_GENERIC, false, false};
+    if (agg_packed_lpp(D) == 0) return c;
+    const bool nowrap = P1 >= 0 && P2 >= 0 && cm + P2 + std::max(P1, P2) <= 255;
+    c.kind = nowrap ? AGG_PACKED_NOWRAP : AGG_PACKED_WRAP;
     // the fused sweeps cover the 8-path no-wrap case; everything else stays on the line kernels
-    // (3*P2 <= 255: the excess sum of three paths fits a byte)
     // Auto mode takes the fused pipelines only for batches: their latency (H rows in sequence for a sweep, down then
     // up; three passes along 1242-pixel rows for a pair) is 1.0 / 2.0 ms (4 / 8 paths) whatever the frame count,
     // while the line kernels scale with it.  Measured at 1242x375x128 (ms per batch, line vs fused):
     // 8 paths 8 frames 1.96 / 2.20, 12 frames 2.89 / 2.29; 4 paths 8 frames 1.18 / 1.19, 12 frames 1.67 / 1.28.
-    const int min_batch = p->prm.paths == 8 ? par_min_batch() : pairs_min_batch();
-    const bool want = p->agg_mode == 2 || p->agg_mode == 3 || (p->agg_mode == 0 && p->batch >= min_batch);
+    const int min_batch = paths == 8 ? par_min_batch(W, H, D) : pairs_min_batch(W, H, D);
+    const bool want = agg_mode == 2 || agg_mode == 3 || (agg_mode == 0 && batch >= min_batch);
     // (P1 <= P2: the fused kernels' form of the step clamps path states at P2 first, epi_sweep.hip)
-    const bool fusable = nowrap && p->P1 <= p->P2;
-    p->sweep_par = false;
+    const bool fusable = nowrap && P1 <= P2;
     // (the Y volumes hold y + P1 per path since round 3 -- step_b, epi_step.h -- so three / two of them must fit a byte with the bias)
-    if (fusable && 3 * (p->P1 + p->P2) <= 255 && p->prm.paths == 8 && want) {
-        p->kernel_kind = AGG_SWEEP;
+    if (fusable && 3 * (P1 + P2) <= 255 && paths == 8 && want) {
+        c.kind = AGG_SWEEP;
         // Between the line kernels and the full pipeline: the down and the up sweep side by side (H rows in sequence
         // instead of 2 H) with Y_up written out and a WTA kernel over C, Y_dn, Y_up, Y_h: 3 B per voxel more traffic,
         // half the latency.  Mode 3 forces it; auto takes it while the batch is too small to hide the longer chain.
-        p->sweep_par = p->agg_mode == 3 || (p->agg_mode == 0 && p->batch < par_max_batch());
+        c.sweep_par = agg_mode == 3 || (agg_mode == 0 && batch < par_max_batch(W, H, D));
     }
-    // the shipped 4-path configuration: both axes as pair kernels, the vertical one final (2*P2 <= 255:
-    // the excess sum of a pair fits a byte)
-    if (fusable && 2 * (p->P1 + p->P2) <= 255 && p->prm.paths == 4 && want) p->kernel_kind = AGG_PAIRS;
-    // very large batches (or mode 4): the band sweeps
-    p->band_chain = false;
-    if (fusable && band_ok(p->D, p->prm.paths, p->P1, p->P2, cm) &&
-        (p->agg_mode == 4 || p->agg_mode == 5 || (p->agg_mode == 0 && band_choice(p->batch, p->cus, p->prm.paths) != 0))) {
-        p->kernel_kind = AGG_BAND;
-        p->sweep_par = false;
+    // the shipped 4-path configuration: both axes as pair kernels, the vertical one final
+    if (fusable && 2 * (P1 + P2) <= 255 && paths == 4 && want) c.kind = AGG_PAIRS;
+    // very large batches (or mode 4 / 5): the band sweeps
+    const int band = agg_mode == 0 ? band_choice(batch, cus, paths, W, H, D) : 0;
+    if (fusable && band_ok(D, paths, P1, P2, cm) && (agg_mode == 4 || agg_mode == 5 || band != 0)) {
+        c.kind = AGG_BAND;
+        c.sweep_par = false;
         // mode 5 / auto between the sequential form's rounds: the bands of a frame as workgroups of their own (chained)
-        p->band_chain = p->agg_mode == 5 || (p->agg_mode == 0 && band_choice(p->batch, p->cus, p->prm.paths) == 2);
+        c.band_chain = agg_mode == 5 || band == 2;
     }
+    return c;
+}
+
+static const char* pipeline_name(int kind, bool sweep_par, bool band_chain) {
+    switch (kind) {
+        case AGG_PACKED_NOWRAP: return "packed16/nowrap";
+        case AGG_PACKED_WRAP: return "packed16/wrap";
+        case AGG_SWEEP: return sweep_par ? "sweep16par/nowrap" : "sweep16/nowrap";
+        case AGG_PAIRS: return "pairs16/nowrap";
+        case AGG_BAND: return band_chain ? "band16chain/nowrap" : "band16/nowrap";
+        default: return "generic";
+    }
+}
+
+static void select_kernel(fsgm_epi_plan* p) {
+    p->epoch++;
+    p->packed = agg_packed_lpp(p->D) != 0;
+    const int cm = *std::max_element(p->cmax.begin(), p->cmax.end());
+    const PipelineChoice c = choose_pipeline(p->W, p->H, p->D, p->batch, p->prm.paths, p->P1, p->P2, cm, p->agg_mode, p->cus);
+    p->kernel_kind = c.kind;
+    p->sweep_par = c.sweep_par;
+    p->band_chain = c.band_chain;
 }
 
 // Lazily allocated buffer sets of the two fused pipelines.  Everything is created into locals and committed to
@@ -949,14 +994,14 @@ void* fsgm_epi_plan_stream(fsgm_epi_plan* p) { return p ? (void*)p->stream : nul
 
 const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* p) {
     if (!p) return "";
-    switch (p->kernel_kind) {
-        case AGG_PACKED_NOWRAP: return "packed16/nowrap";
-        case AGG_PACKED_WRAP: return "packed16/wrap";
-        case AGG_SWEEP: return p->sweep_par ? "sweep16par/nowrap" : "sweep16/nowrap";
-        case AGG_PAIRS: return "pairs16/nowrap";
-        case AGG_BAND: return p->band_chain ? "band16chain/nowrap" : "band16/nowrap";
-        default: return "generic";
-    }
+    return pipeline_name(p->kernel_kind, p->sweep_par, p->band_chain);
+}
+
+const char* fsgm_epi_auto_pipeline(int32_t width, int32_t height, int32_t dMax, int32_t batch, int32_t paths, int32_t P1, int32_t P2,
+                                   int32_t cmax, int32_t cus) {
+    if (width <= 0 || height <= 0 || dMax <= 0 || batch <= 0 || (paths != 4 && paths != 8) || cus <= 0) return "";
+    const PipelineChoice c = choose_pipeline(width, height, dMax, batch, paths, P1, P2, cmax, 0, cus);
+    return pipeline_name(c.kind, c.sweep_par, c.band_chain);
 }
 
 // The achievable HBM rate of this device, measured the way the aggregation kernels move bytes: a grid-stride

@@ -32,6 +32,12 @@ def _params(paths, subpixel, vz_to_disp, device, fb_check=0):
     return p
 
 
+def auto_pipeline(width, height, dMax, batch, paths=4, P1=6, P2=64, cmax=24, cus=256):
+    """Which aggregation pipeline auto mode takes for `batch` frames of this shape (fsgm_epi_auto_pipeline): a pure function of
+    its arguments and the FSGM_EPI_* environment, no device needed."""
+    return _lib.load().fsgm_epi_auto_pipeline(int(width), int(height), int(dMax), int(batch), int(paths), int(P1), int(P2), int(cmax), int(cus)).decode()
+
+
 def calc_cost_sgm_batch(frames, dMax, vMax, P1, P2, *, paths=4, subpixel=1, vz_to_disp=1, device=0,
                         return_volumes=False, fb_check=0):
     """frames: list of (I1, I2, pixelPosD0, normDir, offset) of one shape, processed concurrently."""

@@ -147,10 +147,18 @@ fsgm_status fsgm_epi_plan_time(fsgm_epi_plan* plan, int32_t stages, int32_t warm
                                int32_t iters, float* ms_avg);
 /* the hipStream_t the plan launches on */
 void*       fsgm_epi_plan_stream(fsgm_epi_plan* plan);
-/* which aggregation kernel the plan selected: "sweep16/nowrap" (8 paths, full sweep pipeline), "sweep16par/nowrap" (8 paths,
- * parallel sweeps: auto mode for 5..17 frames), "pairs16/nowrap" (4 paths, pair pipeline), "packed16/nowrap", "packed16/wrap"
- * (per-direction line kernels), "generic" (any dMax).  New names may be added: dispatch on these with a default branch. */
+/* which aggregation kernel the plan selected: "band16/nowrap" (band sweeps, one workgroup per frame: hundreds of frames),
+ * "band16chain/nowrap" (band sweeps, the bands of a frame as workgroups of their own), "sweep16/nowrap" (8 paths, block sweep
+ * pipeline), "sweep16par/nowrap" (8 paths, parallel sweeps: auto mode for 4..17 frames), "pairs16/nowrap" (4 paths, pair
+ * pipeline), "packed16/nowrap", "packed16/wrap" (per-direction line kernels), "generic" (any dMax).  New names may be added:
+ * dispatch on these with a default branch. */
 const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* plan);
+/* The same answer without a plan: what auto mode takes for `batch` frames of width x height x dMax with these penalties, costs
+ * up to cmax (24 for volumes built by the cost stage) and a device of `cus` compute units (MI355X: 256).  The switch points
+ * were measured at 1242x375x128 and move with the frame's voxels^(-2/3) (smaller frames stay on the line kernels for longer);
+ * FSGM_EPI_PAR_MIN / _PAR_MAX / _PAIRS_MIN / _BAND_MIN in the environment override them.  "" for invalid arguments. */
+const char* fsgm_epi_auto_pipeline(int32_t width, int32_t height, int32_t dMax, int32_t batch, int32_t paths, int32_t P1, int32_t P2,
+                                   int32_t cmax, int32_t cus);
 /* device-to-device copy bandwidth probe (GB/s, read+written bytes counted) used by bench.py: the library's own
  * grid-stride copy kernel, 16 B per lane per access -- the access width of the aggregation kernels */
 fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t iters, double* gbps);

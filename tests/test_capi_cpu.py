@@ -95,3 +95,26 @@ def test_window_mean_rounding_identity_of_the_rows_cost_kernel():
         got = ((2 * s + win) * inv) >> 20
         np.testing.assert_array_equal(got, want)
         assert ((2 * s + win) * inv).max() < 2 ** 32
+
+
+def test_auto_mode_table():
+    """fsgm_epi_auto_pipeline (a pure function: no device).  KITTI shape, 8 paths, no-wrap penalties: line kernels below 4 frames,
+    parallel sweeps below 18, the block sweep pipeline from there, the band sweeps where a round of them pays (230..256 frames,
+    473..512), the chained form between the rounds; 4 paths: line kernels below 9 frames, then the pair kernels, then bands.
+    Smaller frames: the switch points move with voxels^(-2/3) -- measured at 320x240x64 (profiles/r03_crossover_320x240x64.txt):
+    line kernels fastest up to ~26 frames at 8 paths and ~48 at 4, block sweeps from ~80, band sweeps at 4 paths / 512 frames only."""
+    from fsgm_amd import auto_pipeline
+    kitti = [(8, 1, "packed16/nowrap"), (8, 3, "packed16/nowrap"), (8, 4, "sweep16par/nowrap"), (8, 17, "sweep16par/nowrap"), (8, 18, "sweep16/nowrap"),
+             (8, 200, "sweep16/nowrap"), (8, 256, "band16/nowrap"), (8, 300, "band16chain/nowrap"), (8, 512, "band16/nowrap"),
+             (4, 8, "packed16/nowrap"), (4, 9, "pairs16/nowrap"), (4, 128, "pairs16/nowrap"), (4, 512, "band16/nowrap")]
+    for paths, B, name in kitti:
+        assert auto_pipeline(1242, 375, 128, B, paths, 6, 64) == name, (paths, B)
+    small = [(8, 16, "packed16/nowrap"), (8, 40, "sweep16par/nowrap"), (8, 128, "sweep16/nowrap"), (8, 512, "sweep16/nowrap"),
+             (4, 40, "packed16/nowrap"), (4, 128, "pairs16/nowrap"), (4, 512, "band16/nowrap")]
+    for paths, B, name in small:
+        assert auto_pipeline(320, 240, 64, B, paths, 6, 64) == name, (paths, B)
+    assert auto_pipeline(32, 16, 64, 200, 8, 6, 64) == "packed16/nowrap"          # tiny frames: nothing to fuse for
+    assert auto_pipeline(1242, 375, 128, 512, 8, 100, 200) == "packed16/wrap"      # wrapping penalties: the exact u8 line kernels
+    assert auto_pipeline(1242, 375, 128, 512, 8, 64, 6) == "packed16/nowrap"       # P1 > P2: not a fused pipeline's case
+    assert auto_pipeline(1242, 375, 100, 512, 8, 6, 64) == "generic"               # dMax not a multiple of 16
+    assert auto_pipeline(0, 375, 128, 1, 8, 6, 64) == ""

@@ -247,7 +247,9 @@ def test_cost_volume_kitti_shape_general_field(gpu_lib, oracle):
         np.testing.assert_array_equal(plan.download_cost(0), want)
 
 
-@pytest.mark.parametrize("paths,n", [(8, 18), (4, 9), (8, 5), (8, 3)])  # auto mode, 8 paths: line kernels / parallel sweeps from 4 frames / full sweeps from 18; 4 paths: pairs from 9
+# (auto mode: frames this small stay on the line kernels at every batch size -- the fused pipelines through the batch host call
+#  are covered at the KITTI shape, tests/test_gpu_configs_full_size.py)
+@pytest.mark.parametrize("paths,n", [(8, 18), (4, 9), (8, 5), (8, 3)])
 def test_batch_matches_single_frames(gpu_lib, oracle, paths, n):
     W, H, D = 96, 64, 64
     frames = []
@@ -444,15 +446,15 @@ def test_parallel_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, subpixel)
 
 
 def test_auto_mode_by_batch_size(gpu_lib):
-    """8 paths, no-wrap penalties: line kernels below 4 frames, parallel sweeps below 18, the full sweep pipeline from there,
-    the band sweeps from 230 frames -- one workgroup per frame where a round of those pays (238..256 frames, 473..512), the
-    chained form (one workgroup per band and frame) between the rounds; 4 paths: line kernels below 9 frames, then the pair kernels, then bands."""
-    for paths, B, name in [(8, 3, "packed16/nowrap"), (8, 4, "sweep16par/nowrap"), (8, 17, "sweep16par/nowrap"), (8, 18, "sweep16/nowrap"),
-                           (8, 200, "sweep16/nowrap"), (8, 256, "band16/nowrap"), (8, 300, "band16chain/nowrap"), (8, 512, "band16/nowrap"),
-                           (4, 8, "packed16/nowrap"), (4, 9, "pairs16/nowrap"), (4, 512, "band16/nowrap")]:
-        with EpiPlan(32, 16, 64, B, paths=paths) as plan:
+    """A plan in auto mode runs what fsgm_epi_auto_pipeline says (the table itself: tests/test_capi_cpu.py); small frames stay
+    on the line kernels far beyond the KITTI shape's switch points; wrapping penalties always take the line kernels."""
+    from fsgm_amd import auto_pipeline
+    for (W, H, D), paths, B in [((32, 16, 64), 8, 3), ((32, 16, 64), 8, 40), ((32, 16, 64), 4, 9), ((320, 240, 64), 8, 24), ((320, 240, 64), 4, 48)]:
+        with EpiPlan(W, H, D, B, paths=paths) as plan:
             plan.set_penalties(6, 64, 0.3)
-            assert plan.kernel_name == name, (paths, B)
+            assert plan.kernel_name == auto_pipeline(W, H, D, B, paths, 6, 64), (W, H, D, paths, B)
+            if W == 32:
+                assert plan.kernel_name == "packed16/nowrap"
             plan.set_penalties(100, 200, 0.3)
             assert plan.kernel_name == "packed16/wrap"
 

@@ -2,7 +2,8 @@ import os, sys; sys.path.insert(0, '.')
 import numpy as np, fsgm_amd
 from fsgm_amd import synth, EpiPlan
 from fsgm_amd._lib import STAGE_AGGREGATE, STAGE_WTA
-W, H, D = 1242, 375, 128
+# usage: crossover.py [batches] [WxHxD]   (default: the KITTI shape; BASELINE configs[1] is 320x240x64)
+W, H, D = (int(v) for v in sys.argv[2].split("x")) if len(sys.argv) > 2 else (1242, 375, 128)
 _, _, off = synth.epi_maps(W, H, "axis")
 base = synth.cost_volume(W, H, D, seed=1, cmax=24)
 Bs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8, 12, 16, 24, 40]
@@ -20,4 +21,4 @@ for paths in (8, 4):
                 plan.set_agg_mode(mode)
                 r.append((plan.kernel_name + ("+strips" if strips == "1" else ""), plan.time(STAGE_AGGREGATE | STAGE_WTA, 2, 6)))
             plan.close()
-        print(f"paths {paths} B {B}: " + "  ".join(f"{n} {ms:.3f}" for n, ms in r), flush=True)
+        print(f"{W}x{H}x{D} paths {paths} B {B}: " + "  ".join(f"{n} {ms:.3f}" for n, ms in r), flush=True)
