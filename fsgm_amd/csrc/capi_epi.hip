@@ -54,7 +54,7 @@ struct fsgm_epi_plan {
     // epipolar driver (fsgm_epipolar_sgm_of_host): rotation flow, composed flow, RGB staging
     double *dRflow = nullptr, *dFlow = nullptr;
     uint8_t* dRgb = nullptr;
-    uint4* dRec = nullptr;
+    uint2* dRec = nullptr;
     uint16_t* dS0 = nullptr;
     size_t state_stride = 0;
     hipStream_t stream_h = nullptr, stream_b = nullptr, stream_c = nullptr;
@@ -472,12 +472,12 @@ static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
     if (p->dCkptV && p->dLh && p->dCkpt && p->dRec && p->dS0 && p->stream_h) return FSGM_OK;
     const size_t B = p->batch;
     LazySet ls;
-    uint8_t *lh = p->dLh, *ck = p->dCkpt, *ckv = p->dCkptV; uint4* rec = p->dRec; uint16_t* s0 = p->dS0;
+    uint8_t *lh = p->dLh, *ck = p->dCkpt, *ckv = p->dCkptV; uint2* rec = p->dRec; uint16_t* s0 = p->dS0;
     hipStream_t sh = p->stream_h; hipEvent_t ef = p->ev_fork, eh = p->ev_h;
     if (!lh) ls.alloc(&lh, B * p->N);
     if (!ck) ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
     if (!ckv) ls.alloc(&ckv, B * pair_ckpt_bytes(p->W, p->H, p->D, 1));
-    if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint4));
+    if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint2));
     if (!s0) ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
     if (!sh) ls.stream(&sh);
     if (!ef) ls.event(&ef);
@@ -493,12 +493,12 @@ static fsgm_status ensure_sweep_buffers(fsgm_epi_plan* p) {
     const size_t B = p->batch;
     const size_t state_stride = sweep_state_bytes(p->W, p->D);
     LazySet ls;
-    uint8_t *lh = p->dLh, *ck = p->dCkpt, *state = nullptr, *x = p->dX; uint4* rec = p->dRec; uint16_t* s0 = p->dS0;
+    uint8_t *lh = p->dLh, *ck = p->dCkpt, *state = nullptr, *x = p->dX; uint2* rec = p->dRec; uint16_t* s0 = p->dS0;
     hipStream_t sh = p->stream_h, sb = p->stream_b, sc = p->stream_c;
     hipEvent_t ef = p->ev_fork, eh = p->ev_h, eb = p->ev_b, ec = p->ev_c, ehl[3] = {p->ev_hl[0], p->ev_hl[1], p->ev_hl[2]};
     if (!lh) ls.alloc(&lh, B * p->N);
     if (!ck) ls.alloc(&ck, B * pair_ckpt_bytes(p->W, p->H, p->D, 0));
-    if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint4));
+    if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint2));
     if (!s0) ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
     if (!x) ls.alloc(&x, B * p->N);
     if (!sh) ls.stream(&sh);
@@ -528,11 +528,11 @@ static fsgm_status ensure_band_buffers(fsgm_epi_plan* p) {
     if (p->dBandEdge && p->band_edge_maps >= maps && p->dX && p->dRec && p->dS0 && (!p->band_chain || p->dBandTicket)) return FSGM_OK;
     const size_t B = p->batch;
     LazySet ls;
-    uint8_t* x = p->dX; uint4 *rec = p->dRec, *edge = p->dBandEdge; uint16_t* s0 = p->dS0; uint32_t *bits = p->dBits, *ticket = p->dBandTicket, *err = p->dBandErr;
+    uint8_t* x = p->dX; uint2* rec = p->dRec; uint4* edge = p->dBandEdge; uint16_t* s0 = p->dS0; uint32_t *bits = p->dBits, *ticket = p->dBandTicket, *err = p->dBandErr;
     const bool new_edge = !edge || p->band_edge_maps < maps;
     const size_t edge_bytes = B * maps * band_edge_uint4s(p->W, p->D, 8) * sizeof(uint4);
     if (!x) ls.alloc(&x, B * p->N);
-    if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint4));
+    if (!rec) ls.alloc(&rec, B * p->NP * sizeof(uint2));
     if (!s0) ls.alloc(&s0, B * p->NP * sizeof(uint16_t));
     if (new_edge) ls.alloc(&edge, edge_bytes);
     if (!bits && p->prm.paths == 8) ls.alloc(&bits, B * band_bits_u32s(p->W, p->H, p->D) * sizeof(uint32_t));

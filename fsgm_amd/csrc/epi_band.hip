@@ -14,7 +14,7 @@
 //
 //   down pass (MODE 0)   C -> Y_dn (+ bit plane), the four pass-0 paths
 //   final pass (MODE 2)  on the point-mirrored frame (pass 1, :114-123): its own four paths, then in registers
-//                        S = 8*(C + P2) - (Y_up + Y_dn) and the WTA; one 18-byte record per pixel (sweep_finish_kernel
+//                        S = 8*(C + P2) - (Y_up + Y_dn) and the WTA; one 10-byte record per pixel (sweep_finish_kernel
 //                        does the parabola / vz conversion as for the block sweeps)
 //   5.3 B per voxel through HBM (PMC counters, profiles/r03_pmc_traffic.json) instead of 9.7, ~650 wave-instructions per
 //   8 pixels instead of ~880.

@@ -53,7 +53,7 @@ struct SweepArgs {
     size_t x_frame_stride;
     const uint8_t* Lh;        // mode 2: [frames] the horizontal pair's sum Y_h (pair kernels)
     size_t lh_frame_stride;
-    uint4* rec;               // mode 2: [frames][NP] {best, minC, S[best-1], S[best+1]}
+    uint2* rec;               // mode 2: [frames][NP] {best | minC << 16, S[best-1] | S[best+1] << 16} (sums of u8 path costs: 16 bits)
     uint16_t* s0;             // mode 2: [frames][NP] S[0] of every pixel
     const uint8_t* state_in;  // [frames][3][W][D] normalised path states of the row above this block
     uint8_t* state_out;       // same, written for the next block
@@ -73,7 +73,7 @@ struct BandArgs {
     size_t yb_frame_stride;   // in dwords
     uint4* edge;              // [frames][W][states][LPP] path states of a band's last row for the band below (3 states at 8 paths, 1 at 4)
     size_t edge_frame_stride; // in uint4
-    uint4* rec;               // mode 2: [frames][NP] {best, minC, S[best-1], S[best+1]}
+    uint2* rec;               // mode 2: [frames][NP] {best | minC << 16, S[best-1] | S[best+1] << 16} (sums of u8 path costs: 16 bits)
     uint16_t* s0;             // mode 2: [frames][NP] S[0] of every pixel
     uint32_t* Sdbg;           // mode 2, optional: natural-order u32 dump of S [frames][NP][D] (debug tap)
     // chained form: one workgroup per (band, frame), the bands of a frame handing over while they run
@@ -108,7 +108,7 @@ struct PairArgs {              // an opposite pair of paths as one excess sum (e
     size_t ckpt_frame_stride;
     const uint8_t* Xother;    // final pass: [frames] the other axis' sum
     size_t xo_frame_stride;
-    uint4* rec;               // final pass: [frames][NP] {best, minC, S[best-1], S[best+1]}
+    uint2* rec;               // final pass: [frames][NP] {best | minC << 16, S[best-1] | S[best+1] << 16}
     uint16_t* s0;             // final pass: [frames][NP] S[0] of every pixel
     int nC;                   // final pass: S = nC * (C + P2) - (Y + Yother)
     int prio;                 // s_setprio level of the pair kernels' waves (0-3)
@@ -149,7 +149,7 @@ size_t band_bits_u32s(int W, int H, int D);                 // bit plane of one 
 bool   band_needs_bits(int paths, int P1, int P2);
 bool   band_ok(int D, int paths, int P1, int P2, int cmax);
 void launch_band(hipStream_t st, const BandArgs& a, int frames, int paths, int mode);   // 0 first pass, 2 second pass + WTA records
-void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames);
+void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint2* rec, const uint16_t* s0, int frames);
 void launch_wta_sweep(hipStream_t st, const WtaArgs& a, const SweepSumArgs& q, int frames);
 void launch_fb_check(hipStream_t st, const FbArgs& a, int frames);
 void launch_vz_convert(hipStream_t st, uint32_t* bestD, const double* off, int W, int H, int D, double vMax, int frames);

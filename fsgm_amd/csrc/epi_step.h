@@ -226,14 +226,14 @@ __device__ __forceinline__ void wta_row_record_at(const uint32_t (&ST)[8], uint3
         const uint16_t* srow = (const uint16_t*)sRow;
         const uint32_t c_1 = best > 0 ? srow[srow_index<NT>(tid, best - 1)] : 0u;
         const uint32_t c1 = best + 1 < (uint32_t)D ? srow[srow_index<NT>(tid, best + 1)] : 0u;   // best == D-1: the finish kernel takes the next pixel's S[0]
-        *(uint4*)(recb + pix * 16u) = make_uint4(best, minc, c_1, c1);
+        *(uint2*)(recb + pix * 8u) = make_uint2(best | (minc << 16), c_1 | (c1 << 16));   // (every field below 2^16: sums of <= 16 u8 path costs)
         *(uint16_t*)(s0b + pix * 2u) = (uint16_t)ST[0];        // S[0]: register 0, low half of the pixel's first lane (this one)
     }
 }
 
 template <int LPP, int NT>
 __device__ __forceinline__ void wta_row_record(const uint32_t (&ST)[8], uint32_t* sRow, int tid, int j,
-                                               bool ok, uint4* rec, uint16_t* s0, size_t idx) {
+                                               bool ok, uint2* rec, uint16_t* s0, size_t idx) {
     wta_row_record_at<LPP, NT>(ST, sRow, tid, j, ok, (uint8_t*)(rec + idx), (uint8_t*)(s0 + idx), 0u);
 }
 

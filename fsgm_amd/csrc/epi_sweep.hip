@@ -10,7 +10,7 @@
 //   pair kernels (AXIS 0)   C -> Y_h, the two horizontal paths (checkpoint-and-recompute, see the pair section)
 //   down sweep   (MODE 0)   C -> Y_dn, the three pass-0 paths from above
 //   final sweep  (MODE 2)   on the point-mirrored frame (pass 1): its own three paths, then in registers
-//                           S = 8*(C + P2) - (Y_up + Y_dn + Y_h) and the WTA; writes one 18-byte record per PIXEL
+//                           S = 8*(C + P2) - (Y_up + Y_dn + Y_h) and the WTA; writes one 10-byte record per PIXEL
 //   sweep_finish_kernel     parabola / vz->disparity from the records -> bestD, minC
 //
 // THE STEP (calc_cost_sgm.cpp:33-66) in the form the kernels compute it.  With L' = L_prev - m_prev the previous
@@ -352,16 +352,17 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
 // finish kernel for MODE 2: parabola + vz->disparity from the per-pixel records
 // (calc_cost_sgm.cpp:278-308, :414-426).  best == D-1 reads the next pixel's S[0] (:296).
 // =============================================================================================
-__global__ __launch_bounds__(256) void sweep_finish_kernel(WtaArgs a, const uint4* __restrict__ rec,
+__global__ __launch_bounds__(256) void sweep_finish_kernel(WtaArgs a, const uint2* __restrict__ rec,
                                                            const uint16_t* __restrict__ s0) {
     const int NP = a.W * a.H;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= NP) return;
     const size_t f = blockIdx.y;
-    const uint4 r = rec[f * (size_t)NP + p];
-    uint32_t c1 = r.w;
-    if (r.x + 1 == (uint32_t)a.D) c1 = p + 1 < NP ? (uint32_t)s0[f * (size_t)NP + p + 1] : 0u;
-    wta_finish(a, f, p, r.x, r.y, r.z, c1);
+    const uint2 r = rec[f * (size_t)NP + p];
+    const uint32_t best = r.x & 0xFFFFu, minc = r.x >> 16, c_1 = r.y & 0xFFFFu;
+    uint32_t c1 = r.y >> 16;
+    if (best + 1 == (uint32_t)a.D) c1 = p + 1 < NP ? (uint32_t)s0[f * (size_t)NP + p + 1] : 0u;
+    wta_finish(a, f, p, best, minc, c_1, c1);
 }
 
 // =============================================================================================
@@ -924,7 +925,7 @@ void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode, int 
     }
 }
 
-void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint4* rec, const uint16_t* s0, int frames) {
+void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint2* rec, const uint16_t* s0, int frames) {
     hipLaunchKernelGGL(sweep_finish_kernel, dim3((a.W * a.H + 255) / 256, frames), dim3(256), 0, st, a, rec, s0);
 }
 
