@@ -1,5 +1,5 @@
 // epi_step.h -- the DP step of calc_cost_sgm.cpp:33-66 in the mirrored variable, the register / byte layouts around it and the
-// per-pixel WTA record, shared by the fused aggregation kernels (epi_sweep.hip: block sweeps, strips, pair kernels;
+// per-pixel WTA record, shared by the fused aggregation kernels (epi_sweep.hip: block sweeps, pair kernels;
 // epi_band.hip: band sweeps).  Derivation and layout: the header of epi_sweep.hip.
 #pragma once
 #include "fsgm_device.h"
@@ -170,7 +170,7 @@ __device__ __forceinline__ void step_b(uint32_t (&S)[8], const uint32_t (&CB)[8]
     for (int i = 0; i < 8; i++) S[i] = pk_subs(p2m, N[i]);
 }
 
-// hand-off words between workgroups that run at the same time (strip sweeps, chained band sweeps): written and read past
+// hand-off words between workgroups that run at the same time (the chained band sweeps): written and read past
 // the L1 and coherently across the XCDs' L2s, 8 bytes at a time; every dword carries its launch's tag in its bytes' top bits
 __device__ __forceinline__ uint4 edge_load(const uint4* p) {
     // two 8-byte agent-scope loads: served past the L1 and coherent across the XCDs' L2s
