@@ -41,6 +41,10 @@ __device__ __forceinline__ uint32_t dpp_shift0(uint32_t src) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t dup16(uint32_t v) { return v | (v << 16); }
+// a candidate row (NW dwords, 4-byte aligned) as ONE memory instruction: the lanes of a pixel then cover its bytes without gaps
+template <int N> struct alignas(4) RowDw { uint32_t v[N]; };
+template <int N> __device__ __forceinline__ RowDw<N> load_row(const void* p) { return *(const RowDw<N>*)p; }
+template <int N> __device__ __forceinline__ void store_row(void* p, const RowDw<N>& r) { *(RowDw<N>*)p = r; }
 
 // =============================================================================================
 // 2-D window cost  (calc_pyd_cost_sgm.cpp:374-437), aggregation radius <= 2.
@@ -242,9 +246,10 @@ __global__ __launch_bounds__(256) void pyd_rows_cost_kernel(PydCostArgs a) {
         out[k] = w;
     }
     if (live && p0 + slot < NP) {
-        uint32_t* dst = (uint32_t*)(a.C + (f * (size_t)NP + (size_t)(p0 + slot)) * a.PS + (size_t)j * a.RS);
+        RowDw<NW> row;
 #pragma unroll
-        for (int k = 0; k < NW; k++) dst[k] = out[k];
+        for (int k = 0; k < NW; k++) row.v[k] = out[k];
+        store_row<NW>(a.C + (f * (size_t)NP + (size_t)(p0 + slot)) * a.PS + (size_t)j * a.RS, row);
     }
 }
 
@@ -417,9 +422,9 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
     int fpix = pix, fcx = cx, ft = 0;
     auto issue = [&](Fetch& o) {
         const int p = ft < len ? fpix : pix0;
-        const uint32_t* src = (const uint32_t*)(Cf + (size_t)p * PS + rowoff);
+        const RowDw<NL> row = load_row<NL>(Cf + (size_t)p * PS + rowoff);
 #pragma unroll
-        for (int k = 0; k < NL; k++) o.c[k] = src[k];
+        for (int k = 0; k < NL; k++) o.c[k] = row.v[k];
         o.desc = Df[p];
         o.pix = p;
         ft++;
@@ -585,12 +590,13 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
             // wait for the prefetched loads is a counted s_waitcnt vmcnt(1), not a wait for the store.
             uint32_t* dl = (uint32_t*)(cur + (is_out ? sx : DUMPROW) * ROWB + ROWDATA + 4 * q);
             uint32_t* dg = (is_out && active && t < len) ? (uint32_t*)(Lf + (size_t)pix * PS + rowoff) : a.dump;
+            RowDw<NL> row;
 #pragma unroll
             for (int k = 0; k < NL; k++) {
-                const uint32_t w = LE[k] | (LO[k] << 8);
-                dl[k] = w;
-                dg[k] = w;
+                row.v[k] = LE[k] | (LO[k] << 8);
+                dl[k] = row.v[k];
             }
+            store_row<NL>(dg, row);
         }
         __builtin_amdgcn_wave_barrier();
         uint8_t* tmp = pre; pre = cur; cur = tmp;
@@ -630,9 +636,11 @@ __global__ __launch_bounds__(256) void pyd_rows_wta_kernel(PydWtaArgs a) {
     const uint8_t* __restrict__ Lp = a.L + f * a.ndirs * vol + (size_t)p * a.PS + (size_t)sxc * a.RS;
     uint32_t v[8][NW];
 #pragma unroll
-    for (int r = 0; r < 8; r++)
+    for (int r = 0; r < 8; r++) {
+        const RowDw<NW> row = load_row<NW>(Lp + (r < a.ndirs ? r : 0) * vol);      // (a direction that is not there: weight 0)
 #pragma unroll
-        for (int k = 0; k < NW; k++) v[r][k] = r < a.ndirs ? ((const uint32_t*)(Lp + r * vol))[k] : 0u;
+        for (int k = 0; k < NW; k++) v[r][k] = row.v[k];
+    }
     // Sp += L (:227-232) as byte dot products: the four bytes of a dword are four sy, so the dwords of four directions are
     // transposed (8 v_perm) into one dword per sy holding that sy of the four directions, and v_dot4_u32_u8 with the
     // directions' weights as bytes (a third pass repeats the mirrored one) adds them up: 3 instructions per loaded dword.
