@@ -273,11 +273,17 @@ __device__ __forceinline__ bool absent_centre(int c, int S) { return c <= -3 || 
 __device__ bool fit_shift(double delta, int S, int& kf, int& na) {
     int t[ROWS_MAXS];
     int jstar = -1, tstar = 0;
+    // (|delta| < 2^30: every j + delta + 0.5 lies inside the int range, where cvttsd2si is the plain truncating conversion)
+    if (fabs(delta) < 1073741824.0) {
 #pragma unroll
-    for (int j = 0; j < ROWS_MAXS; j++) {
-        t[j] = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)j, delta), 0.5));
-        if (j < S && !absent_centre(t[j], S)) { jstar = j; tstar = t[j]; }
+        for (int j = 0; j < ROWS_MAXS; j++) t[j] = (int)__dadd_rn(__dadd_rn((double)j, delta), 0.5);
+    } else {
+#pragma unroll
+        for (int j = 0; j < ROWS_MAXS; j++) t[j] = f64_to_i32_x86(__dadd_rn(__dadd_rn((double)j, delta), 0.5));
     }
+#pragma unroll
+    for (int j = 0; j < ROWS_MAXS; j++)
+        if (j < S && !absent_centre(t[j], S)) { jstar = j; tstar = t[j]; }
     if (jstar < 0) { kf = S + 3; na = 0; return true; }      // every neighbourhood lies outside the window
     kf = tstar - jstar;
     na = 0;
