@@ -68,12 +68,6 @@ struct fsgm_epi_plan {
     int cus = 256;                       // compute units of the device (band sweeps: one workgroup per frame, two per CU)
     int kernel_kind = AGG_GENERIC;
     bool packed = false;
-    // The fused-sweep stage is ~100 launches on three streams; FSGM_EPI_GRAPH=1 replays it as one HIP graph
-    // per stage mask (captured on first use; any change of kernel selection or penalties bumps the epoch
-    // and drops it).  Off by default: measured slower, see env_graph().
-    struct GraphSlot { hipGraphExec_t exec = nullptr; uint64_t epoch = 0; };
-    GraphSlot graphs[8];
-    uint64_t epoch = 1;
 };
 
 // batch sizes at which auto mode moves from the line kernels to the parallel sweeps and on to the full sweep pipeline
@@ -180,7 +174,6 @@ static const char* pipeline_name(int kind, bool sweep_par, bool band_chain) {
 }
 
 static void select_kernel(fsgm_epi_plan* p) {
-    p->epoch++;
     p->packed = agg_packed_lpp(p->D) != 0;
     const int cm = *std::max_element(p->cmax.begin(), p->cmax.end());
     const PipelineChoice c = choose_pipeline(p->W, p->H, p->D, p->batch, p->prm.paths, p->P1, p->P2, cm, p->agg_mode, p->cus);
@@ -267,8 +260,6 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    for (auto& g : p->graphs)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : {p->ev_fork, p->ev_h, p->ev_b, p->ev_c, p->ev_hl[0], p->ev_hl[1], p->ev_hl[2]})
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {p->stream, p->stream_h, p->stream_b, p->stream_c})
@@ -682,7 +673,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         b.W = p->W; b.H = p->H; b.D = p->D; b.P1 = p->P1; b.P2 = p->P2;
         b.chain = p->band_chain ? 1 : 0;
         b.frames = p->batch; b.nbands = (p->H + band_rows(p->D) - 1) / band_rows(p->D);
-        { static const int g = env_int("FSGM_BAND_GROUP", 0); b.group = g > 0 ? std::min(g, p->batch) : p->batch; }   // frames whose bands are dealt band-major (A/B knob)
+        b.group = p->batch;                                  // frames whose bands are dealt band-major: all (groups of 16-64 measured: no gain)
         b.ticket = p->dBandTicket; b.err = p->dBandErr;
         if (b.chain && p->band_edge_untagged) {              // words of the sequential form / the S tap could pass for tag 0: all ones is never a tag
             FSGM_HIP(hipMemsetAsync(p->dBandEdge, 0xFF, (size_t)p->batch * b.edge_frame_stride * sizeof(uint4), p->stream));
@@ -765,37 +756,10 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
     return FSGM_OK;
 }
 
-// FSGM_EPI_GRAPH: 0 = plain launches on three streams (default), 1 = replay the fused-sweep stage as one
-// HIP graph.  Measured on MI355X / ROCm 7.2 (32 frames, same box, alternating runs): the graph replay
-// is 9 % SLOWER (5.23 vs 4.79 ms per step) -- the runtime does not overlap the three captured branches
-// as well as the three streams do -- so it stays opt-in.
-static int env_graph() {
-    const char* e = getenv("FSGM_EPI_GRAPH");
-    return (e && *e) ? atoi(e) : 0;
-}
-
-static fsgm_status run_stages(fsgm_epi_plan* p, int stages) {
-    fsgm_status st = prepare(p, stages);                         // kernel selection and allocations: before the graph decision, outside any capture
-    if (st != FSGM_OK) return st;
-    const bool graphable = p->kernel_kind == AGG_SWEEP && !(stages & FSGM_STAGE_COST) && !p->prm.fb_check && env_graph() != 0;
-    if (!graphable) return enqueue(p, stages);
-    fsgm_epi_plan::GraphSlot& g = p->graphs[stages & 7];
-    if (!g.exec || g.epoch != p->epoch) {
-        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-        hipGraph_t graph = nullptr;
-        FSGM_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-        st = enqueue(p, stages);
-        const hipError_t e = hipStreamEndCapture(p->stream, &graph);
-        if (st != FSGM_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
-        FSGM_HIP(e);
-        const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        FSGM_HIP(ei);
-        g.epoch = p->epoch;
-    }
-    FSGM_HIP(hipGraphLaunch(g.exec, p->stream));
-    return FSGM_OK;
-}
+// (Replaying the fused-sweep stage -- ~100 launches on three streams -- as one HIP graph was measured on MI355X / ROCm 7.2, 32 frames,
+// same box, alternating runs: 9 % SLOWER, 5.23 vs 4.79 ms per step; the runtime does not overlap the three captured branches as well
+// as the three streams do.  Removed in round 3.)
+static fsgm_status run_stages(fsgm_epi_plan* p, int stages) { return enqueue(p, stages); }
 
 fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* p, int32_t stages) {
     FSGM_REQUIRE(p, "null plan");
@@ -1052,8 +1016,6 @@ static fsgm_status cached_plan(fsgm_epi_plan** out, int W, int H, int D, int bat
     for (fsgm_epi_plan* p : g_cache)
         if (p->W == W && p->H == H && p->D == D && p->batch == batch && p->prm.paths == pr.paths &&
             p->prm.device == pr.device && p->prm.fb_check == pr.fb_check) {
-            // subpixel / vz_to_disp are baked into kernel arguments: a captured graph of the old settings must go
-            if (p->prm.subpixel != pr.subpixel || p->prm.vz_to_disp != pr.vz_to_disp) p->epoch++;
             p->prm = pr;
             *out = p;
             return FSGM_OK;

@@ -111,7 +111,6 @@ struct PairArgs {              // an opposite pair of paths as one excess sum (e
     uint2* rec;               // final pass: [frames][NP] {best | minC << 16, S[best-1] | S[best+1] << 16}
     uint16_t* s0;             // final pass: [frames][NP] S[0] of every pixel
     int nC;                   // final pass: S = nC * (C + P2) - (Y + Yother)
-    int prio;                 // s_setprio level of the pair kernels' waves (0-3)
     int xo_natural;           // final pass: Xother is in natural d order (written by the pairx_* kernels), not the private one
     int W, H, D;
     int P1, P2;

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void pair_ckpt_kernel(PairArgs a) {
     if (lg * PXW >= nl) return;                                 // wave-uniform
     // the pair kernels are few waves with a long serial chain each (len steps): beside the sweeps' many waves they
     // must not queue for issue slots, or the whole stage waits for them
-    if (a.prio == 3) __builtin_amdgcn_s_setprio(3); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(3);
     const int l = min(lg * PXW + g, nl - 1);                    // lines past the last redo the last (same bytes, same addresses)
     const int NT = (len + HP_TC - 1) / HP_TC;
     if (NT < 2) return;                                         // a single tile starts at the border: no checkpoint
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void pair_sum_kernel(PairArgs a) {        /
     const int nl = AXIS ? a.W : a.H, len = AXIS ? a.H : a.W;
     const int lg = (int)blockIdx.x * 4 + wave;
     if (lg * PXW >= nl) return;
-    if (a.prio == 3) __builtin_amdgcn_s_setprio(3); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(3);
     const bool own_ok = lg * PXW + g < nl;
     const int l = min(lg * PXW + g, nl - 1);
     const int NT = (len + TC - 1) / TC;
@@ -850,14 +850,8 @@ void launch_pair_x_fine(hipStream_t st, const PairArgs& a, int frames) {
 // One axis (0 horizontal, 1 vertical).  phase 0: checkpoint pass + sum pass; 1: checkpoint pass only;
 // 2: sum pass only (so that the caller can put an event between them).  final_pass: the sum pass adds
 // a.Xother and writes WTA records instead of Y.
-static int pair_prio() {
-    static const int v = [] { const char* e = getenv("FSGM_PAIR_PRIO"); const int x = (e && *e) ? atoi(e) : 3; return x < 0 ? 0 : (x > 3 ? 3 : x); }();
-    return v;
-}
-
 void launch_pair(hipStream_t st, const PairArgs& a0, int frames, int axis, bool final_pass, int phase) {
-    PairArgs a = a0;
-    a.prio = pair_prio();
+    const PairArgs& a = a0;
     switch (agg_packed_lpp(a.D)) {
         case 1: launch_pair_t<1>(st, a, frames, axis, final_pass, phase); break;
         case 2: launch_pair_t<2>(st, a, frames, axis, final_pass, phase); break;
@@ -877,15 +871,9 @@ void launch_pair(hipStream_t st, const PairArgs& a0, int frames, int axis, bool 
 int sweep_rows_per_launch(int D) { const int lpp = agg_packed_lpp(D); return lpp ? (FSGM_SWEEP_WAVES / 2) * (64 / lpp) : 0; }
 size_t sweep_state_bytes(int W, int D) { return (size_t)3 * W * D; }
 
-// FSGM_SWEEP_GPW: pixel groups per wave (1 = default, or 2; A/B switch).  With 2 a wave owns 16 columns at D = 128 -- six
-// own DP steps and one halo step per row instead of three and one: the halo (and its cost unpack and LDS round trip)
-// weighs half as much, the strips are 64 columns wide -- but twice the registers and half the workgroups: measured
-// 7 % slower (4.04 vs 3.78 ms per 32 frames).
-static int sweep_gpw() {
-    static const int v = [] { const char* e = getenv("FSGM_SWEEP_GPW"); const int x = (e && *e) ? atoi(e) : 1; return x == 2 ? 2 : 1; }();
-    return v;
-}
-
+// (sweep_kernel's GPW parameter: pixel groups per wave.  2 -- six own DP steps and one halo step per row instead of three and one,
+// 64-column strips -- halves the halo's weight but needs twice the registers and leaves half the workgroups: measured 7 % slower
+// (4.04 vs 3.78 ms per 32 frames); only GPW = 1 is instantiated.)
 template <int LPP, int GPW, int NWV>
 static void launch_sweep_g(hipStream_t st, SweepArgs a, int frames, int mode) {
     constexpr int STRIP = NWV * GPW * (64 / LPP), T = (NWV / 2) * (64 / LPP);
@@ -910,7 +898,6 @@ static void launch_sweep_g(hipStream_t st, SweepArgs a, int frames, int mode) {
 template <int LPP>
 static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode, int tall) {
     if (tall && mode != 2) launch_sweep_g<LPP, 1, 8>(st, a, frames, mode);
-    else if (sweep_gpw() == 2) launch_sweep_g<LPP, 2, FSGM_SWEEP_WAVES>(st, a, frames, mode);
     else launch_sweep_g<LPP, 1, FSGM_SWEEP_WAVES>(st, a, frames, mode);
 }
 
