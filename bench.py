@@ -325,9 +325,10 @@ def main():
     stages = STAGE_AGGREGATE | STAGE_WTA
 
     def barrier():
+        torch.cuda.synchronize()                             # the plan's own stream too (device-wide)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         plan.run(stages)
