@@ -16,6 +16,9 @@ pytestmark = pytest.mark.gpu
     (45, 19, 45, 19, 5, 5, 2, "int"), (31, 22, 31, 22, 4, 2, 1, "int"), (29, 17, 30, 18, 5, 3, 0, "general"),
     (26, 14, 26, 14, 6, 5, 2, "general"), (26, 14, 26, 14, 2, 6, 2, "int"),       # 13-wide windows: compact layout
     (23, 16, 23, 16, 2, 2, 3, "general"),                                         # aggregation radius 3: generic kernel
+    # frames with an interior: waves with every sample inside both images, with samples outside image 2 only, and border waves
+    # (the three tap loops of pyd_rows_cost_kernel), at 5, 8 (capped) and 8 pixels a wave
+    (160, 90, 160, 90, 5, 5, 2, "general"), (150, 70, 151, 71, 3, 4, 1, "even"), (140, 60, 140, 60, 1, 2, 2, "int"),
 ])
 def test_pyd_cost_volume_bit_exact(gpu_lib, oracle, W, H, mvW, mvH, rX, rY, rAgg, kind):
     I1, I2 = synth.image_pair(W, H, 16, seed=W)
