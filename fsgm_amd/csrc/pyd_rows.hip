@@ -360,7 +360,10 @@ constexpr int ROWS_WAVE_BYTES = 2 * 4 * 16 * ROWB + 4 * 32 * 4;    // two buffer
 
 template <int NW, bool WIDE>
 __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int slot, uint32_t* sRows) {
-    constexpr int PF = 4;                                    // prefetch distance in steps
+#ifndef FSGM_PYD_PF
+#define FSGM_PYD_PF 4
+#endif
+    constexpr int PF = FSGM_PYD_PF;                          // prefetch distance in steps (A/B knob: 6 and 8 measured no better)
     constexpr int NL = WIDE ? 1 : NW;                        // dwords of a candidate row this lane owns
     constexpr int NE = NL + (WIDE ? 2 : 1);                  // realigned dwords of the previous row it needs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
