@@ -385,8 +385,16 @@ int plan_pyd_dirs(PydAggArgs& a, int diagonal, int totalPass, uint32_t weight[8]
         acc += (nlines + lpb - 1) / lpb;
         n++;
     };
-    if (totalPass >= 1) for (int k = 0; k < nd; k++) add(fwd[k], 1u);
-    if (totalPass >= 2) for (int k = 0; k < nd; k++) add(fwd[k] | 4, (uint32_t)(totalPass - 1));
+    // (the order of the slots is free -- volumes, descriptors and weights all go by slot.  The wide ones first: blocks are dispatched
+    //  in order, so the long one-line-per-wave workgroups then start on CUs of their own and the packed ones fill in around them --
+    //  0.69 -> 0.64 ms at 1242x375 against the order "pass 0, then pass 1"; handing the items out from a counter to 2-5 workgroups
+    //  per CU instead, wide ones first, was no better: 0.66-0.72)
+    if (wide_rows) {
+        if (totalPass >= 1) add(fwd[0], 1u);
+        if (totalPass >= 2) add(fwd[0] | 4, (uint32_t)(totalPass - 1));
+    }
+    if (totalPass >= 1) for (int k = wide_rows ? 1 : 0; k < nd; k++) add(fwd[k], 1u);
+    if (totalPass >= 2) for (int k = wide_rows ? 1 : 0; k < nd; k++) add(fwd[k] | 4, (uint32_t)(totalPass - 1));
     a.ndirs = n;
     for (int i = n; i <= 8; i++) a.blk_begin[i] = acc;
     for (int i = n; i < 8; i++) { a.dir_code[i] = 0; weight[i] = 0; }

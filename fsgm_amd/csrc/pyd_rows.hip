@@ -10,6 +10,7 @@
 #include "pyd_kernels.h"
 #include "fsgm_device.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace fsgm {
 
