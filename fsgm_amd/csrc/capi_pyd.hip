@@ -60,7 +60,8 @@ fsgm_status fsgm_pyd_plan_create(fsgm_pyd_plan** out, int32_t W, int32_t H, int3
     alloc((void**)&p->dMv, B * p->MV * 16);
     alloc((void**)&p->dC, B * p->N);
     alloc((void**)&p->dL, B * p->N * 8);
-    if (pyd_rows_layout(p->Sx, p->Sy)) alloc((void**)&p->dDesc, (B * p->NP * 8 + 4) * 4);   // + the dump slot
+    // (the row-packed aggregation addresses a frame's volume with 32-bit byte offsets: larger frames take the generic kernels)
+    if (pyd_rows_layout(p->Sx, p->Sy) && p->N < (1ull << 32)) alloc((void**)&p->dDesc, (B * p->NP * 8 + 4) * 4);   // + the dump slot
     alloc((void**)&p->dBestD, B * p->NP * 4);
     alloc((void**)&p->dMinC, B * p->NP * 4);
     alloc((void**)&p->dMvSub, B * p->NP * 16);

@@ -370,7 +370,7 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, row4 = lane >> 4;
     const int code = a.dir_code[slot];
-    const int base = code & 3;
+    const int base = WIDE ? 0 : (code & 3);                 // (the one-line-per-wave mapping is only ever given the along-x slots: the walk below folds to +-1)
     const bool mirror = (code & 4) != 0;
     const int W = a.W, H = a.H, Sx = a.Sx, Sy = a.Sy, RS = a.RS, PS = a.PS;
     const int NP = W * H;
@@ -416,29 +416,38 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
     int cx = base == 0 ? 0 : line;                           // pass-0 column (diagonals only)
     int pix = base == 0 ? line * W : line;                   // first pixel: (0, line) for rows, (line, 0) otherwise
     if (mirror) pix = NP - 1 - pix;                          // (shadowed inside the loop by the current step's pixel)
-    auto advance = [&](int& p, int& c) {
+    // (the byte offset of the pixel's bytes in a volume moves along with the index: no multiplication, no 64-bit address per step --
+    //  a frame's volume is below 4 GB or the plan has no descriptors and this kernel is not used, capi_pyd.hip)
+    const uint32_t dstepB = (uint32_t)(dstep * PS), dwrapB = (uint32_t)(dwrap * PS);
+    auto advance = [&](int& p, int& c, uint32_t& off) {
         p += dstep;
+        off += dstepB;
         if (base >= 2) {
             c += dcx;
-            if (c == cwrap) { c = creset; p += dwrap; }
+            if (c == cwrap) { c = creset; p += dwrap; off += dwrapB; }
         }
     };
     // Prefetch ring: costs and descriptor of step t+PF are requested while step t computes (HBM latency
     // is several steps long).  The ring rotates by unrolling, not by copying: a copy would wait for
     // the load it copies.  The fetch cursor runs PF steps ahead of the step being computed; steps past
     // the end of the line re-read the first pixel and store into the dump slot.
-    struct Fetch { uint32_t c[NL]; uint32_t desc; int pix; };
+    struct Fetch { uint32_t c[NL]; uint32_t desc; int pix; uint32_t off; };
     const int pix0 = pix;
+    const uint32_t off0 = (uint32_t)pix * (uint32_t)PS + rowoff;   // this lane's bytes of the line's first pixel
     int fpix = pix, fcx = cx, ft = 0;
+    uint32_t foff = off0;
     auto issue = [&](Fetch& o) {
-        const int p = ft < len ? fpix : pix0;
-        const RowDw<NL> row = load_row<NL>(Cf + (size_t)p * PS + rowoff);
+        const bool in_line = ft < len;
+        const int p = in_line ? fpix : pix0;
+        const uint32_t off = in_line ? foff : off0;
+        const RowDw<NL> row = load_row<NL>((const uint8_t*)Cf + off);
 #pragma unroll
         for (int k = 0; k < NL; k++) o.c[k] = row.v[k];
-        o.desc = Df[p];
+        o.desc = *(const uint32_t*)((const uint8_t*)Df + ((uint32_t)p << 2));
         o.pix = p;
+        o.off = off;
         ft++;
-        advance(fpix, fcx);
+        advance(fpix, fcx, foff);
     };
     Fetch ring[PF];
 #pragma unroll
@@ -599,7 +608,7 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
             // slot in HBM.  With one store per step at a fixed place in the instruction stream the
             // wait for the prefetched loads is a counted s_waitcnt vmcnt(1), not a wait for the store.
             uint32_t* dl = (uint32_t*)(cur + (is_out ? sx : DUMPROW) * ROWB + ROWDATA + 4 * q);
-            uint32_t* dg = (is_out && active && t < len) ? (uint32_t*)(Lf + (size_t)pix * PS + rowoff) : a.dump;
+            uint32_t* dg = (is_out && active && t < len) ? (uint32_t*)(Lf + now.off) : a.dump;
             RowDw<NL> row;
 #pragma unroll
             for (int k = 0; k < NL; k++) {
