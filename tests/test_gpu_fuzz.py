@@ -1,6 +1,8 @@
 """Seeded random-configuration parity sweep: GPU (through the C ABI) vs CPU oracle over random
 shapes, disparity ranges, penalties, hint maps and switches -- shapes that are not multiples of
 any tile (strip, wave, row block) and parameters on both sides of the no-wrap boundary."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,12 +11,19 @@ from fsgm_amd._lib import STAGE_AGGREGATE, STAGE_WTA, STAGE_ALL
 
 pytestmark = pytest.mark.gpu
 
+# FSGM_FUZZ_SEEDS=N in the environment runs every sweep below with N seeds instead of its default count (a soak run)
+_SOAK = int(os.environ.get("FSGM_FUZZ_SEEDS", "0"))
+
+
+def _seeds(default):
+    return range(_SOAK if _SOAK > 0 else default)
+
 
 def _rng(seed):
     return np.random.RandomState(seed)          # only picks test configurations; data comes from synth
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _seeds(24))
 def test_epi_random_configs(gpu_lib, oracle, seed):
     r = _rng(seed)
     D = int(r.choice([16, 32, 64, 128, 256, 8, 20, 48, 100]))
@@ -48,7 +57,7 @@ def test_epi_random_configs(gpu_lib, oracle, seed):
                 np.testing.assert_array_equal(plan.download_sum(f), S[:-1].reshape(H, W, D), err_msg=msg)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", _seeds(16))
 def test_epi_random_tall_configs(gpu_lib, oracle, seed):
     """Tall narrow frames: several bands of the band sweeps (both forms), several row blocks of the block sweeps."""
     r = _rng(500 + seed)
@@ -85,7 +94,7 @@ def test_epi_random_tall_configs(gpu_lib, oracle, seed):
         plan.sync()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _seeds(12))
 def test_pyd_random_configs(gpu_lib, oracle, seed):
     r = _rng(100 + seed)
     W, H = int(r.randint(1, 60)), int(r.randint(1, 45))
@@ -111,7 +120,7 @@ def test_pyd_random_configs(gpu_lib, oracle, seed):
     np.testing.assert_array_equal(gms, ms, err_msg=msg)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", _seeds(16))
 def test_ng_random_configs(gpu_lib, oracle, seed):
     r = _rng(200 + seed)
     W, H = int(r.randint(1, 40)), int(r.randint(1, 30))
