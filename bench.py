@@ -429,7 +429,8 @@ def main():
                 for f in range(B):
                     plan.upload(f, I1, I2, pd0, nd, offg)
                 all_ms = plan.time(STAGE_COST | STAGE_AGGREGATE | STAGE_WTA, warmup=1, iters=3)
-                out[key] = {"ms_per_frame": all_ms / B, "frames_per_s": B / (all_ms * 1e-3),
+                cost_ms = plan.time(STAGE_COST, warmup=1, iters=3)
+                out[key] = {"ms_per_frame": all_ms / B, "frames_per_s": B / (all_ms * 1e-3), "cost_stage_ms_per_frame": cost_ms / B,
                             "stages": f"census x2, cost fill, box, aggregate({PATHS} paths), WTA", "inputs": "resident in HBM",
                             "maps": "SURVEY 8(d) timing maps" if kind == "axis" else "random direction per pixel"}
         if world == 1 and not args.no_extras:

@@ -296,15 +296,10 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
     const size_t B = batch;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(ptr, bytes); };
-    alloc((void**)&p->dI1, B * p->NP);
-    alloc((void**)&p->dI2, B * p->NP);
-    alloc((void**)&p->dCen1, B * p->NP * 4);
-    alloc((void**)&p->dCen2, B * p->NP * 4);
-    alloc((void**)&p->dPd0, B * p->NP * 16);
-    alloc((void**)&p->dNd, B * p->NP * 16);
+    // images, census codes, the two fp64 coordinate maps and the raw cost volume belong to the cost stage and are allocated
+    // on first use (ensure_cost_buffers): an aggregation-only plan holds C, the offsets and its pipeline's volumes only
     alloc((void**)&p->dOff, B * p->NP * 8);
     alloc((void**)&p->dVz, (size_t)D * 8);
-    alloc((void**)&p->dCraw, B * p->N);
     alloc((void**)&p->dC, B * p->N);
     // the per-voxel intermediates of the two aggregation strategies (L_r for the line kernels;
     // L_left/right, X_dn, states, records for the fused sweeps) are allocated on first use
@@ -331,18 +326,38 @@ fsgm_status fsgm_epi_plan_create(fsgm_epi_plan** out, int32_t W, int32_t H, int3
         std::lock_guard<std::mutex> lk(mu);
         int& s = state[pr.device & 63];
         if (s == 0) {
-            const int r = fused_step_selftest(p->stream);
+            int r = fused_step_selftest(p->stream);
+            if (r == 0) r = costbox_selftest(p->stream);         // the fused cost kernel's mean as one fp16 multiply on denormal patterns
             if (r < 0) { fsgm_epi_plan_destroy(p); return fail(FSGM_ERR_HIP, "fsgm_epi_plan_create: self-test of the packed step could not run"); }
             s = r == 0 ? 1 : 2;
         }
         if (s == 2) {
             fsgm_epi_plan_destroy(p);
-            return fail(FSGM_ERR_UNSUPPORTED, "this build's v_pk_maximum3_f16 / v_pk_minimum3_f16 do not act as u16 max / min on denormal "
-                                              "patterns (toolchain or float-mode change): the fused aggregation kernels would be wrong");
+            return fail(FSGM_ERR_UNSUPPORTED, "this build's v_pk_maximum3_f16 / v_pk_minimum3_f16 / v_pk_mul_f16 do not act as exact u16 operations on denormal "
+                                              "patterns (toolchain or float-mode change): the fused kernels would be wrong");
         }
     }
     select_kernel(p);
     *out = p;
+    return FSGM_OK;
+}
+
+// Buffers of the cost stage (census x2 -> raw costs -> box mean) and of everything else that reads the image pair or the
+// coordinate maps: created together on first use, committed only when the whole set exists.
+static fsgm_status ensure_cost_buffers(fsgm_epi_plan* p) {
+    if (p->dCraw) return FSGM_OK;                                // the set's own marker: created last
+    const size_t B = p->batch;
+    LazySet ls;
+    uint8_t *i1, *i2, *craw; uint32_t *c1, *c2; double *pd0, *nd;
+    ls.alloc(&i1, B * p->NP);
+    ls.alloc(&i2, B * p->NP);
+    ls.alloc(&c1, B * p->NP * 4);
+    ls.alloc(&c2, B * p->NP * 4);
+    ls.alloc(&pd0, B * p->NP * 16);
+    ls.alloc(&nd, B * p->NP * 16);
+    ls.alloc(&craw, B * p->N);
+    if (ls.err != hipSuccess) return lazy_fail(ls, "cost stage buffers");
+    p->dI1 = i1; p->dI2 = i2; p->dCen1 = c1; p->dCen2 = c2; p->dPd0 = pd0; p->dNd = nd; p->dCraw = craw;
     return FSGM_OK;
 }
 
@@ -379,6 +394,7 @@ fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* p, int32_t f, const uint8_t* I1,
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_REQUIRE(I1 && I2 && pd0 && nd && off, "fsgm_epi_plan_upload: null input");
     FSGM_HIP(hipSetDevice(p->prm.device));
+    { fsgm_status cs = ensure_cost_buffers(p); if (cs != FSGM_OK) return cs; }
     const size_t NP = p->NP;
     StreamGuard guard(p->stream);
     FSGM_HIP(hipMemcpyAsync(p->dI1 + f * NP, I1, NP, hipMemcpyHostToDevice, p->stream));
@@ -554,6 +570,10 @@ static fsgm_status ensure_par_buffers(fsgm_epi_plan* p) {
 // (values <= 24), so the bound of the cost values -- and with it the kernel selection -- is settled first;
 // then the buffer set of the selected pipeline.
 static fsgm_status prepare(fsgm_epi_plan* p, int stages) {
+    if ((stages & FSGM_STAGE_COST) || p->prm.fb_check) {
+        fsgm_status cs = ensure_cost_buffers(p);
+        if (cs != FSGM_OK) return cs;
+    }
     if (stages & FSGM_STAGE_COST) {
         bool changed = false;
         for (int& c : p->cmax) { if (c != 24) changed = true; c = 24; }
@@ -778,7 +798,7 @@ fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* p, int32_t mode) {
 
 // the chained band sweeps' bounded hand-off waits raise a device flag instead of hanging: surface it after a sync
 static fsgm_status check_handoff(fsgm_epi_plan* p) {
-    if (p->band_chain && p->dBandErr) {                          // chained band sweeps: bounded waits between the bands of a frame
+    if (p->dBandErr) {                                           // a chained launch happened at some point (the selection may have moved on since)
         uint32_t e = 0;
         FSGM_HIP(hipMemcpy(&e, p->dBandErr, sizeof(e), hipMemcpyDeviceToHost));
         if (e != 0) {
@@ -813,6 +833,7 @@ fsgm_status fsgm_epi_plan_download_fb(fsgm_epi_plan* p, int32_t f, uint8_t* conf
     FSGM_REQUIRE(p->prm.fb_check, "the plan was created without fb_check");
     FSGM_HIP(hipSetDevice(p->prm.device));
     FSGM_HIP(hipStreamSynchronize(p->stream));
+    { fsgm_status hs = check_handoff(p); if (hs != FSGM_OK) return hs; }
     if (conf) FSGM_HIP(hipMemcpy(conf, p->dConf + f * p->NP, p->NP, hipMemcpyDeviceToHost));
     if (bestD2) FSGM_HIP(hipMemcpy(bestD2, p->dD2 + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
     return FSGM_OK;
@@ -831,6 +852,7 @@ fsgm_status fsgm_epi_plan_download_census(fsgm_epi_plan* p, int32_t f, uint32_t*
     FSGM_REQUIRE(p, "null plan");
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_HIP(hipSetDevice(p->prm.device));
+    FSGM_REQUIRE(p->dCen1, "fsgm_epi_plan_download_census: the cost stage has not run on this plan");
     FSGM_HIP(hipStreamSynchronize(p->stream));
     if (cen1) FSGM_HIP(hipMemcpy(cen1, p->dCen1 + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
     if (cen2) FSGM_HIP(hipMemcpy(cen2, p->dCen2 + f * p->NP, p->NP * 4, hipMemcpyDeviceToHost));
@@ -841,6 +863,8 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
     FSGM_REQUIRE(p && S, "fsgm_epi_plan_download_sum: null argument");
     FSGM_REQUIRE(f >= 0 && f < p->batch, "frame %d out of range (batch %d)", f, p->batch);
     FSGM_HIP(hipSetDevice(p->prm.device));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    { fsgm_status hs = check_handoff(p); if (hs != FSGM_OK) return hs; }
     if (p->kernel_kind == AGG_SWEEP) {
         // S never exists in HBM in sweep mode.  Debug tap: materialise X_up of that frame with a
         // non-final up sweep, then let wta_sweep_kernel rebuild S = X_dn + X_up + 6C + L_left + L_right.
@@ -951,7 +975,7 @@ fsgm_status fsgm_epi_plan_time(fsgm_epi_plan* p, int32_t stages, int32_t warmup,
     float ms = 0;
     FSGM_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     *ms_avg = ms / iters;
-    return FSGM_OK;
+    return check_handoff(p);                                     // a timed run that gave up on a hand-off is not a measurement
 }
 
 void* fsgm_epi_plan_stream(fsgm_epi_plan* p) { return p ? (void*)p->stream : nullptr; }
@@ -1067,6 +1091,7 @@ fsgm_status fsgm_calc_cost_sgm_batch_host(int32_t n, const fsgm_epi_in* in, cons
     if (st != FSGM_OK) return st;
     if ((st = fsgm_epi_plan_set_penalties(p, in[0].P1, in[0].P2, in[0].vMax)) != FSGM_OK) return st;
     FSGM_HIP(hipSetDevice(p->prm.device));
+    if ((st = ensure_cost_buffers(p)) != FSGM_OK) return st;
     // One call = one stream-ordered sequence with a single host wait: every frame's inputs go up asynchronously on the
     // plan's stream (hipMemcpyAsync from the caller's pageable memory runs at the pinned rate here, ~50 GB/s, so there is
     // no staging copy: tools/ubench/h2d_rates.hip), the batched kernels follow, the results come down at the end.
@@ -1134,6 +1159,7 @@ fsgm_status fsgm_census_host(const uint8_t* img, int32_t W, int32_t H, uint32_t*
     fsgm_status st = cached_plan(&p, W, H, 16, 1, pr);           // any dMax: only the image / census buffers are used
     if (st != FSGM_OK) return st;
     FSGM_HIP(hipSetDevice(device));
+    if ((st = ensure_cost_buffers(p)) != FSGM_OK) return st;
     StreamGuard guard(p->stream);
     FSGM_HIP(hipMemcpyAsync(p->dI1, img, p->NP, hipMemcpyHostToDevice, p->stream));
     launch_census(p->stream, p->dI1, p->dCen1, W, H, 1);
@@ -1154,6 +1180,7 @@ static EpiGeomArgs geom_args(const fsgm_epi_geometry* g, int W, int H, double* P
 }
 
 static fsgm_status ensure_driver_buffers(fsgm_epi_plan* p, int channels) {
+    { fsgm_status cs = ensure_cost_buffers(p); if (cs != FSGM_OK) return cs; }
     if (!p->dRflow) FSGM_HIP(hipMalloc((void**)&p->dRflow, (size_t)p->batch * p->NP * 16));
     if (!p->dFlow) FSGM_HIP(hipMalloc((void**)&p->dFlow, (size_t)p->batch * p->NP * 24));
     if (channels == 3 && !p->dRgb) FSGM_HIP(hipMalloc((void**)&p->dRgb, p->NP * 3 * 2));

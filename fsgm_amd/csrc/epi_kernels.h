@@ -133,6 +133,10 @@ enum { AGG_PACKED_NOWRAP = 0, AGG_PACKED_WRAP = 1, AGG_GENERIC = 2, AGG_SWEEP = 
 int  agg_packed_lpp(int D);   // lanes per pixel of the packed kernels, 0 if D is not 16<<k, k<=4
 void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int H, int frames);
 void launch_epi_cost(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frames);
+// the cost stage as one kernel (epi_cost.hip): raw costs + 5x5 box mean, a.Craw unused
+bool costbox_ok(int W, int H, int D);
+void launch_epi_costbox(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frames);
+int  costbox_selftest(hipStream_t st);      // 0: the mean's fp16 multiply is exact on this device; > 0: mismatches; < 0: could not run
 void launch_aggregate(hipStream_t st, AggArgs a, int paths, int frames, int kernel_kind);
 void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
 int    sweep_rows_per_launch(int D);

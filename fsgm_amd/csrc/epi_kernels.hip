@@ -824,6 +824,9 @@ void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int
 }
 
 void launch_epi_cost(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frames) {
+    // FSGM_COST_FUSED=0: the two-kernel form (raw volume through HBM) -- A/B switch and the cross-check of the fused kernel in the tests
+    const bool fused = [] { const char* e = getenv("FSGM_COST_FUSED"); return !(e && e[0] == '0'); }();   // read per launch: the tests flip it
+    if (fused && costbox_ok(a.W, a.H, a.D)) { launch_epi_costbox(st, a, C, frames); return; }
     const long long n = (long long)a.W * a.H * ((a.D + 3) / 4);
     dim3 grid((unsigned)((n + 255) / 256), frames);
     if ((a.D & 7) == 0 && a.W < (1 << 22) && a.H < (1 << 24)) {

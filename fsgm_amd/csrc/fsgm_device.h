@@ -33,23 +33,24 @@ __device__ __forceinline__ int32_t round_to_i32_x86(double v) {
     return fabs(v) < 2147483648.0 ? (int32_t)(n + inc) : INT32_MIN;
 }
 
-// clamp((int)round(v), 0, hi) for a finite |v| < 2^31 - 1 (the caller has proved it), six full-rate
-// instructions: every negative v rounds to something <= 0 and clamps to 0, so v is clamped at 0.0 first;
-// for v >= 0 round-half-away is floor(v) + [fract(v) >= 0.5], v_cvt_i32_f64 is the floor and v_fract_f64
-// is exact.  The half test is a signed compare of fract's high word (fract(-0.0) = -0.0 must fail it).
-__device__ __forceinline__ int round_clamp_small(double v, int hi) {
-    const double vp = fmax(v, 0.0);
-    const int n = __double2int_rz(vp);
-    const double fr = __builtin_amdgcn_fract(vp);
-    const int r = n + (__double2hiint(fr) >= 0x3FE00000 ? 1 : 0);
-    return min(r, hi);
-}
-
 // clamp to [0, hi] in one instruction (hi >= 0)
 __device__ __forceinline__ int clamp0(int v, int hi) {
     int r;
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi));
     return r;
+}
+
+// clamp((int)round(v), 0, hi) for a finite |v| < 2^30 (the caller has proved it), three full-rate instructions:
+//   trunc(fl(v + pred(0.5))) is C round() -- half away from zero -- for every 0 <= v < 2^51: with h = pred(0.5) =
+//   0.5 - 2^-54 the exact sum v + h lies 2^-54 below v + 0.5, and (i) v = k + 0.5: the sum k + 1 - 2^-54 is nearer to
+//   k + 1 than to the double below it (a tie for k = 0, which goes to the even mantissa of 1.0), so it rounds UP to
+//   k + 1; (ii) v below k + 0.5 by at least its own ulp: the sum stays below k + 1 after rounding, because the
+//   doubles below k + 1 are no coarser than ulp(v) >= 2^-53 > 2^-54 apart from the sum; (iii) v < 0.5: sum < 1.
+//   (Adding 0.5 itself fails at v = pred(0.5): 1 - 2^-54 ties up to 1.0.)  Negative v: v > -0.5 gives a sum in
+//   (-2^-54, 0.5) -> 0; v <= -0.5 gives a sum <= 0 that truncates to <= 0 and the clamp returns 0, as it does for
+//   the reference's round(v) <= -1.  tests/test_capi_cpu.py checks the identity around every half integer.
+__device__ __forceinline__ int round_clamp_small(double v, int hi) {
+    return clamp0(__double2int_rz(__dadd_rn(v, 0x1.fffffffffffffp-2)), hi);
 }
 
 // parabola vertex offset as the pyramidal variant writes it (calc_pyd_cost_sgm.cpp:341-344)

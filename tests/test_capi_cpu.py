@@ -118,3 +118,42 @@ def test_auto_mode_table():
     assert auto_pipeline(1242, 375, 128, 512, 8, 64, 6) == "packed16/nowrap"       # P1 > P2: not a fused pipeline's case
     assert auto_pipeline(1242, 375, 100, 512, 8, 6, 64) == "generic"               # dMax not a multiple of 16
     assert auto_pipeline(0, 375, 128, 1, 8, 6, 64) == ""
+
+
+def test_round_half_away_as_one_addition_of_pred_half():
+    """epi_cost.hip / fsgm_device.h round_clamp_small: max(trunc(v + pred(0.5)), 0) == max(C round(v), 0) for |v| < 2^30,
+    checked on both sides of every half integer and integer (the doubles next to them), across magnitudes, and at random."""
+    h = np.nextafter(0.5, 0.0)
+
+    def c_round_clamped(v):
+        a = np.abs(v)
+        r = np.floor(a) + ((a - np.floor(a)) >= 0.5)
+        return np.maximum(np.where(v < 0, -r, r), 0.0)
+
+    ks = np.concatenate([np.arange(0, 4096), 2.0 ** np.arange(12, 31), 2.0 ** np.arange(12, 31) - 1, [2.0 ** 30 - 7]])
+    vs = []
+    for base in (ks + 0.5, ks):
+        up, dn = base.copy(), base.copy()
+        vs.append(base)
+        for _ in range(5):
+            up, dn = np.nextafter(up, np.inf), np.nextafter(dn, -np.inf)
+            vs += [up, dn]
+    vs.append(np.array([0.0, -0.0, 5e-324, -5e-324, h, -h, np.nextafter(h, 0), 0.25, -0.25, -0.5, np.nextafter(-0.5, 0), np.nextafter(-0.5, -1)]))
+    v = np.concatenate(vs)
+    v = np.concatenate([v, -v])
+    np.testing.assert_array_equal(np.maximum(np.trunc(v + h), 0.0), c_round_clamped(v))
+    assert np.trunc(h + 0.5) == 1.0                       # what the plain + 0.5 gets wrong
+    rng = np.random.default_rng(5)
+    v = np.concatenate([rng.uniform(-200, 3000, 2_000_000),
+                        np.round(rng.uniform(0, 2 ** 30, 1_000_000)) + rng.choice([0.5, -0.5, 0.49999999, 0.50000001], 1_000_000)])
+    np.testing.assert_array_equal(np.maximum(np.trunc(v + h), 0.0), c_round_clamped(v))
+
+
+def test_box_mean_as_one_fp16_multiply():
+    """epi_cost.hip: (u8)(1.0 * s / 25 + 0.5) (calc_cost_sgm.cpp:403-404) == (2 s + 25) / 50 == the u16 pattern of s, read as a
+    denormal fp16, times fp16(0.04) -- for every sum below 1024 (a 5x5 window of census costs reaches 600)."""
+    s = np.arange(0, 1024, dtype=np.uint16)
+    got = (s.view(np.float16) * np.float16(0.04)).view(np.uint16)
+    assert np.float16(0.04).view(np.uint16) == 0x291F
+    np.testing.assert_array_equal(got, ((2 * s.astype(np.int64) + 25) // 50).astype(np.uint16))
+    np.testing.assert_array_equal(got[:601], (1.0 * s[:601] / 25 + 0.5).astype(np.uint8))
