@@ -27,11 +27,26 @@
 // second kernel that re-reads the raw volume five rows deep (box5x5_sliding16_kernel: 120 MB per 1242x375x128 frame, 0.035 ms).
 #include "epi_kernels.h"
 #include "fsgm_device.h"
+#include <algorithm>
 
 namespace fsgm {
 
 constexpr int CB_OUT = 60;                    // output columns per workgroup (64 raw columns)
 constexpr uint32_t CB_K25 = 0x291F291Fu;      // fp16(0.04) twice
+
+// buffer_load_dword ... idxen: address = base + index * stride (stride 4 from the descriptor), so the gather's address is the
+// pixel index itself -- one v_mad_u32_u24 per sample instead of a shift and a multiply-add
+typedef int cb_i32x4 __attribute__((ext_vector_type(4)));
+__device__ uint32_t cb_struct_buffer_load_u32(cb_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i32");
+__device__ __forceinline__ cb_i32x4 cb_make_rsrc(const void* base, uint32_t records) {
+    const uint64_t b = (uint64_t)base;
+    cb_i32x4 r;
+    r.x = (int)(uint32_t)b;
+    r.y = (int)(((uint32_t)(b >> 32) & 0xFFFFu) | (4u << 16));              // stride 4 bytes in bits 61:48
+    r.z = (int)records;                                                      // records of `stride` bytes (idxen range check)
+    r.w = 0x00020000;                                                        // gfx9 raw dword format
+    return r;
+}
 
 __device__ __forceinline__ uint32_t pk_mul_f16(uint32_t a, uint32_t b) {
     uint32_t r;
@@ -46,26 +61,37 @@ struct CbPix {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 4) void epi_costbox_kernel(EpiCostArgs a, uint8_t* __restrict__ Cout, int seg_rows) {
+__global__ __launch_bounds__(NW * 64, 4) void epi_costbox_kernel(EpiCostArgs a, uint8_t* __restrict__ Cout, int seg_rows, uint32_t total_items) {
     __shared__ __attribute__((aligned(16))) uint4 xch[NW][68];              // a wave's raw row: slots 2 .. 65, two spare either side
+    __shared__ __attribute__((aligned(16))) uint4 outt[2][64][NW + 1];      // a row of C, [pixel][16-byte piece], one piece of padding
     const int W = a.W, H = a.H, D = a.D;
+    // Work item of this workgroup.  Workgroups go to the 8 XCDs round-robin by their linear id; the items (strip fastest, then
+    // row segment, then frame) are dealt so that every XCD walks a contiguous eighth of the list: the workgroups resident on an
+    // XCD then belong to one or two frames and their samples of image 2's census map share that XCD's L2 (with the plain
+    // blockIdx order an XCD sees strips of eight frames at once and a scattered direction field fetches 800 MB per frame).
+    const int strips = (W + CB_OUT - 1) / CB_OUT, segs = (H + seg_rows - 1) / seg_rows;
+    const uint32_t per_xcd = (total_items + 7u) >> 3;
+    const uint32_t item = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || item >= total_items) return;         // uniform over the workgroup
+    const int strip = (int)(item % (uint32_t)strips), seg = (int)((item / (uint32_t)strips) % (uint32_t)segs);
     const uint32_t NP = (uint32_t)W * (uint32_t)H;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d0 = 16 * w;
-    const size_t f = blockIdx.z;
-    const int xq = (int)blockIdx.x * CB_OUT - 2 + lane;                      // raw column of this lane (may lie outside: replicate)
+    const size_t f = item / (uint32_t)(strips * segs);
+    const int xs = strip * CB_OUT;
+    const int xq = xs - 2 + lane;                      // raw column of this lane (may lie outside: replicate)
     const int px = clampi(xq, 0, W - 1);
-    const int y0 = (int)blockIdx.y * seg_rows, y1 = min(y0 + seg_rows, H);
+    const int y0 = seg * seg_rows, y1 = min(y0 + seg_rows, H);
     const int nsteps = y1 - y0 + 4;                                          // raw rows y0 - 2 .. y1 + 1
     const double* __restrict__ p0 = a.pd0 + f * 2 * (size_t)NP;
     const double* __restrict__ nd = a.nd + f * 2 * (size_t)NP;
     const double* __restrict__ of = a.off + f * (size_t)NP;
     const uint32_t* __restrict__ cen1 = a.cen1 + f * (size_t)NP;
     const char* __restrict__ cen2 = (const char*)(a.cen2 + f * (size_t)NP);
-    uint8_t* __restrict__ Cf = Cout + f * (size_t)NP * D + d0;
+    uint8_t* __restrict__ Cf = Cout + f * (size_t)NP * D;
     const int xhi = W - 1, yhi = H - 1;
-    const uint32_t W4 = 4u * (uint32_t)W;
+    const uint32_t W4 = 4u * (uint32_t)W;                                    // (the general path's byte offsets)
     double vz[16];                                                           // wave-uniform: scalar registers
 #pragma unroll
     for (int k = 0; k < 16; k++) vz[k] = a.vz[d0 + k];
@@ -96,21 +122,26 @@ __global__ __launch_bounds__(NW * 64, 4) void epi_costbox_kernel(EpiCostArgs a, 
             const double ox = __dmul_rn(s, q.ux), oy = __dmul_rn(s, q.uy);                      // :365-366
             const double vx = __dadd_rn(bx, ox), vy = __dadd_rn(by, oy);
             const int x2 = round_clamp_small(vx, xhi), y2 = round_clamp_small(vy, yhi);         // :371-375
-            boff[k] = __umul24((uint32_t)y2, W4) + ((uint32_t)x2 << 2);
+            boff[k] = __umul24((uint32_t)y2, (uint32_t)W) + (uint32_t)x2;                       // pixel index (W < 2^22, H < 2^24: launcher)
         }
     };
-    auto gather = [&](const uint32_t (&boff)[8], uint32_t (&word)[8]) {
+    const cb_i32x4 cen2_rsrc = cb_make_rsrc(cen2, NP);
+    auto gather = [&](const uint32_t (&idx)[8], uint32_t (&word)[8]) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) word[k] = *(const uint32_t*)(cen2 + boff[k]);
+        for (int k = 0; k < 8; k++) word[k] = cb_struct_buffer_load_u32(cen2_rsrc, (int)idx[k], 0, 0, 0);
     };
     auto hamming = [&](const uint32_t c1, const uint32_t (&word)[8], uint32_t& lo, uint32_t& hi) {
-        uint32_t pk[2] = {0, 0};
+        uint32_t c[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t cost = __popc(c1 ^ word[k]);                                         // :377-378
-            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(pk[k >> 2]) : "v"(cost), "n"(8 * (k & 3)));
-        }
-        lo = pk[0]; hi = pk[1];
+        for (int k = 0; k < 8; k++) c[k] = __popc(c1 ^ word[k]);                                // :377-378
+        auto pack4 = [](uint32_t c0, uint32_t c1_, uint32_t c2, uint32_t c3) {
+            uint32_t t, u, r;
+            asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(t) : "v"(c1_), "v"(c0));
+            asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(u) : "v"(c3), "v"(c2));
+            asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(r) : "v"(u), "v"(t));
+            return r;
+        };
+        lo = pack4(c[0], c[1], c[2], c[3]); hi = pack4(c[4], c[5], c[6], c[7]);
     };
 
     uint32_t ring[5][8];                                                     // horizontal 5-sums of the last five rows, 2 x u16
@@ -150,12 +181,19 @@ __global__ __launch_bounds__(NW * 64, 4) void epi_costbox_kernel(EpiCostArgs a, 
                 const uint32_t me = pk_mul_f16(se, CB_K25), mo = pk_mul_f16(so, CB_K25);   // :403-404
                 asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(o[i]) : "v"(mo), "v"(me));
             }
-            if (lane >= 2 && lane < 2 + CB_OUT && xq < W)
-                *(uint4*)(Cf + ((uint32_t)yo * (uint32_t)W + (uint32_t)xq) * (uint32_t)D) = make_uint4(o[0], o[1], o[2], o[3]);
+            // the waves' 16-byte pieces of a pixel meet in LDS and leave as whole lines: wave w stores pixels 64 / NW * w ...,
+            // one 16-byte piece per lane (16-byte stores 128 bytes apart were measured at 1.85 x the written bytes in HBM)
+            outt[st & 1][lane][w] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        if (st >= 4) {
+            __syncthreads();                                                 // every wave runs the same steps: uniform
+            constexpr int PPW = 64 / NW;                                     // pixels a wave stores
+            const int pl = w * PPW + lane / NW, piece = lane % NW;           // pixel (= lane of the producers), piece
+            const int xo = xs - 2 + pl;
+            if (pl >= 2 && pl < 2 + CB_OUT && xo < W)
+                *(uint4*)(Cf + ((uint32_t)yo * (uint32_t)W + (uint32_t)xo) * (uint32_t)D + 16u * piece) = outt[st & 1][pl][piece];
         }
     };
-    // The row nobody expects (a sample position that may reach 2^31): the x86 conversion restated, one voxel at a time --
-    // written for few registers, not for speed, so that it does not weigh on the allocation of the loop it sits in.
     auto fill_general = [&](const int st, uint32_t (&pslot)[8]) {
         if (st >= 1) tail(st - 1, pslot);                                    // wave-uniform
         const double bx = __dsub_rn(cur.px, 1.0), by = __dsub_rn(cur.py, 1.0);
@@ -228,22 +266,34 @@ bool costbox_ok(int W, int H, int D) {
     return (D == 16 || D == 32 || D == 64 || D == 128 || D == 256) && W < (1 << 22) && H < (1 << 24);
 }
 
-// rows per segment: whole frames' worth of workgroups decide -- long segments (less apron) once the chip is full anyway
-int costbox_seg_rows(int W, int H, int frames) {
+// Rows per segment.  A workgroup's time goes with its rows + 4 (the apron rows), the launch's with the rounds of resident
+// workgroups it takes (16 waves per CU at <= 128 VGPRs: 16 / NW workgroups): the segment count that minimises
+// rounds x (rows + 4) -- few long segments once the frames alone fill the chip, many short ones for a single frame.
+int costbox_seg_rows(int W, int H, int D, int frames, int cus) {
     const long long strips = (W + CB_OUT - 1) / CB_OUT;
-    for (int rows : {128, 64, 32, 16}) {
-        const int nseg = (H + rows - 1) / rows;
-        const int even = (H + nseg - 1) / nseg;                              // equal segments: 375 rows -> 3 x 125, not 128 + 128 + 119
-        if (strips * nseg * frames >= 1024 || rows == 16) return even;
+    const long long resident = (long long)cus * std::max(1, 16 / (D >> 4));
+    long long best = -1;
+    int best_rows = H;
+    for (int nseg = 1; nseg <= std::max(1, H / 8); nseg++) {
+        const int rows = (H + nseg - 1) / nseg;                              // equal segments: 375 rows -> 3 x 125, not 128 + 128 + 119
+        const long long items = strips * ((H + rows - 1) / rows) * frames;
+        const long long cost = ((items + resident - 1) / resident) * (rows + 4);
+        if (best < 0 || cost < best) { best = cost; best_rows = rows; }
     }
-    return 16;
+    return best_rows;
 }
 
 void launch_epi_costbox(hipStream_t st, const EpiCostArgs& a, uint8_t* C, int frames) {
-    const int seg = costbox_seg_rows(a.W, a.H, frames);
-    dim3 grid((a.W + CB_OUT - 1) / CB_OUT, (a.H + seg - 1) / seg, frames);
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const int seg = costbox_seg_rows(a.W, a.H, a.D, frames, cus);
+    const uint32_t total = (uint32_t)((a.W + CB_OUT - 1) / CB_OUT) * (uint32_t)((a.H + seg - 1) / seg) * (uint32_t)frames;
+    dim3 grid(8u * ((total + 7u) / 8u));
     switch (a.D >> 4) {
-#define FSGM_CB(NW) case NW: hipLaunchKernelGGL(epi_costbox_kernel<NW>, grid, dim3(NW * 64), 0, st, a, C, seg); break;
+#define FSGM_CB(NW) case NW: hipLaunchKernelGGL(epi_costbox_kernel<NW>, grid, dim3(NW * 64), 0, st, a, C, seg, total); break;
         FSGM_CB(1) FSGM_CB(2) FSGM_CB(4) FSGM_CB(8) FSGM_CB(16)
 #undef FSGM_CB
     }
