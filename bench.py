@@ -33,10 +33,21 @@ def measured_traffic(kernel_name, paths):
         try:
             t = json.load(open(f))
             if t.get("pipeline") == kernel_name and t.get("paths") == paths:
-                return float(t["bytes_per_voxel"]), os.path.relpath(f, ROOT)
+                return float(t["bytes_per_voxel"]), {"file": os.path.relpath(f, ROOT), "measured": t.get("date"), "lib_sha16": t.get("lib_sha16")}
         except Exception:
             pass
     return None, None
+
+
+def lib_sha16():
+    """sha256 (first 16 hex digits) of the library this run loads: the PMC summaries carry the same field, so a traffic figure
+    measured on another build of the kernels shows (roofline.traffic_stale)."""
+    import hashlib
+    from fsgm_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
 
 
 def cpu_baseline(sample_rows=48, PATHS=PATHS):
@@ -224,6 +235,95 @@ def postprocess(args):
           flush=True)
 
 
+def _pci_bus_id(dev):
+    try:
+        import ctypes as _C
+        hip = _C.CDLL("libamdhip64.so")
+        buf = _C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev)) == 0:
+            return buf.value.decode()
+    except Exception:
+        pass
+    return str(dev)
+
+
+def in_process(args):
+    """--in-process N: the headline step on N devices from THIS process -- what a MATLAB session (one process) gets through the
+    device lists of the C ABI (include/fsgm.h): one plan + stream per device-list entry, entry i on device i mod the device
+    count, frames sharded by entry, no collective.  Weak scaling like the torchrun form: --frames-per-gpu frames per entry.
+    On a one-GPU box every entry is device 0 (the entries then share the GPU: a rehearsal of the plumbing, not a scaling point)."""
+    import numpy as np
+    import fsgm_amd
+    from fsgm_amd import synth, EpiPlan
+    from fsgm_amd._lib import STAGE_AGGREGATE, STAGE_WTA
+    PATHS = args.paths
+    N = args.in_process
+    ndev = fsgm_amd.load_library().fsgm_device_count()
+    assert ndev >= 1, "bench.py needs a GPU"
+    devs = [i % ndev for i in range(N)]
+    B = args.frames_per_gpu
+    _, _, off = synth.epi_maps(W, H, "axis")
+    plans, check = [], []
+    for slot, dev in enumerate(devs):
+        plan = EpiPlan(W, H, D, B, paths=PATHS, device=dev)
+        plan.set_penalties(P1, P2, VMAX)
+        if args.agg_mode:
+            plan.set_agg_mode(args.agg_mode)
+        bases = [synth.cost_volume(W, H, D, seed=1000 * slot + s, cmax=24) for s in range(min(4, B))]
+        for f in range(B):
+            if f < 4:
+                plan.upload_cost(f, bases[f])
+            else:
+                plan.copy_cost(f, f % 4, 37 * (f // 4))
+            plan.upload_offset(f, off)
+        plan.sync()
+        check.append(bases[0])
+        plans.append(plan)
+    stages = STAGE_AGGREGATE | STAGE_WTA
+    for _ in range(args.warmup):
+        for pl in plans:
+            pl.run(stages)
+    for pl in plans:
+        pl.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for pl in plans:                                    # asynchronous: every entry's step is queued before any is waited for
+            pl.run(stages)
+    for pl in plans:
+        pl.sync()
+    dt = time.perf_counter() - t0
+    # self-check: frame 0 of every entry against the line kernels on the same volume
+    ok = True
+    for slot, pl in enumerate(plans):
+        got = pl.download(0)
+        with EpiPlan(W, H, D, 1, paths=PATHS, device=devs[slot]) as ref:
+            ref.set_penalties(P1, P2, VMAX)
+            ref.set_agg_mode(1)
+            ref.upload_cost(0, check[slot])
+            ref.upload_offset(0, off)
+            ref.run(stages)
+            r = ref.download(0)
+        ok = ok and np.array_equal(got[0], r[0]) and np.array_equal(got[1], r[1])
+    assert ok, "an entry's bestD/minC differ from the line kernels' on the same volume"
+    bus = [_pci_bus_id(d) for d in devs]
+    vps = N * B * W * H * D * PATHS
+    alg = B * W * H * D * PATHS
+    stage_ms = [pl.time(STAGE_AGGREGATE, warmup=1, iters=3) for pl in plans[:1]][0]
+    achieved = alg / (stage_ms * 1e-3) / 1e9
+    out = {"metric": f"aggregated cost-volume voxel-paths/s (HxWxDx{PATHS} paths), KITTI 1242x375 D=128", "value": vps * args.steps / dt,
+           "unit": "voxel-paths/s", "n_gpus": len(set(bus)), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"KITTI 1242x375 D=128, {PATHS} paths, aggregation stage (C resident in HBM -> bestD/minC)",
+                      "frames_per_gpu": B, "total_frames": N * B, "in_process_entries": N, "device_list": devs, "kernel": plans[0].kernel_name,
+                      "sharding": "frames by device-list entry inside one process, no collective", "pci_bus_ids": bus, "distinct_devices": len(set(bus))},
+           "roofline": {"bound": "hbm", "kernel": "aggregation stage of entry 0 alone", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg, "stage_ms": stage_ms},
+           "checked": True, "argv": " ".join(sys.argv[1:])}
+    for pl in plans:
+        pl.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,9 +336,9 @@ def main():
     ap.add_argument("--total-frames", type=int, default=0,
                     help="strong scaling: a fixed batch of this many frames split over the ranks by fsgm_amd.batch.shard_indices "
                          "(BASELINE config 5 literally = 8); default 0 = weak scaling with --frames-per-gpu frames on every GPU")
-    ap.add_argument("--agg-mode", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--agg-mode", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="force an aggregation pipeline (fsgm_epi_plan_set_agg_mode): 0 auto (default), 1 line kernels, 2 fused sweeps / pairs, "
-                         "3 parallel sweeps, 4 band sweeps")
+                         "3 parallel sweeps, 4 band sweeps, 5 chained band sweeps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed loop, the self-check and the roofline block (no whole-MEX / host-call legs): for profiler runs")
@@ -250,7 +350,12 @@ def main():
                     help="epi8 = the headline metric (default); pyramid3 = BASELINE config 4, one pyramidal_sgm at 1242x375 "
                          "(3 levels); postprocess = the test.m:45-50 chain on a 1242x375 map (both secondary, 1 GPU, "
                          "not the judged line)")
+    ap.add_argument("--in-process", type=int, default=0,
+                    help="N > 0: the headline step on N device-list entries from this one process (entry i on device i mod the device "
+                         "count; what a single MATLAB process gets through the C ABI's device lists); prints the distinct PCI bus ids")
     args = ap.parse_args()
+    if args.in_process > 0:
+        return in_process(args)
     if args.workload == "pyramid3":
         return pyramid3(args)
     if args.workload == "pyramid3_ng":
@@ -319,7 +424,7 @@ def main():
             plan.copy_cost(f, f % 4, 37 * (f // 4))         # the same rotation, device to device (no PCIe transfer per frame)
         plan.upload_offset(f, off)
     plan.sync()
-    check_frames = sorted({0, B - 1})
+    check_frames = sorted({int(round(i * (B - 1) / 15)) for i in range(16)}) if B > 1 else [0]     # 16 frames spread over the batch
     check_vols = [frame_volume(f) for f in check_frames]
     del bases
     stages = STAGE_AGGREGATE | STAGE_WTA
@@ -377,6 +482,7 @@ def main():
             "sweep16par/nowrap": ("sweep_kernel<8,0> + sweep_kernel<8,1> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + wta_sweep_kernel<8>", True),
             "pairs16/nowrap": ("pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + pair_ckpt_kernel<8,1> + pair_sum_kernel<8,1,true>", False),
             "band16/nowrap": (f"band_kernel<8,0,8,{PATHS}> + band_kernel<8,2,8,{PATHS}>", False),
+            "band16chain/nowrap": (f"band_kernel<8,0,8,{PATHS}> + band_kernel<8,2,8,{PATHS}> (one workgroup per band and frame)", False),
         }.get(plan.kernel_name, ("agg_packed_kernel<128,false,true> + wta_packed_kernel<8>", True))
         stage_time_ms = agg_ms + (wta_ms if stage_kernels[1] else 0.0)
         achieved = alg_bytes_launch / (stage_time_ms * 1e-3) / 1e9
@@ -398,6 +504,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "aggregation stage: " + stage_kernels[0],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": bpv * B * W * H * D if bpv else None, "traffic_source": traffic_src,
+                         # the PMC figure is read from a committed profile, not measured in this run: it is this build's only if
+                         # the library hash recorded with it equals this run's
+                         "lib_sha16": lib_sha16(),
+                         "traffic_stale": (traffic_src is not None and traffic_src.get("lib_sha16") != lib_sha16()) if bpv else None,
                          # the rate at which that traffic moved; the same access patterns without arithmetic reach 5.1-5.6 TB/s
                          # (tools/ubench/pattern_rates.hip, profiles/r02_ubench_pattern_rates.txt)
                          "traffic_GBps": (bpv * B * W * H * D / (stage_time_ms * 1e-3) / 1e9) if bpv else None,

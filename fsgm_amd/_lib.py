@@ -57,6 +57,12 @@ def load():
     lib.fsgm_epi_params_default.restype = EpiParams
     lib.fsgm_calc_cost_sgm_host.argtypes = [C.POINTER(EpiIn), C.POINTER(EpiOut), C.POINTER(EpiParams)]
     lib.fsgm_calc_cost_sgm_batch_host.argtypes = [i32, C.POINTER(EpiIn), C.POINTER(EpiOut), C.POINTER(EpiParams)]
+    i32p = C.POINTER(C.c_int32)
+    lib.fsgm_calc_cost_sgm_batch_devices_host.argtypes = [i32, C.POINTER(EpiIn), C.POINTER(EpiOut), C.POINTER(EpiParams), i32, i32p]
+    lib.fsgm_parse_device_list.argtypes = [C.c_char_p, i32p, i32]
+    lib.fsgm_parse_device_list.restype = i32
+    lib.fsgm_shard_frames.argtypes = [i32, i32, i32, i32p, i32p]
+    lib.fsgm_shard_frames.restype = None
     lib.fsgm_epi_plan_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, C.POINTER(EpiParams)]
     lib.fsgm_epi_plan_destroy.argtypes = [vp]
     lib.fsgm_epi_plan_destroy.restype = None
@@ -91,6 +97,20 @@ def load():
 def check(status):
     if status != FSGM_OK:
         raise FsgmError(status, load().fsgm_last_error().decode())
+
+
+def device_array(devices):
+    """(count, int32 array) of a device list given as a sequence of ordinals or as text "0,1,2" (FSGM_DEVICES' format)."""
+    if isinstance(devices, str):
+        buf = (C.c_int32 * 1024)()
+        n = load().fsgm_parse_device_list(devices.encode(), buf, 1024)
+        if n <= 0:
+            raise ValueError(f"not a device list: {devices!r}")
+        return n, buf
+    devs = [int(d) for d in devices]
+    if not devs:
+        raise ValueError("empty device list")
+    return len(devs), (C.c_int32 * len(devs))(*devs)
 
 
 def ptr(a):

@@ -1,6 +1,7 @@
 // capi_common.h -- error plumbing shared by the C-ABI translation units
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include "../../include/fsgm.h"
@@ -28,6 +29,17 @@ inline fsgm_status fail(fsgm_status st, const char* fmt, ...) {
     do {                                                                 \
         if (!(cond)) return ::fsgm::fail(FSGM_ERR_INVALID, __VA_ARGS__); \
     } while (0)
+
+// The host-pointer entry points keep their cached plans / arenas PER DEVICE and hold that device's lock for the length of a
+// call: calls on different devices run side by side (fsgm_*_batch_devices_host starts one host thread per device of its
+// list), calls on one device take turns -- they would share the GPU anyway.
+constexpr int FSGM_MAX_DEVICES = 64;
+template <class T>
+struct PerDevice {
+    std::mutex mu[FSGM_MAX_DEVICES];
+    T v[FSGM_MAX_DEVICES];
+};
+#define FSGM_DEVICE_SLOT(dev) FSGM_REQUIRE((dev) >= 0 && (dev) < ::fsgm::FSGM_MAX_DEVICES, "device %d out of range", (int)(dev))
 
 // Scope guard for host-pointer entry points: work queued on `st` may still read the caller's input
 // buffers or write its output buffers (async copies), so every exit that is not the normal one

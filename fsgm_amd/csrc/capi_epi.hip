@@ -1033,10 +1033,10 @@ fsgm_status fsgm_measure_copy_bandwidth(int32_t device, size_t bytes, int32_t it
 // host-pointer entry points (the MEX boundary).  Plans are cached per shape for the lifetime of
 // the process so repeated MEX calls do not re-allocate HBM (SURVEY 8b "ownership").
 // ---------------------------------------------------------------------------------------------
-static std::mutex g_cache_mu;
-static std::vector<fsgm_epi_plan*> g_cache;
+static PerDevice<std::vector<fsgm_epi_plan*>> g_epi;            // cached plans per device, under that device's lock
 
 static fsgm_status cached_plan(fsgm_epi_plan** out, int W, int H, int D, int batch, const fsgm_epi_params& pr) {
+    std::vector<fsgm_epi_plan*>& g_cache = g_epi.v[pr.device];   // (the caller holds g_epi.mu[pr.device])
     for (fsgm_epi_plan* p : g_cache)
         if (p->W == W && p->H == H && p->D == D && p->batch == batch && p->prm.paths == pr.paths &&
             p->prm.device == pr.device && p->prm.fb_check == pr.fb_check) {
@@ -1068,9 +1068,11 @@ void fsgm_shutdown(void) {
     fsgm_post_shutdown_internal();
     fsgm_pyramid_shutdown_internal();
     fsgm_pyd_shutdown_internal();
-    std::lock_guard<std::mutex> lk(g_cache_mu);
-    for (fsgm_epi_plan* p : g_cache) fsgm_epi_plan_destroy(p);
-    g_cache.clear();
+    for (int d = 0; d < FSGM_MAX_DEVICES; d++) {
+        std::lock_guard<std::mutex> lk(g_epi.mu[d]);
+        for (fsgm_epi_plan* p : g_epi.v[d]) fsgm_epi_plan_destroy(p);
+        g_epi.v[d].clear();
+    }
 }
 
 fsgm_status fsgm_calc_cost_sgm_batch_host(int32_t n, const fsgm_epi_in* in, const fsgm_epi_out* out,
@@ -1085,7 +1087,8 @@ fsgm_status fsgm_calc_cost_sgm_batch_host(int32_t n, const fsgm_epi_in* in, cons
                      in[i].P1 == in[0].P1 && in[i].P2 == in[0].P2 && in[i].vMax == in[0].vMax,
                      "fsgm_calc_cost_sgm: frames of one batch must share shape and parameters (frame %d differs)", i);
     }
-    std::lock_guard<std::mutex> lk(g_cache_mu);
+    FSGM_DEVICE_SLOT(pr.device);
+    std::lock_guard<std::mutex> lk(g_epi.mu[pr.device]);
     fsgm_epi_plan* p = nullptr;
     fsgm_status st = cached_plan(&p, in[0].width, in[0].height, in[0].dMax, n, pr);
     if (st != FSGM_OK) return st;
@@ -1136,7 +1139,8 @@ fsgm_status fsgm_sgm_host(const uint8_t* C, int32_t W, int32_t H, int32_t D, int
     FSGM_REQUIRE(C && bestD && minC, "fsgm_sgm: null argument");
     fsgm_epi_params pr = fsgm_epi_params_default();
     pr.paths = paths; pr.device = device; pr.vz_to_disp = 0; pr.subpixel = 1;
-    std::lock_guard<std::mutex> lk(g_cache_mu);
+    FSGM_DEVICE_SLOT(device);
+    std::lock_guard<std::mutex> lk(g_epi.mu[device]);
     fsgm_epi_plan* p = nullptr;
     fsgm_status st = cached_plan(&p, W, H, D, 1, pr);
     if (st != FSGM_OK) return st;
@@ -1154,7 +1158,8 @@ fsgm_status fsgm_census_host(const uint8_t* img, int32_t W, int32_t H, uint32_t*
     FSGM_REQUIRE(W >= 1 && H >= 1, "width/height must be >= 1 (got %d x %d)", W, H);
     fsgm_epi_params pr = fsgm_epi_params_default();
     pr.device = device;
-    std::lock_guard<std::mutex> lk(g_cache_mu);
+    FSGM_DEVICE_SLOT(device);
+    std::lock_guard<std::mutex> lk(g_epi.mu[device]);
     fsgm_epi_plan* p = nullptr;
     fsgm_status st = cached_plan(&p, W, H, 16, 1, pr);           // any dMax: only the image / census buffers are used
     if (st != FSGM_OK) return st;
@@ -1193,7 +1198,8 @@ fsgm_status fsgm_epipolar_maps_host(const fsgm_epi_geometry* g, int32_t W, int32
     FSGM_REQUIRE(W >= 1 && H >= 1, "width/height must be >= 1 (got %d x %d)", W, H);
     fsgm_epi_params pr = fsgm_epi_params_default();
     pr.device = device;
-    std::lock_guard<std::mutex> lk(g_cache_mu);
+    FSGM_DEVICE_SLOT(device);
+    std::lock_guard<std::mutex> lk(g_epi.mu[device]);
     fsgm_epi_plan* p = nullptr;
     fsgm_status st = cached_plan(&p, W, H, 16, 1, pr);           // any dMax: only the map buffers are used
     if (st != FSGM_OK) return st;
@@ -1219,7 +1225,8 @@ fsgm_status fsgm_epipolar_sgm_of_host(const uint8_t* I0, const uint8_t* I1, int3
     FSGM_REQUIRE(channels == 1 || channels == 3, "channels must be 1 (gray) or 3 (RGB planes), got %d", channels);
     fsgm_epi_params pr = prm ? *prm : fsgm_epi_params_default();
     FSGM_REQUIRE(pr.vz_to_disp && !pr.fb_check, "fsgm_epipolar_sgm_of: the flow needs disparities (vz_to_disp = 1, fb_check = 0)");
-    std::lock_guard<std::mutex> lk(g_cache_mu);
+    FSGM_DEVICE_SLOT(pr.device);
+    std::lock_guard<std::mutex> lk(g_epi.mu[pr.device]);
     fsgm_epi_plan* p = nullptr;
     fsgm_status st = cached_plan(&p, W, H, dMax, 1, pr);
     if (st != FSGM_OK) return st;

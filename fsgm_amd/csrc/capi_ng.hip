@@ -23,10 +23,12 @@ struct NgPool {
     int small_calls = 0;               // consecutive calls that used at most a quarter of the arena
     hipStream_t stream = nullptr;
 };
-NgPool g_pool;
+NgPool g_pools[FSGM_MAX_DEVICES];      // one arena per device: calls on different devices run side by side
 
-struct DevBufs {                       // the arena for the duration of one call
-    std::unique_lock<std::mutex> lk{g_pool.mu};
+struct DevBufs {                       // the arena of `device` for the duration of one call
+    NgPool& g_pool;
+    std::unique_lock<std::mutex> lk;
+    explicit DevBufs(int device) : g_pool(g_pools[device]), lk(g_pools[device].mu) {}
     std::vector<std::pair<void**, size_t>> req;
     hipStream_t stream = nullptr;
     // Every exit drains the arena's stream before the pool mutex (declared first, released last) lets the next
@@ -61,7 +63,7 @@ fsgm_status pick_device(int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(FSGM_ERR_HIP, "no HIP device available (libfsgm_hip has no CPU fallback)");
-    FSGM_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+    FSGM_REQUIRE(device >= 0 && device < ndev && device < FSGM_MAX_DEVICES, "device %d out of range (have %d)", device, ndev);
     FSGM_HIP(hipSetDevice(device));
     return FSGM_OK;
 }
@@ -70,11 +72,13 @@ fsgm_status pick_device(int device) {
 extern "C" {
 
 void fsgm_ng_shutdown_internal(void) {
-    std::lock_guard<std::mutex> lk(g_pool.mu);
-    if (g_pool.device >= 0) (void)hipSetDevice(g_pool.device);
-    if (g_pool.base) (void)hipFree(g_pool.base);
-    if (g_pool.stream) (void)hipStreamDestroy(g_pool.stream);
-    g_pool.base = nullptr; g_pool.cap = 0; g_pool.stream = nullptr; g_pool.device = -1;
+    for (NgPool& g_pool : g_pools) {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        if (g_pool.device >= 0) (void)hipSetDevice(g_pool.device);
+        if (g_pool.base) (void)hipFree(g_pool.base);
+        if (g_pool.stream) (void)hipStreamDestroy(g_pool.stream);
+        g_pool.base = nullptr; g_pool.cap = 0; g_pool.stream = nullptr; g_pool.device = -1;
+    }
 }
 
 fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in, const fsgm_ng_out* out, int32_t device) {
@@ -98,7 +102,7 @@ fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in
     fsgm_status st = pick_device(device);
     if (st != FSGM_OK) return st;
     const size_t NP = (size_t)W * H, MV = (size_t)a.mvWidth * a.mvHeight, N = NP * D, B = n;
-    DevBufs d;
+    DevBufs d(device);
     uint8_t *dI1, *dI2, *dDk; uint16_t *dDd, *dCm; uint32_t* dCk; uint32_t *dCen1, *dCen2, *dS, *dMinC, *dUnsafe, *dBox, *dKstat; double *dMv, *dFlow; Cand* dC;
     d.want((void**)&dUnsafe, 4);
     d.want((void**)&dI1, B * NP);
@@ -178,7 +182,7 @@ fsgm_status fsgm_calc_cost_sgm_ng_batch_host(int32_t n, const fsgm_otf_in* in, c
     fsgm_status st = pick_device(device);
     if (st != FSGM_OK) return st;
     const size_t NP = (size_t)W * H, B = n, rowE = (size_t)W * OTF_E;
-    DevBufs d;
+    DevBufs d(device);
     uint8_t *dI1, *dI2; uint32_t *dCen1, *dCen2, *dMinC; double* dFlow; int32_t* dRnd; Cand* dLrow;
     d.want((void**)&dI1, B * NP);
     d.want((void**)&dI2, B * NP);

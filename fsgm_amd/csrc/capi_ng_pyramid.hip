@@ -246,19 +246,22 @@ fsgm_status fsgm_ng_pyramid_plan_time(fsgm_ng_pyramid_plan* p, int32_t warmup, i
 }
 
 // ---- host-pointer entry point: one call = the whole loop; plans are cached per shape like fsgm_pyramidal_sgm_host's ----
-static std::mutex g_ngpyr_mu;
-static std::vector<fsgm_ng_pyramid_plan*> g_ngpyr_cache;
+static PerDevice<std::vector<fsgm_ng_pyramid_plan*>> g_ngpyr;   // cached plans per device, under that device's lock
 
 void fsgm_ng_pyramid_shutdown_internal(void) {
-    std::lock_guard<std::mutex> lk(g_ngpyr_mu);
-    for (fsgm_ng_pyramid_plan* p : g_ngpyr_cache) fsgm_ng_pyramid_plan_destroy(p);
-    g_ngpyr_cache.clear();
+    for (int d = 0; d < FSGM_MAX_DEVICES; d++) {
+        std::lock_guard<std::mutex> lk(g_ngpyr.mu[d]);
+        for (fsgm_ng_pyramid_plan* p : g_ngpyr.v[d]) fsgm_ng_pyramid_plan_destroy(p);
+        g_ngpyr.v[d].clear();
+    }
 }
 
 fsgm_status fsgm_pyramidal_sgm_ng_host(const uint8_t* I0, const uint8_t* I1, int32_t width, int32_t height, int32_t channels,
                                        const fsgm_ng_pyramid_params* prm, double* flow, uint32_t* minC, double* const* flowPyd) {
     FSGM_REQUIRE(I0 && I1 && prm && flow, "fsgm_pyramidal_sgm_ng: null argument");
-    std::lock_guard<std::mutex> lk(g_ngpyr_mu);
+    FSGM_DEVICE_SLOT(prm->device);
+    std::lock_guard<std::mutex> lk(g_ngpyr.mu[prm->device]);
+    std::vector<fsgm_ng_pyramid_plan*>& g_ngpyr_cache = g_ngpyr.v[prm->device];
     fsgm_ng_pyramid_plan* p = nullptr;
     for (fsgm_ng_pyramid_plan* q : g_ngpyr_cache)
         if (q->W == width && q->H == height && q->channels == channels && q->batch == 1 && memcmp(&q->prm, prm, sizeof *prm) == 0) p = q;

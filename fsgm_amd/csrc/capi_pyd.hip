@@ -243,13 +243,14 @@ fsgm_status fsgm_pyd_plan_time(fsgm_pyd_plan* p, int32_t stages, int32_t warmup,
 }
 
 // ---- host-pointer entry points (the calc_pyd_cost_sgm gateway) ----
-static std::mutex g_pyd_mu;
-static std::vector<fsgm_pyd_plan*> g_pyd_cache;
+static PerDevice<std::vector<fsgm_pyd_plan*>> g_pyd;            // cached plans per device, under that device's lock
 
 void fsgm_pyd_shutdown_internal(void) {
-    std::lock_guard<std::mutex> lk(g_pyd_mu);
-    for (fsgm_pyd_plan* p : g_pyd_cache) fsgm_pyd_plan_destroy(p);
-    g_pyd_cache.clear();
+    for (int d = 0; d < FSGM_MAX_DEVICES; d++) {
+        std::lock_guard<std::mutex> lk(g_pyd.mu[d]);
+        for (fsgm_pyd_plan* p : g_pyd.v[d]) fsgm_pyd_plan_destroy(p);
+        g_pyd.v[d].clear();
+    }
 }
 
 fsgm_status fsgm_calc_pyd_cost_sgm_batch_host(int32_t n, const fsgm_pyd_in* in, const fsgm_pyd_out* out, int32_t device) {
@@ -266,7 +267,9 @@ fsgm_status fsgm_calc_pyd_cost_sgm_batch_host(int32_t n, const fsgm_pyd_in* in, 
                      b.adpativeP2 == a.adpativeP2,
                      "frames of one batch must share shape and parameters (frame %d differs)", i);
     }
-    std::lock_guard<std::mutex> lk(g_pyd_mu);
+    FSGM_DEVICE_SLOT(device);
+    std::lock_guard<std::mutex> lk(g_pyd.mu[device]);
+    std::vector<fsgm_pyd_plan*>& g_pyd_cache = g_pyd.v[device];
     fsgm_pyd_plan* p = nullptr;
     for (fsgm_pyd_plan* q : g_pyd_cache)
         if (q->W == a.width && q->H == a.height && q->mvW == a.mvWidth && q->mvH == a.mvHeight &&

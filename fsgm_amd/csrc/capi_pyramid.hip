@@ -212,15 +212,21 @@ fsgm_status fsgm_pyramid_plan_download_frame(fsgm_pyramid_plan* p, int32_t frame
     return FSGM_OK;
 }
 
-fsgm_status fsgm_pyramid_plan_download_gray(fsgm_pyramid_plan* p, int32_t level, uint8_t* g0, uint8_t* g1) {
+fsgm_status fsgm_pyramid_plan_download_gray_frame(fsgm_pyramid_plan* p, int32_t frame, int32_t level, uint8_t* g0, uint8_t* g1) {
     FSGM_REQUIRE(p, "null plan");
     FSGM_REQUIRE(level >= 1 && level <= p->prm.numPyd, "level %d out of range 1..%d", level, p->prm.numPyd);
+    FSGM_REQUIRE(frame >= 0 && frame < p->batch, "frame %d out of range (batch %d)", frame, p->batch);
     FSGM_HIP(hipSetDevice(p->device));
     FSGM_HIP(hipStreamSynchronize(p->stream));
     const fsgm_pyd_plan* q = p->lv[level - 1];
-    if (g0) FSGM_HIP(hipMemcpy(g0, q->dI1, q->NP, hipMemcpyDeviceToHost));
-    if (g1) FSGM_HIP(hipMemcpy(g1, q->dI2, q->NP, hipMemcpyDeviceToHost));
+    const size_t o = (size_t)frame * q->NP;
+    if (g0) FSGM_HIP(hipMemcpy(g0, q->dI1 + o, q->NP, hipMemcpyDeviceToHost));
+    if (g1) FSGM_HIP(hipMemcpy(g1, q->dI2 + o, q->NP, hipMemcpyDeviceToHost));
     return FSGM_OK;
+}
+
+fsgm_status fsgm_pyramid_plan_download_gray(fsgm_pyramid_plan* p, int32_t level, uint8_t* g0, uint8_t* g1) {
+    return fsgm_pyramid_plan_download_gray_frame(p, 0, level, g0, g1);
 }
 
 fsgm_status fsgm_pyramid_plan_time(fsgm_pyramid_plan* p, int32_t warmup, int32_t iters, float* ms_avg) {
@@ -241,19 +247,22 @@ fsgm_status fsgm_pyramid_plan_time(fsgm_pyramid_plan* p, int32_t warmup, int32_t
 }
 
 // ---- host-pointer entry point: one call = pyramidal_sgm(I0, I1, numPyd) ----
-static std::mutex g_pyr_mu;
-static std::vector<fsgm_pyramid_plan*> g_pyr_cache;
+static PerDevice<std::vector<fsgm_pyramid_plan*>> g_pyr;        // cached plans per device, under that device's lock
 
 void fsgm_pyramid_shutdown_internal(void) {
-    std::lock_guard<std::mutex> lk(g_pyr_mu);
-    for (fsgm_pyramid_plan* p : g_pyr_cache) fsgm_pyramid_plan_destroy(p);
-    g_pyr_cache.clear();
+    for (int d = 0; d < FSGM_MAX_DEVICES; d++) {
+        std::lock_guard<std::mutex> lk(g_pyr.mu[d]);
+        for (fsgm_pyramid_plan* p : g_pyr.v[d]) fsgm_pyramid_plan_destroy(p);
+        g_pyr.v[d].clear();
+    }
 }
 
 fsgm_status fsgm_pyramidal_sgm_host(const uint8_t* I0, const uint8_t* I1, int32_t width, int32_t height, int32_t channels,
                                     const fsgm_pyramid_params* prm, double* mv, uint32_t* minC, double* const* mvPyd) {
     FSGM_REQUIRE(I0 && I1 && prm && mv, "fsgm_pyramidal_sgm: null argument");
-    std::lock_guard<std::mutex> lk(g_pyr_mu);
+    FSGM_DEVICE_SLOT(prm->device);
+    std::lock_guard<std::mutex> lk(g_pyr.mu[prm->device]);
+    std::vector<fsgm_pyramid_plan*>& g_pyr_cache = g_pyr.v[prm->device];
     fsgm_pyramid_plan* p = nullptr;
     for (fsgm_pyramid_plan* q : g_pyr_cache)
         if (q->W == width && q->H == height && q->channels == channels && q->batch == 1 && memcmp(&q->prm, prm, sizeof *prm) == 0) p = q;

@@ -39,8 +39,12 @@ def auto_pipeline(width, height, dMax, batch, paths=4, P1=6, P2=64, cmax=24, cus
 
 
 def calc_cost_sgm_batch(frames, dMax, vMax, P1, P2, *, paths=4, subpixel=1, vz_to_disp=1, device=0,
-                        return_volumes=False, fb_check=0):
-    """frames: list of (I1, I2, pixelPosD0, normDir, offset) of one shape, processed concurrently."""
+                        return_volumes=False, fb_check=0, devices=None):
+    """frames: list of (I1, I2, pixelPosD0, normDir, offset) of one shape, processed concurrently.
+
+    devices: a device list (sequence of HIP ordinals, or text "0,1,2" like FSGM_DEVICES) -- frame i runs on
+    devices[i % len(devices)], one host thread per entry inside the library, no collective
+    (fsgm_calc_cost_sgm_batch_devices_host); `device` is ignored then.  Results do not depend on the list."""
     lib = _lib.load()
     n = len(frames)
     if n == 0:
@@ -70,7 +74,11 @@ def calc_cost_sgm_batch(frames, dMax, vMax, P1, P2, *, paths=4, subpixel=1, vz_t
         r = (bestD, minC, Cv, Sv) if return_volumes else (bestD, minC)
         res.append(r + (conf, bestD2) if fb_check else r)
     prm = _params(paths, subpixel, vz_to_disp, device, fb_check)
-    check(lib.fsgm_calc_cost_sgm_batch_host(n, ins, outs, C.byref(prm)))
+    if devices is not None:
+        nd, darr = _lib.device_array(devices)
+        check(lib.fsgm_calc_cost_sgm_batch_devices_host(n, ins, outs, C.byref(prm), nd, darr))
+    else:
+        check(lib.fsgm_calc_cost_sgm_batch_host(n, ins, outs, C.byref(prm)))
     return res
 
 

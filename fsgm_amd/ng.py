@@ -40,6 +40,8 @@ def _bind(lib):
     lib.fsgm_calc_cost_sgm_ng_host.argtypes = [C.POINTER(OtfIn), C.POINTER(OtfOut), C.c_int32]
     lib.fsgm_calc_pyd_cost_sgm_ng_batch_host.argtypes = [C.c_int32, C.POINTER(NgIn), C.POINTER(NgOut), C.c_int32]
     lib.fsgm_calc_cost_sgm_ng_batch_host.argtypes = [C.c_int32, C.POINTER(OtfIn), C.POINTER(OtfOut), C.c_int32]
+    lib.fsgm_calc_pyd_cost_sgm_ng_batch_devices_host.argtypes = [C.c_int32, C.POINTER(NgIn), C.POINTER(NgOut), C.c_int32, C.POINTER(C.c_int32)]
+    lib.fsgm_calc_cost_sgm_ng_batch_devices_host.argtypes = [C.c_int32, C.POINTER(OtfIn), C.POINTER(OtfOut), C.c_int32, C.POINTER(C.c_int32)]
     lib.fsgm_sgm_ng_rand_draws.argtypes = [C.c_int32, C.c_int32]
     lib.fsgm_sgm_ng_rand_draws.restype = C.c_int64
     lib._ng_bound = True
@@ -106,9 +108,9 @@ def calc_cost_sgm_ng(I1, I2, preMv=None, halfSearchWinSize=1, aggSize=2, subPixe
     return minC, flow
 
 
-def calc_pyd_cost_sgm_ng_batch(frames, halfSearchWinSize, aggSize, subPixelRefine, P1, P2, *, device=0):
+def calc_pyd_cost_sgm_ng_batch(frames, halfSearchWinSize, aggSize, subPixelRefine, P1, P2, *, device=0, devices=None):
     """frames: list of (I1, I2, preMv) of one shape; one launch sequence for all of them.
-    Returns a list of (minC, flow)."""
+    Returns a list of (minC, flow).  devices: a device list (frame i on devices[i % len], fsgm_amd.calc_cost_sgm_batch)."""
     lib = _lib.load()
     _bind(lib)
     n = len(frames)
@@ -127,11 +129,15 @@ def calc_pyd_cost_sgm_ng_batch(frames, halfSearchWinSize, aggSize, subPixelRefin
         outs[i].minC, outs[i].flow, outs[i].S = ptr(minC), ptr(flow), None
         keep.append((I1, I2, preMv))
         res.append((minC, flow))
-    check(lib.fsgm_calc_pyd_cost_sgm_ng_batch_host(n, ins, outs, int(device)))
+    if devices is not None:
+        nd, darr = _lib.device_array(devices)
+        check(lib.fsgm_calc_pyd_cost_sgm_ng_batch_devices_host(n, ins, outs, nd, darr))
+    else:
+        check(lib.fsgm_calc_pyd_cost_sgm_ng_batch_host(n, ins, outs, int(device)))
     return res
 
 
-def calc_cost_sgm_ng_batch(frames, P1=6, P2=32, *, device=0):
+def calc_cost_sgm_ng_batch(frames, P1=6, P2=32, *, device=0, devices=None):
     """frames: list of (I1, I2, rand_stream) of one shape (rand_stream as for calc_cost_sgm_ng, not None:
     frames of a batch run side by side, so there is no 'order of draws' between them).  Returns a list of (minC, flow)."""
     lib = _lib.load()
@@ -150,5 +156,9 @@ def calc_cost_sgm_ng_batch(frames, P1=6, P2=32, *, device=0):
         outs[i].minC, outs[i].flow = ptr(minC), ptr(flow)
         keep.append((I1, I2, rs))
         res.append((minC, flow))
-    check(lib.fsgm_calc_cost_sgm_ng_batch_host(n, ins, outs, int(device)))
+    if devices is not None:
+        nd, darr = _lib.device_array(devices)
+        check(lib.fsgm_calc_cost_sgm_ng_batch_devices_host(n, ins, outs, nd, darr))
+    else:
+        check(lib.fsgm_calc_cost_sgm_ng_batch_host(n, ins, outs, int(device)))
     return res

@@ -28,6 +28,7 @@ def _bind(lib):
     vp, i32 = C.c_void_p, C.c_int32
     lib.fsgm_calc_pyd_cost_sgm_host.argtypes = [C.POINTER(PydIn), C.POINTER(PydOut), i32]
     lib.fsgm_calc_pyd_cost_sgm_batch_host.argtypes = [i32, C.POINTER(PydIn), C.POINTER(PydOut), i32]
+    lib.fsgm_calc_pyd_cost_sgm_batch_devices_host.argtypes = [i32, C.POINTER(PydIn), C.POINTER(PydOut), i32, C.POINTER(i32)]
     lib.fsgm_pyd_plan_create.argtypes = [C.POINTER(vp)] + [i32] * 9
     lib.fsgm_pyd_plan_destroy.argtypes = [vp]
     lib.fsgm_pyd_plan_destroy.restype = None
@@ -84,6 +85,39 @@ def calc_pyd_cost_sgm(I1, I2, preMv, halfSearchWinSizeX, halfSearchWinSizeY, agg
     o.bestD, o.minC, o.mvSub, o.C, o.S = ptr(bestD), ptr(minC), ptr(mvSub), ptr(Cv), ptr(S)
     check(lib.fsgm_calc_pyd_cost_sgm_host(C.byref(a), C.byref(o), int(device)))
     return (bestD, minC, mvSub, Cv, S) if return_volumes else (bestD, minC, mvSub)
+
+
+def calc_pyd_cost_sgm_batch(frames, halfSearchWinSizeX, halfSearchWinSizeY, aggHalfWinSize, subPixelRefine,
+                            P1, P2, enableDiagnalPath, totalPass, adpativeP2, *, device=0, devices=None):
+    """frames: list of (I1, I2, preMv) of one shape and one parameter set, processed together; returns a list of
+    (bestD, minC, mvSub).  devices: a device list -- frame i runs on devices[i % len(devices)], one host thread per entry
+    inside the library, no collective (fsgm_calc_pyd_cost_sgm_batch_devices_host)."""
+    lib = _lib.load()
+    _bind(lib)
+    n = len(frames)
+    if n == 0:
+        return []
+    ins, outs, keep, res = (PydIn * n)(), (PydOut * n)(), [], []
+    for i, (I1, I2, preMv) in enumerate(frames):
+        I1, I2, preMv = _check_inputs(I1, I2, preMv)
+        H, W = I1.shape
+        a = ins[i]
+        a.I1, a.I2, a.width, a.height = ptr(I1), ptr(I2), W, H
+        a.preMv, a.mvWidth, a.mvHeight = ptr(preMv), preMv.shape[2], preMv.shape[1]
+        a.halfSearchWinSizeX, a.halfSearchWinSizeY, a.aggHalfWinSize = int(halfSearchWinSizeX), int(halfSearchWinSizeY), int(aggHalfWinSize)
+        a.subPixelRefine, a.P1, a.P2 = int(subPixelRefine), int(P1), int(P2)
+        a.enableDiagnalPath, a.totalPass, a.adpativeP2 = int(bool(enableDiagnalPath)), int(totalPass), int(bool(adpativeP2))
+        bestD, minC, mvSub = np.zeros((H, W), np.uint32), np.zeros((H, W), np.uint32), np.zeros((2, H, W), np.float64)
+        o = outs[i]
+        o.bestD, o.minC, o.mvSub, o.C, o.S = ptr(bestD), ptr(minC), ptr(mvSub), None, None
+        keep.append((I1, I2, preMv))
+        res.append((bestD, minC, mvSub))
+    if devices is not None:
+        nd, darr = _lib.device_array(devices)
+        check(lib.fsgm_calc_pyd_cost_sgm_batch_devices_host(n, ins, outs, nd, darr))
+    else:
+        check(lib.fsgm_calc_pyd_cost_sgm_batch_host(n, ins, outs, int(device)))
+    return res
 
 
 class PydPlan:

@@ -35,6 +35,7 @@ def _bind(lib):
     lib.fsgm_pyramid_plan_sync.argtypes = [vp]
     lib.fsgm_pyramid_plan_download.argtypes = [vp, i32, vp, vp]
     lib.fsgm_pyramid_plan_download_gray.argtypes = [vp, i32, vp, vp]
+    lib.fsgm_pyramid_plan_download_gray_frame.argtypes = [vp, i32, i32, vp, vp]
     lib.fsgm_pyramid_plan_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
     lib._pyramid_bound = True
 
@@ -76,6 +77,47 @@ def pyramidal_sgm(I0, I1, numPyd=5, *, device=0, **overrides):
     ptrs = (C.c_void_p * len(mvPyd))(*[a.ctypes.data for a in mvPyd])
     check(lib.fsgm_pyramidal_sgm_host(ptr(I0), ptr(I1), W, H, ch, C.byref(prm), ptr(mv), ptr(minC), ptrs))
     return mv, mvPyd, minC
+
+
+class PyramidPair(C.Structure):
+    _fields_ = [("I0", C.c_void_p), ("I1", C.c_void_p), ("mv", C.c_void_p), ("minC", C.c_void_p), ("mvPyd", C.c_void_p)]
+
+
+def _pairs_over_devices(fn, prm, pairs, devices):
+    """pairs of one shape through fsgm_pyramidal_sgm(_ng)_batch_devices_host: pair i on devices[i % len(devices)]."""
+    n = len(pairs)
+    arr, keep, res = (PyramidPair * n)(), [], []
+    shape = None
+    for i, (I0, I1) in enumerate(pairs):
+        I0, I1, ch = _check_images(I0, I1)
+        H, W = I0.shape[-2:]
+        if shape not in (None, (W, H, ch)):
+            raise ValueError("all pairs of a batch must share one shape")
+        shape = (W, H, ch)
+        sizes = [(W, H)]
+        for _ in range(1, prm.numPyd):
+            sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+        mv, minC = np.zeros((2, H, W), np.float64), np.zeros((H, W), np.uint32)
+        lv = [np.zeros((2, h, w), np.float64) for (w, h) in sizes]
+        ptrs = (C.c_void_p * len(lv))(*[a.ctypes.data for a in lv])
+        arr[i].I0, arr[i].I1, arr[i].mv, arr[i].minC = ptr(I0), ptr(I1), ptr(mv), ptr(minC)
+        arr[i].mvPyd = C.cast(ptrs, C.c_void_p)
+        keep.append((I0, I1, ptrs))
+        res.append((mv, lv, minC))
+    nd, darr = _lib.device_array(devices)
+    W, H, ch = shape
+    check(fn(n, arr, W, H, ch, C.byref(prm), nd, darr))
+    return res
+
+
+def pyramidal_sgm_batch(pairs, numPyd=5, *, devices=(0,), **overrides):
+    """pyramidal_sgm for a list of (I0, I1) pairs of one shape, pair i on devices[i % len(devices)] (one host thread per
+    entry inside the library, no collective); returns a list of (mvCurLevel, mvPyd, minC) like pyramidal_sgm."""
+    lib = _lib.load()
+    _bind(lib)
+    lib.fsgm_pyramidal_sgm_batch_devices_host.argtypes = [C.c_int32, C.POINTER(PyramidPair), C.c_int32, C.c_int32, C.c_int32,
+                                                          C.POINTER(PyramidParams), C.c_int32, C.POINTER(C.c_int32)]
+    return _pairs_over_devices(lib.fsgm_pyramidal_sgm_batch_devices_host, _params(lib, numPyd, 0, overrides), pairs, devices)
 
 
 class PyramidPlan:
@@ -135,11 +177,11 @@ class PyramidPlan:
         check(self.lib.fsgm_pyramid_plan_download_frame(self._h, int(frame), int(level), ptr(mv), ptr(minC)))
         return mv, minC
 
-    def download_gray(self, level=1):
-        """The gray image pair calc_pyd_cost_sgm saw at `level` (after impyramid / rgb2gray)."""
+    def download_gray(self, level=1, frame=0):
+        """The gray image pair calc_pyd_cost_sgm saw at `level` (after impyramid / rgb2gray), of pair `frame` of the batch."""
         w, h = self.level_size(level)
         g0, g1 = np.empty((h, w), np.uint8), np.empty((h, w), np.uint8)
-        check(self.lib.fsgm_pyramid_plan_download_gray(self._h, int(level), ptr(g0), ptr(g1)))
+        check(self.lib.fsgm_pyramid_plan_download_gray_frame(self._h, int(frame), int(level), ptr(g0), ptr(g1)))
         return g0, g1
 
     def time(self, warmup=1, iters=5):
@@ -233,6 +275,22 @@ class NgPyramidPlan:
         ms = C.c_float()
         check(self.lib.fsgm_ng_pyramid_plan_time(self._h, int(warmup), int(iters), C.byref(ms)))
         return float(ms.value)
+
+
+def pyramidal_sgm_ng_batch(pairs, numPyd=3, *, devices=(0,), **overrides):
+    """pyramidal_sgm_ng for a list of (I0, I1) pairs of one shape, pair i on devices[i % len(devices)]; returns a list of
+    (flow of level 1, [flow per level], minC of level 1) like pyramidal_sgm_ng."""
+    lib = _lib.load()
+    _bind_ng(lib)
+    lib.fsgm_pyramidal_sgm_ng_batch_devices_host.argtypes = [C.c_int32, C.POINTER(PyramidPair), C.c_int32, C.c_int32, C.c_int32,
+                                                             C.POINTER(NgPyramidParams), C.c_int32, C.POINTER(C.c_int32)]
+    prm = lib.fsgm_ng_pyramid_params_default()
+    prm.numPyd = int(numPyd)
+    for k, v in overrides.items():
+        if not hasattr(prm, k):
+            raise TypeError(f"unknown pyramidal_sgm_ng parameter {k!r}")
+        setattr(prm, k, int(v))
+    return _pairs_over_devices(lib.fsgm_pyramidal_sgm_ng_batch_devices_host, prm, pairs, devices)
 
 
 def pyramidal_sgm_ng(I0, I1, numPyd=3, *, device=0, **overrides):

@@ -117,8 +117,18 @@ fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t
  * 4 = the band sweeps (epi_band.hip: all four paths of a raster pass in one sweep, one workgroup per frame, for batches of
  * hundreds of frames; D = 16<<k, no-wrap penalties with P1 <= P2, P1 + P2 <= 127), 5 = the band sweeps with the bands of a
  * frame as workgroups of their own that hand their last row over while they run ("band16chain/nowrap").
- * Auto, 8 paths: line kernels below 5 frames, 3 below 18, 2 from there; 4 paths: line kernels below 9 frames, then 2
- * (the measured crossovers at 1242x375x128).  Results are identical. */
+ * Auto picks by batch size, frame shape and path count; fsgm_epi_auto_pipeline() below answers for any configuration and
+ * fsgm_epi_plan_kernel_name() for a plan.  At 1242x375x128, 256 CUs: 8 paths -- line kernels below 4 frames, 3 below 18, 2 up
+ * to ~229, then 4 where a round of one workgroup per frame pays (230-256, 473-512, ...) and 5 between those rounds; 4 paths --
+ * line kernels below 9 frames, then 2, then 4 / 5 likewise.  The switch points move with the frame shape by voxels^(-2/3)
+ * (FSGM_EPI_SHAPE_SCALE).  Results are identical in every mode.
+ * HBM a plan holds per frame beyond C (allocated when a mode first runs, kept until the plan is destroyed; N = W*H*D bytes):
+ * mode 1: paths x N (path volumes); mode 2: 2 N + N/8 + boundary states (8 paths) / N + 2 N/8 (4 paths); mode 3: one more N;
+ * modes 4, 5: N + N/4 (9th-bit plane, 8 paths only) + one hand-off map of 3*W*D bytes (mode 5: one per band boundary,
+ * ~1.4 B per voxel at 1242x375x128), + 10 bytes per pixel of WTA records for modes 2-5.  Mode 5 synchronises its
+ * workgroups through bounded polls on device memory; a poll that gives up raises a flag that fsgm_epi_plan_sync / _download /
+ * _time report as FSGM_ERR_HIP.  The cost stage's own buffers (images, census, coordinate maps) appear with the first upload
+ * or FSGM_STAGE_COST run: an aggregation-only plan never allocates them. */
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* plan, int32_t mode);
 /* host -> HBM (async on the plan's stream) */
 fsgm_status fsgm_epi_plan_upload(fsgm_epi_plan* plan, int32_t frame, const uint8_t* I1,
@@ -317,7 +327,8 @@ fsgm_status fsgm_pyramid_plan_run_images(fsgm_pyramid_plan* plan);
 /* HBM -> host (synchronous): flow and/or minC of one level; either pointer may be NULL */
 fsgm_status fsgm_pyramid_plan_download(fsgm_pyramid_plan* plan, int32_t level, double* mv, uint32_t* minC);
 /* debug tap: the gray images calc_pyd_cost_sgm saw at one level (after impyramid and rgb2gray), u8 [H_l][W_l] */
-fsgm_status fsgm_pyramid_plan_download_gray(fsgm_pyramid_plan* plan, int32_t level, uint8_t* gray0, uint8_t* gray1);
+fsgm_status fsgm_pyramid_plan_download_gray(fsgm_pyramid_plan* plan, int32_t level, uint8_t* gray0, uint8_t* gray1);   /* frame 0 */
+fsgm_status fsgm_pyramid_plan_download_gray_frame(fsgm_pyramid_plan* plan, int32_t frame, int32_t level, uint8_t* gray0, uint8_t* gray1);
 /* average milliseconds of one whole pyramid run (HIP events on the plan's stream) */
 fsgm_status fsgm_pyramid_plan_time(fsgm_pyramid_plan* plan, int32_t warmup, int32_t iters, float* ms_avg);
 
@@ -465,6 +476,50 @@ int64_t     fsgm_sgm_ng_rand_draws(int32_t width, int32_t height);
 fsgm_status fsgm_calc_cost_sgm_ng_host(const fsgm_otf_in* in, const fsgm_otf_out* out, int32_t device);
 fsgm_status fsgm_calc_cost_sgm_ng_batch_host(int32_t n_frames, const fsgm_otf_in* in,
                                              const fsgm_otf_out* out, int32_t device);
+
+/* ------------------------------------------------------------------------------------------
+ * Device lists: a batch over several GPUs of one node from ONE process  (SURVEY 8(b) "batch variants", 8(e);
+ * north_star: the host stays MATLAB -- one process -- and a batch of frames shards across the 8 GPUs of a node).
+ *
+ * Frame i of the batch runs on devices[i % n_devices]; every list entry gets a host thread of its own that runs its frames
+ * through the single-device batch call above (own cached plan, own stream); nothing is exchanged between devices -- frames
+ * are independent (calc_cost_sgm.cpp has no state across calls), so there is no collective and no peer copy.  Entries are HIP
+ * ordinals taken modulo the number of devices present: {0,1,...,7} is valid on any box, on a one-GPU box all entries share the
+ * device and take turns.  Results are identical to single calls whatever the list.  Errors: the first failing entry's status
+ * and message, prefixed with the entry.  The MEX gateway calc_cost_sgm takes its list from FSGM_DEVICES=0,1,... when it is
+ * handed a batch.
+ * ------------------------------------------------------------------------------------------ */
+fsgm_status fsgm_calc_cost_sgm_batch_devices_host(int32_t n_frames, const fsgm_epi_in* in, const fsgm_epi_out* out,
+                                                  const fsgm_epi_params* prm /* device field ignored */,
+                                                  int32_t n_devices, const int32_t* devices);
+fsgm_status fsgm_calc_pyd_cost_sgm_batch_devices_host(int32_t n_frames, const fsgm_pyd_in* in, const fsgm_pyd_out* out,
+                                                      int32_t n_devices, const int32_t* devices);
+fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_devices_host(int32_t n_frames, const fsgm_ng_in* in, const fsgm_ng_out* out,
+                                                         int32_t n_devices, const int32_t* devices);
+/* frames whose rand_stream is NULL get their libc rand() draws on the calling thread, in frame order, before they scatter:
+ * the draws a sequence of single calls would have made (calc_cost_sgm_ng.cpp:148-149) */
+fsgm_status fsgm_calc_cost_sgm_ng_batch_devices_host(int32_t n_frames, const fsgm_otf_in* in, const fsgm_otf_out* out,
+                                                     int32_t n_devices, const int32_t* devices);
+/* image pairs through the pyramidal drivers: arguments per pair as fsgm_pyramidal_sgm_host / fsgm_pyramidal_sgm_ng_host take them */
+typedef struct {
+    const uint8_t* I0;
+    const uint8_t* I1;
+    double*   mv;                 /* level-1 flow f64 [2][H][W] */
+    uint32_t* minC;               /* may be NULL */
+    double* const* mvPyd;         /* may be NULL: numPyd pointers, per-level flows */
+} fsgm_pyramid_pair;
+fsgm_status fsgm_pyramidal_sgm_batch_devices_host(int32_t n_pairs, const fsgm_pyramid_pair* pairs, int32_t width, int32_t height,
+                                                  int32_t channels, const fsgm_pyramid_params* prm /* device field ignored */,
+                                                  int32_t n_devices, const int32_t* devices);
+fsgm_status fsgm_pyramidal_sgm_ng_batch_devices_host(int32_t n_pairs, const fsgm_pyramid_pair* pairs, int32_t width, int32_t height,
+                                                     int32_t channels, const fsgm_ng_pyramid_params* prm /* device field ignored */,
+                                                     int32_t n_devices, const int32_t* devices);
+/* "0,1,2" (commas, semicolons or blanks) -> devices[]; returns the number of entries, 0 for an empty / NULL text, -1 for anything
+ * that is not a list of non-negative integers */
+int32_t fsgm_parse_device_list(const char* text, int32_t* devices, int32_t max_devices);
+/* the partition itself, for callers that want to know it: the frames of entry `slot` of a list of n_devices entries
+ * (frames may be NULL to get the count only) */
+void fsgm_shard_frames(int32_t n_frames, int32_t n_devices, int32_t slot, int32_t* frames, int32_t* count);
 
 #ifdef __cplusplus
 }

@@ -157,3 +157,33 @@ def test_box_mean_as_one_fp16_multiply():
     assert np.float16(0.04).view(np.uint16) == 0x291F
     np.testing.assert_array_equal(got, ((2 * s.astype(np.int64) + 25) // 50).astype(np.uint16))
     np.testing.assert_array_equal(got[:601], (1.0 * s[:601] / 25 + 0.5).astype(np.uint8))
+
+
+def test_device_list_helpers():
+    """fsgm_parse_device_list / fsgm_shard_frames (include/fsgm.h "Device lists"): the text format of FSGM_DEVICES and the
+    partition frame i -> entry i mod n -- the same round-robin as fsgm_amd.batch.shard_indices uses across processes."""
+    import ctypes as C
+    from fsgm_amd.batch import shard_indices
+    lib = _lib.load()
+    buf = (C.c_int32 * 16)()
+    for text, want in (("0,1,2", [0, 1, 2]), (" 3 ; 1,,7 ", [3, 1, 7]), ("0", [0]), ("", []), ("0,0", [0, 0])):
+        n = lib.fsgm_parse_device_list(text.encode(), buf, 16)
+        assert n == len(want) and list(buf[:n]) == want
+    for text in ("0,x", "-1", "1.5", "a"):
+        assert lib.fsgm_parse_device_list(text.encode(), buf, 16) == -1
+    assert lib.fsgm_parse_device_list(b"0,1,2,3", buf, 2) == 2              # never writes past max_devices
+    for n_frames, n_dev in ((8, 2), (8, 8), (7, 3), (3, 5), (0, 2), (1, 1)):
+        seen = []
+        for slot in range(n_dev):
+            out, cnt = (C.c_int32 * 64)(), C.c_int32()
+            lib.fsgm_shard_frames(n_frames, n_dev, slot, out, C.byref(cnt))
+            assert list(out[:cnt.value]) == shard_indices(n_frames, slot, n_dev)
+            seen += list(out[:cnt.value])
+        assert sorted(seen) == list(range(n_frames))                         # a partition: every frame exactly once
+    # without a device the multi-device calls fail loudly too (no CPU fallback)
+    if lib.fsgm_device_count() == 0:
+        from fsgm_amd import calc_cost_sgm_batch
+        I1, I2 = synth.image_pair(16, 8, 8, seed=1)
+        maps = synth.epi_maps(16, 8, "axis")
+        with pytest.raises(fsgm_amd.FsgmError):
+            calc_cost_sgm_batch([(I1, I2) + maps] * 2, 8, 0.3, 6, 64, devices=[0, 0])

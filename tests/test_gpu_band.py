@@ -221,3 +221,47 @@ def test_chained_band_sweeps_kitti_shape(gpu_lib, oracle):
             S = oracle.epi_aggregate(base, 6, 64, paths)
             bd, mc = oracle.epi_wta(S, W, H, D, 1)
             np.testing.assert_array_equal(want[0][1], mc)
+
+
+@pytest.mark.parametrize("paths,mode", [(8, 4), (4, 4), (8, 5)])
+def test_band_sweeps_with_more_workgroups_than_the_chip_holds(gpu_lib, oracle, paths, mode):
+    """600 frames of 70 x 64 x 128 (mode 4: one workgroup per frame = 600 workgroups; mode 5: 70 rows are two bands, 1200):
+    more than two per CU on 256 CUs, so workgroups start as others retire and two share a CU's LDS -- the regime of the
+    512-frame headline run, which bench.py only self-checks against the line kernels.  A sample of frames spread over the
+    batch against the oracle (minC, bestD; S of two of them), every frame against the first frame that holds the same volume."""
+    W, H, D, B = 70, 70 if mode == 5 else 64, 128, 600
+    NV = 5                                                   # distinct volumes; frame f holds volume f % NV rolled by f // NV columns
+    vols = [synth.cost_volume(W, H, D, seed=4000 + v, cmax=24) for v in range(NV)]
+    for v in vols:
+        v[:, ::7, :] = 0
+    _, _, off = synth.epi_maps(W, H, "general", seed=3)
+    with EpiPlan(W, H, D, B, paths=paths) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        for f in range(B):
+            if f < NV:
+                plan.upload_cost(f, vols[f])
+            else:
+                plan.copy_cost(f, f % NV, f // NV)
+            plan.upload_offset(f, off)
+        plan.set_agg_mode(mode)
+        assert plan.kernel_name == ("band16/nowrap" if mode == 4 else "band16chain/nowrap")
+        for _ in range(2):
+            plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        plan.sync()
+        sample = sorted({0, 1, 255, 256, 257, 511, 512, 513, B - 1} | {int(round(i * (B - 1) / 11)) for i in range(12)})
+        for f in sample:
+            v = np.ascontiguousarray(np.roll(vols[f % NV], f // NV, axis=1))
+            S = oracle.epi_aggregate(v, 6, 64, paths)
+            bd, mc = oracle.epi_wta(S, W, H, D, 1)
+            gbd, gmc = plan.download(f)
+            np.testing.assert_array_equal(gmc, mc, err_msg=f"frame {f} minC")
+            np.testing.assert_array_equal(gbd, oracle.epi_vz_to_disp(bd, off, 0.3, D + 1), err_msg=f"frame {f} bestD")
+            if f in (257, B - 1):
+                np.testing.assert_array_equal(plan.download_sum(f), S[:-1].reshape(H, W, D), err_msg=f"frame {f} S")
+        # frames NV apart in the same residue class hold the same volume rolled by one more column: minC rolls with it only if
+        # the roll does not move a path start, so compare exact duplicates instead -- roll by a multiple of W
+        dup = [f for f in range(B) if (f // NV) % W == 0 and f >= NV]
+        for f in dup:
+            a, b = plan.download(f), plan.download(f % NV)
+            np.testing.assert_array_equal(a[1], b[1], err_msg=f"frame {f} vs {f % NV} minC")
+            np.testing.assert_array_equal(a[0], b[0], err_msg=f"frame {f} vs {f % NV} bestD")

@@ -210,6 +210,16 @@ def test_pyramid_batch_matches_single_pairs(gpu_lib, oracle):
             for _ in range(2):                                  # twice: buffers are reused
                 plan.run()
             got = [[plan.download(l, frame=f) for l in (1, 2, 3)] for f in range(B)]
+            # the gray levels of frames other than 0 (impyramid 'reduce' / rgb2gray per frame of the batch)
+            for f in (1, B - 1):
+                c0, c1 = pairs[f]
+                for l in (1, 2, 3):
+                    if l > 1:
+                        c0 = np.stack([oracle.impyramid_reduce(c) for c in c0]) if ch == 3 else oracle.impyramid_reduce(c0)
+                        c1 = np.stack([oracle.impyramid_reduce(c) for c in c1]) if ch == 3 else oracle.impyramid_reduce(c1)
+                    g0, g1 = plan.download_gray(l, frame=f)
+                    np.testing.assert_array_equal(g0, oracle.rgb2gray(c0) if ch == 3 else c0, err_msg=f"{ch} channels, frame {f}, gray level {l}")
+                    np.testing.assert_array_equal(g1, oracle.rgb2gray(c1) if ch == 3 else c1, err_msg=f"{ch} channels, frame {f}, gray level {l}")
         for f, (a, b) in enumerate(pairs):
             want_mv, want_minC, want_lv = oracle.pyramidal_sgm(a, b, 3)
             for l in (1, 2, 3):
