@@ -274,12 +274,22 @@ fsgm_status fsgm_pyramidal_sgm_ng_host(const uint8_t* I0, const uint8_t* I1, int
         }
         g_ngpyr_cache.push_back(p);
     }
-    if ((st = fsgm_ng_pyramid_plan_upload(p, I0, I1)) != FSGM_OK) return st;
-    if ((st = fsgm_ng_pyramid_plan_run(p)) != FSGM_OK) return st;
-    if ((st = fsgm_ng_pyramid_plan_download(p, 1, flow, minC)) != FSGM_OK) return st;
+    // one stream-ordered sequence, a single host wait (see fsgm_pyramidal_sgm_host)
+    FSGM_HIP(hipSetDevice(p->device));
+    StreamGuard guard(p->stream);
+    const size_t nimg = (size_t)channels * width * height;
+    FSGM_HIP(hipMemcpyAsync(channels == 3 ? p->dP0[0] : p->dG0[0], I0, nimg, hipMemcpyHostToDevice, p->stream));
+    FSGM_HIP(hipMemcpyAsync(channels == 3 ? p->dP1[0] : p->dG1[0], I1, nimg, hipMemcpyHostToDevice, p->stream));
+    if ((st = ng_pyramid_enqueue(p)) != FSGM_OK) return st;
+    const size_t np1 = (size_t)width * height;
+    FSGM_HIP(hipMemcpyAsync(flow, p->dFlow[0], 2 * np1 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    if (minC) FSGM_HIP(hipMemcpyAsync(minC, p->dMinC[0], np1 * 4, hipMemcpyDeviceToHost, p->stream));
     if (flowPyd)
-        for (int l = 1; l <= prm->numPyd; l++)
-            if (flowPyd[l - 1] && (st = fsgm_ng_pyramid_plan_download(p, l, flowPyd[l - 1], nullptr)) != FSGM_OK) return st;
+        for (int l = 0; l < prm->numPyd; l++)
+            if (flowPyd[l] && flowPyd[l] != flow)
+                FSGM_HIP(hipMemcpyAsync(flowPyd[l], p->dFlow[l], 2 * (size_t)p->Ws[l] * p->Hs[l] * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    FSGM_HIP(hipStreamSynchronize(p->stream));
+    guard.dismiss();
     return FSGM_OK;
 }
 
