@@ -103,8 +103,8 @@ fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in
     if (st != FSGM_OK) return st;
     const size_t NP = (size_t)W * H, MV = (size_t)a.mvWidth * a.mvHeight, N = NP * D, B = n;
     DevBufs d(device);
-    uint8_t *dI1, *dI2, *dDk; uint16_t *dDd, *dCm; uint32_t* dCk; uint32_t *dCen1, *dCen2, *dS, *dMinC, *dUnsafe, *dBox, *dKstat; double *dMv, *dFlow; Cand* dC;
-    d.want((void**)&dUnsafe, 4);
+    uint8_t *dI1, *dI2, *dDk; uint16_t *dDd, *dCm; uint32_t* dCk; uint32_t *dCen1, *dCen2, *dS, *dMinC, *dUnsafe, *dBox, *dKstat; double *dMv, *dFlow; Cand* dC; int16_t* dL4;
+    d.want((void**)&dUnsafe, 8);                       // { a vector beyond the packed matcher's range, a key that does not fit 4 bytes }
     d.want((void**)&dI1, B * NP);
     d.want((void**)&dI2, B * NP);
     d.want((void**)&dCen1, B * NP * 4);
@@ -120,34 +120,43 @@ fsgm_status fsgm_calc_pyd_cost_sgm_ng_batch_host(int32_t n, const fsgm_ng_in* in
     d.want((void**)&dKstat, NG_KSTAT_WORDS * 4);
     d.want((void**)&dCk, B * N * 4);
     d.want((void**)&dCm, B * N * 2);
+    d.want((void**)&dL4, D <= 128 ? B * NP * NG_L4_PER_PIXEL * sizeof(int16_t) : 0);
     { const hipError_t e = d.commit(device); if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP, "fsgm_calc_pyd_cost_sgm_ng: %s", hipGetErrorString(e)); }
     for (int i = 0; i < n; i++) {
         FSGM_HIP(hipMemcpyAsync(dI1 + i * NP, in[i].I1, NP, hipMemcpyHostToDevice, d.stream));
         FSGM_HIP(hipMemcpyAsync(dI2 + i * NP, in[i].I2, NP, hipMemcpyHostToDevice, d.stream));
         FSGM_HIP(hipMemcpyAsync(dMv + i * 2 * MV, in[i].preMv, MV * 16, hipMemcpyHostToDevice, d.stream));
     }
-    FSGM_HIP(hipMemsetAsync(dS, 0, B * N * 4, d.stream));                       // :111
-    FSGM_HIP(hipMemsetAsync(dUnsafe, 0, 4, d.stream));
+    // 4-byte candidate entries (the 3x3 hint kernel's sizes, D = 81): the keys live in S's memory until the matchers need S
+    static const bool k4_env = [] { const char* e = getenv("FSGM_NG_K4"); return !(e && e[0] == '0'); }();      // A/B switch
+    static const bool hint_env = [] { const char* e = getenv("FSGM_NG_COST_HINT"); return !(e && e[0] == '0'); }();
+    const bool dedupe_on = [] { const char* e = getenv("FSGM_NG_DEDUPE"); return !(e && atoi(e) == 0); }();
+    const bool k4 = k4_env && hint_env && dedupe_on && r == 1 && rAgg == 1 && D <= 128;
+    if (!k4) FSGM_HIP(hipMemsetAsync(dS, 0, B * N * 4, d.stream));              // :111
+    FSGM_HIP(hipMemsetAsync(dUnsafe, 0, 8, d.stream));
     launch_census(d.stream, dI1, dCen1, W, H, n);                               // :485-486
     launch_census(d.stream, dI2, dCen2, W, H, n);
     NgCostArgs ca;
+    ca.K4 = k4 ? dS : nullptr; ca.flags = k4 ? dUnsafe : nullptr;
     ca.cen1 = dCen1; ca.cen2 = dCen2; ca.mv = dMv; ca.C = dC; ca.unsafe = dUnsafe; ca.W = W; ca.H = H;
     ca.mvW = a.mvWidth; ca.mvH = a.mvHeight; ca.rAgg = rAgg; ca.rX = r; ca.rY = r;
     launch_ng_cost(d.stream, ca, n);
     NgAggArgs ga;
     ga.C = dC; ga.S = dS; ga.unsafe = dUnsafe; ga.W = W; ga.H = H; ga.D = (int)D; ga.P1 = a.P1; ga.P2 = a.P2;
-    ga.dd = nullptr; ga.dk = nullptr; ga.dbox = nullptr; ga.kstat = nullptr; ga.ck = nullptr; ga.cm = nullptr;
+    ga.dd = nullptr; ga.dk = nullptr; ga.dbox = nullptr; ga.kstat = nullptr; ga.ck = nullptr; ga.cm = nullptr; ga.L4 = nullptr;
     if (D <= 128) {                                  // repeats in the candidate lists: the matchers scan each distinct entry once
-        launch_ng_dedupe(d.stream, dC, dDd, dDk, dBox, dKstat, dCk, dCm, W, H, (int)D, n);
-        ga.dd = dDd; ga.dk = dDk; ga.dbox = dBox; ga.kstat = dKstat; ga.ck = dCk; ga.cm = dCm;
+        launch_ng_dedupe(d.stream, dC, dDd, dDk, dBox, dKstat, dCk, dCm, W, H, (int)D, n, ca.K4, ca.flags);
+        ga.dd = dDd; ga.dk = dDk; ga.dbox = dBox; ga.kstat = dKstat; ga.ck = dCk; ga.cm = dCm; ga.L4 = dL4;
+        if (k4) launch_ng_prepare_matchers(d.stream, ga, dS, dC, dUnsafe, n);
     }
     launch_ng_aggregate(d.stream, ga, n);
     NgWtaArgs wa;
     wa.C = dC; wa.S = dS; wa.minC = dMinC; wa.flow = dFlow; wa.W = W; wa.H = H; wa.D = (int)D;
-    wa.cm = ga.dd ? dCm : nullptr; wa.dk = ga.dd ? dDk : nullptr;
+    wa.cm = ga.dd ? dCm : nullptr; wa.dk = ga.dd ? dDk : nullptr; wa.L4 = ga.L4; wa.kstat = ga.kstat; wa.K4 = ca.K4; wa.flags = ca.flags;
     launch_ng_wta(d.stream, wa, n);
     bool want_S = false;
     for (int i = 0; i < n; i++) want_S = want_S || out[i].S;
+    if (want_S && ga.L4) launch_ng_l4_to_s(d.stream, dS, dL4, dCm, dDk, dKstat, W, H, (int)D, n);   // the compact kernel leaves its sums in L4
     if (want_S && ga.dd) launch_ng_fill_repeats(d.stream, dS, dDd, dCm, W, H, (int)D, n);      // the compact kernel adds to kept entries only
     if (a.subPixelRefine) {                                                     // :516-517
         NgSubpixArgs sa;

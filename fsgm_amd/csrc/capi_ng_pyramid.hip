@@ -29,6 +29,7 @@ struct fsgm_ng_pyramid_plan {
     uint8_t* dDk = nullptr;
     uint32_t* dBox = nullptr;                        // bounding boxes of the lists' motion vectors (grid matcher)
     uint32_t* dKstat = nullptr;                      // partial sums of the list lengths (choice of the matcher form)
+    int16_t* dL4 = nullptr;                          // the compact matcher's per-path costs (ng_kernels.h)
     uint32_t* dCk = nullptr;                         // the kept entries in place order (compact aggregation kernel)
     uint16_t* dCm = nullptr;
     Cand* dC = nullptr;
@@ -54,7 +55,7 @@ void fsgm_ng_pyramid_plan_destroy(fsgm_ng_pyramid_plan* p) {
     (void)hipSetDevice(p->device);
     auto drop = [](auto& v) { for (auto* b : v) if (b) (void)hipFree(b); };
     drop(p->dP0); drop(p->dP1); drop(p->dG0); drop(p->dG1); drop(p->dMv); drop(p->dFlow); drop(p->dMinC);
-    void* one[] = {p->dCen1, p->dCen2, p->dS, p->dUnsafe, p->dC, p->dDd, p->dDk, p->dBox, p->dKstat, p->dCk, p->dCm};
+    void* one[] = {p->dCen1, p->dCen2, p->dS, p->dUnsafe, p->dC, p->dDd, p->dDk, p->dBox, p->dKstat, p->dCk, p->dCm, p->dL4};
     for (void* b : one) if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -118,11 +119,12 @@ fsgm_status fsgm_ng_pyramid_plan_create_batch(fsgm_ng_pyramid_plan** out, int32_
     if (e == hipSuccess) e = hipMalloc((void**)&p->dCen2, B * NP * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dC, B * N * sizeof(Cand));
     if (e == hipSuccess) e = hipMalloc((void**)&p->dS, B * N * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->dUnsafe, 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->dUnsafe, 8);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dDd, B * N * 2);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dDk, B * NP);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dBox, B * NP * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dKstat, NG_KSTAT_WORDS * 4);
+    if (e == hipSuccess && p->D <= 128) e = hipMalloc((void**)&p->dL4, (size_t)B * p->Ws[0] * p->Hs[0] * NG_L4_PER_PIXEL * sizeof(int16_t));
     if (e == hipSuccess) e = hipMalloc((void**)&p->dCk, B * N * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->dCm, B * N * 2);
     if (e == hipSuccess) e = hipMemset(p->dMv[n - 1], 0, B * 2 * (size_t)p->mvW[n - 1] * p->mvH[n - 1] * sizeof(double));   // :34
@@ -173,25 +175,32 @@ static fsgm_status ng_pyramid_enqueue(fsgm_ng_pyramid_plan* p) {
     for (int l = n - 1; l >= 0; l--) {                                           // :37
         const int w = p->Ws[l], h = p->Hs[l];
         const size_t N = (size_t)w * h * D;
-        FSGM_HIP(hipMemsetAsync(p->dS, 0, (size_t)B * N * 4, s));                // calc_pyd_cost_sgm_ng.cpp:111
-        FSGM_HIP(hipMemsetAsync(p->dUnsafe, 0, 4, s));
+        // 4-byte candidate entries (3x3 hint kernel, D = 81): the keys live in S's memory until the matchers need S (ng_kernels.h)
+        static const bool k4_env = [] { const char* e = getenv("FSGM_NG_K4"); return !(e && e[0] == '0'); }();
+        static const bool hint_env = [] { const char* e = getenv("FSGM_NG_COST_HINT"); return !(e && e[0] == '0'); }();
+        const bool dedupe_on = [] { const char* e = getenv("FSGM_NG_DEDUPE"); return !(e && atoi(e) == 0); }();
+        const bool k4 = k4_env && hint_env && dedupe_on && p->prm.halfSearchWinSize == 1 && p->prm.aggSize / 2 == 1 && D <= 128;
+        if (!k4) FSGM_HIP(hipMemsetAsync(p->dS, 0, (size_t)B * N * 4, s));       // calc_pyd_cost_sgm_ng.cpp:111
+        FSGM_HIP(hipMemsetAsync(p->dUnsafe, 0, 8, s));
         launch_census(s, p->dG0[l], p->dCen1, w, h, B);                          // :485-486
         launch_census(s, p->dG1[l], p->dCen2, w, h, B);
         NgCostArgs ca;
+        ca.K4 = k4 ? p->dS : nullptr; ca.flags = k4 ? p->dUnsafe : nullptr;
         ca.cen1 = p->dCen1; ca.cen2 = p->dCen2; ca.mv = p->dMv[l]; ca.C = p->dC; ca.unsafe = p->dUnsafe; ca.W = w; ca.H = h;
         ca.mvW = p->mvW[l]; ca.mvH = p->mvH[l]; ca.rAgg = p->prm.aggSize / 2; ca.rX = p->prm.halfSearchWinSize; ca.rY = p->prm.halfSearchWinSize;
         launch_ng_cost(s, ca, B);
         NgAggArgs ga;
         ga.C = p->dC; ga.S = p->dS; ga.unsafe = p->dUnsafe; ga.W = w; ga.H = h; ga.D = D; ga.P1 = p->prm.P1; ga.P2 = p->prm.P2;
-        ga.dd = nullptr; ga.dk = nullptr; ga.dbox = nullptr; ga.kstat = nullptr; ga.ck = nullptr; ga.cm = nullptr;
+        ga.dd = nullptr; ga.dk = nullptr; ga.dbox = nullptr; ga.kstat = nullptr; ga.ck = nullptr; ga.cm = nullptr; ga.L4 = nullptr;
         if (D <= 128) {
-            launch_ng_dedupe(s, p->dC, p->dDd, p->dDk, p->dBox, p->dKstat, p->dCk, p->dCm, w, h, D, B);
-            ga.dd = p->dDd; ga.dk = p->dDk; ga.dbox = p->dBox; ga.kstat = p->dKstat; ga.ck = p->dCk; ga.cm = p->dCm;
+            launch_ng_dedupe(s, p->dC, p->dDd, p->dDk, p->dBox, p->dKstat, p->dCk, p->dCm, w, h, D, B, ca.K4, ca.flags);
+            ga.dd = p->dDd; ga.dk = p->dDk; ga.dbox = p->dBox; ga.kstat = p->dKstat; ga.ck = p->dCk; ga.cm = p->dCm; ga.L4 = p->dL4;
+            if (k4) launch_ng_prepare_matchers(s, ga, p->dS, p->dC, p->dUnsafe, B);
         }
         launch_ng_aggregate(s, ga, B);
         NgWtaArgs wa;
         wa.C = p->dC; wa.S = p->dS; wa.minC = p->dMinC[l]; wa.flow = p->dFlow[l]; wa.W = w; wa.H = h; wa.D = D;
-        wa.cm = ga.dd ? p->dCm : nullptr; wa.dk = ga.dd ? p->dDk : nullptr;
+        wa.cm = ga.dd ? p->dCm : nullptr; wa.dk = ga.dd ? p->dDk : nullptr; wa.L4 = ga.L4; wa.kstat = ga.kstat; wa.K4 = ca.K4; wa.flags = ca.flags;
         launch_ng_wta(s, wa, B);
         if (p->prm.subPixelRefine) {                                             // :516-517
             NgSubpixArgs sa;

@@ -16,6 +16,8 @@ struct NgCostArgs {
     const uint32_t* cen2;
     const double* mv;       // [frames][2][mvH*mvW]
     Cand* C;                // [frames][NP][D]
+    uint32_t* K4;           // [frames][NP][D] 4-byte entries (ng_key4) -- the 3x3 hint kernel's output when every key fits; null: 12-byte entries only
+    uint32_t* flags;        // two words zeroed by the caller, = { unsafe, a key that does not fit 4 bytes }; needed with K4
     uint32_t* unsafe;       // one word (may be null), zeroed by the caller: set when a motion vector has |v| >= 2^30
     int W, H, mvW, mvH;
     int rAgg, rX, rY;
@@ -37,8 +39,13 @@ struct NgAggArgs {
     int compact_force;      // ... or this one whatever they say (FSGM_NG_COMPACT_G, tests)
     int blk_begin_c[5];     // compact kernel: first block of each range (4 lines a workgroup)
     int slot_of_c[4];
-    const uint32_t* kstat;  // [256] partial sums of the list lengths of a sample of this launch's pixels, [256] flags: bit 0 a list longer
-                            // than 64 entries, bit 1 a pixel whose entries do not fit the packed key (launch_ng_dedupe)
+    int16_t* L4;            // [frames][NP][4 path slots][64] the compact kernel's path costs of the kept entries, by place in the pixel's list:
+                            // plain 2-byte stores, contiguous per pixel and path, instead of one atomic add to S per kept entry and path
+                            // (208 M scattered atomics per batch of 8 at 1242x375: 1.6 of 8.3 ms).  The WTA sums the four slots.
+                            // Null: the compact kernel is not launched
+    uint32_t* kstat;        // [256] partial sums of the list lengths of a sample of this launch's pixels, [256] flags: bit 0 a list longer
+                            // than 64 entries, bit 1 a pixel whose entries do not fit the packed key (launch_ng_dedupe); [257] set by the
+                            // compact kernel when it is the one that runs: S holds nothing then, the sums are in L4
     int W, H, D;
     int P1, P2;
     int blk_begin[5];
@@ -50,6 +57,10 @@ struct NgWtaArgs {
     const uint32_t* S;
     const uint16_t* cm;     // launch_ng_dedupe's kept-entry table and list lengths: the search runs over the groups of repeats,
     const uint8_t* dk;      // whose sums sit at their first members' indices; both null: over all D candidates
+    const int16_t* L4;      // the compact kernel's per-path costs and the launch's statistics words (kstat[257] != 0: sums = the four
+    const uint32_t* kstat;  // slots of L4 at the entry's place; else S); null: S
+    const uint32_t* K4;     // 4-byte entries and the cost kernel's flags (flags[1] == 0: every key fits): the winner's motion vector comes
+    const uint32_t* flags;  // from its key when the compact kernel ran; null: from C
     uint32_t* minC;         // [frames][NP]
     double* flow;           // [frames][2][NP]
     int W, H, D;
@@ -81,11 +92,18 @@ void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames);
 void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames);
 // repeats among the D <= 128 candidates of every pixel (same motion vector and same cost), see ng_dedupe_kernel
 enum { NG_ROLE_ANY = 0, NG_ROLE_GRID = 1, NG_ROLE_LIST = 2, NG_ROLE_COMPACT = 3, NG_ROLE_REST = 4 };
-constexpr int NG_KSTAT_WORDS = 257;
+constexpr int NG_KSTAT_WORDS = 259;
+constexpr int NG_L4_PER_PIXEL = 4 * 64;      // int16 entries of L4 per pixel
 // kstat: NG_KSTAT_WORDS words, zeroed here; ck / cm may be null (no compact kernel)
-void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, uint32_t* ck, uint16_t* cm, int W, int H, int D, int frames);
+void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, uint32_t* ck, uint16_t* cm, int W, int H, int D, int frames,
+                      const uint32_t* K4 = nullptr, const uint32_t* flags = nullptr);
+// With 4-byte entries (K4 in the memory of S): after the dedupe kernel and before launch_ng_aggregate -- decides on the device whether the
+// compact matcher runs (kstat[258]); if not, expands the keys to the Cand list the general matchers read and zeroes S
+void launch_ng_prepare_matchers(hipStream_t st, const NgAggArgs& a, const uint32_t* K4, Cand* C, const uint32_t* flags, int frames);
 // S of the repeats := S of the entries they repeat (only needed when S itself is read back: the WTA looks them up)
 void launch_ng_fill_repeats(hipStream_t st, uint32_t* S, const uint16_t* dd, const uint16_t* cm, int W, int H, int D, int frames);
+// S at the kept entries' first-member indices := the sum of L4's four slots, when the compact kernel ran (kstat[257]): only for reading S back
+void launch_ng_l4_to_s(hipStream_t st, uint32_t* S, const int16_t* L4, const uint16_t* cm, const uint8_t* dk, const uint32_t* kstat, int W, int H, int D, int frames);
 void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames);
 void launch_ng_subpixel(hipStream_t st, const NgSubpixArgs& a, int frames);
 void launch_otf(hipStream_t st, const OtfArgs& a, int frames);

@@ -7,6 +7,12 @@
 #include "fsgm_device.h"
 #include <stdlib.h>
 
+#ifndef FSGM_NG_PRIO
+#define FSGM_NG_PRIO 1
+#endif
+#ifndef FSGM_NG_CPF
+#define FSGM_NG_CPF 8      // compact kernel: steps of list entries in flight (4: a single 1242x375 pair 1.67 ms, 8: 1.56, 2: 1.84)
+#endif
 namespace fsgm {
 
 __device__ __forceinline__ bool near2(int a, int b) {
@@ -93,8 +99,26 @@ __global__ __launch_bounds__(256) void ng_cost_kernel(NgCostArgs a) {
 // The rounded mean of the taps, (int)(1.0 * sum / 9 + 0.5) (:432), is (2 sum + 9) / 18 in integers: 2 sum + 9 is odd,
 // so the quotient sum / 9 + 0.5 is never closer than 1/18 to an integer and no rounding of the double division can
 // cross one.  The wave's 64 x 27 output dwords go through LDS and leave as contiguous stores.
+//
+// K4OUT (round 4): a candidate leaves as ONE dword, ng_key4(mvx, mvy, cost) -- 13 + 13 + 5 bits, the key the dedupe kernel used
+// to build from the 12-byte entry -- when every motion vector lies inside +-4095 (the launch's flags word 1 is raised otherwise,
+// and a second launch of this kernel, the 12-byte form, gated on that flag, writes the Cand list for the general kernels).
+// 151 MB per 1242x375 frame written here and read by the dedupe kernel instead of 453: the two kernels together were
+// 2.6 of 7.4 ms per batch of 8, most of it those bytes.
+__device__ __forceinline__ uint32_t ng_key4(int mvx, int mvy, uint32_t cost) {
+    return ((uint32_t)(mvx + 0x1000) << 18) | ((uint32_t)(mvy + 0x1000) << 5) | cost;
+}
+__device__ __forceinline__ Cand ng_unkey4(uint32_t k) {
+    Cand c;
+    c.mvx = (int)(k >> 18) - 0x1000; c.mvy = (int)((k >> 5) & 0x1FFFu) - 0x1000; c.cost = (int)(k & 31u);
+    return c;
+}
+
+template <bool K4OUT>
 __global__ __launch_bounds__(256) void ng_cost_hint_kernel(NgCostArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t sOut[4][64 * 27];
+    constexpr int OW = K4OUT ? 9 : 27;                                     // dwords a (pixel, hint) leaves
+    __shared__ __attribute__((aligned(16))) uint32_t sOut[4][64 * OW];
+    if (!K4OUT && a.flags && a.flags[1] == 0) return;                      // the 12-byte list is only needed when a key does not fit
     const int W = a.W, H = a.H;
     const int NP = W * H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -136,15 +160,21 @@ __global__ __launch_bounds__(256) void ng_cost_hint_kernel(NgCostArgs a) {
     for (int ky = 0; ky < 5; ky++)
 #pragma unroll
         for (int kx = 0; kx < 5; kx++) P[ky * 5 + kx] = cen2[(size_t)W * Y2[ky] + X2[kx]];
-    uint32_t* out = sOut[wave] + lane * 27;
+    uint32_t* out = sOut[wave] + lane * OW;
     int cmx[3], cmy[3];
-    bool far = false;
+    bool far = false, far4 = false;
 #pragma unroll
     for (int o = 0; o < 3; o++) {
         cmx[o] = f64_to_i32_x86(__dadd_rn(mvx, (double)(o - 1)));          // :433
         cmy[o] = f64_to_i32_x86(__dadd_rn(mvy, (double)(o - 1)));          // :434
         far |= !(cmx[o] > -0x3FF0 && cmx[o] < 0x3FF0 && cmy[o] > -0x3FF0 && cmy[o] < 0x3FF0);
+        far4 |= !(cmx[o] > -0x1000 && cmx[o] < 0x1000 && cmy[o] > -0x1000 && cmy[o] < 0x1000);
     }
+    auto put = [&](const int ox, const int oy, const uint32_t sum) {
+        const uint32_t cost = (2u * sum + 9u) / 18u;                       // <= 24 (out-of-image taps count 5)
+        if (K4OUT) out[ox * 3 + oy] = ng_key4(cmx[ox], cmy[oy], cost);
+        else { uint32_t* o = out + (ox * 3 + oy) * 3; o[0] = (uint32_t)cmx[ox]; o[1] = (uint32_t)cmy[oy]; o[2] = cost; }
+    };
     const bool clean = xin == 31u && yin == 31u && tin == 511u;
     if (__builtin_amdgcn_ballot_w64(!clean) == 0) {
 #pragma unroll
@@ -156,8 +186,7 @@ __global__ __launch_bounds__(256) void ng_cost_hint_kernel(NgCostArgs a) {
                 for (int ty = 0; ty < 3; ty++)
 #pragma unroll
                     for (int tx = 0; tx < 3; tx++) sum += __popc(T[ty * 3 + tx] ^ P[(oy + ty) * 5 + ox + tx]);
-                uint32_t* o = out + (ox * 3 + oy) * 3;
-                o[0] = (uint32_t)cmx[ox]; o[1] = (uint32_t)cmy[oy]; o[2] = (2u * sum + 9u) / 18u;
+                put(ox, oy, sum);
             }
     } else {
 #pragma unroll
@@ -172,15 +201,15 @@ __global__ __launch_bounds__(256) void ng_cost_hint_kernel(NgCostArgs a) {
                         const uint32_t ok = (tin >> (ty * 3 + tx)) & (xin >> (ox + tx)) & (yin >> (oy + ty)) & 1u;   // :405-421
                         sum += ok ? (uint32_t)__popc(T[ty * 3 + tx] ^ P[(oy + ty) * 5 + ox + tx]) : 5u;
                     }
-                uint32_t* o = out + (ox * 3 + oy) * 3;
-                o[0] = (uint32_t)cmx[ox]; o[1] = (uint32_t)cmy[oy]; o[2] = (2u * sum + 9u) / 18u;
+                put(ox, oy, sum);
             }
     }
     // the fast matcher compares motion vectors as packed 16-bit pairs (ng_pack_mv): tell it when one does not fit
     if (a.unsafe && far) atomicOr(a.unsafe, 1u);
+    if (K4OUT && far4 && a.flags[1] == 0) atomicOr(&a.flags[1], 1u);      // a key that does not fit: the launch falls back to 12-byte entries
     __builtin_amdgcn_wave_barrier();
-    const int ndw = (int)min((long long)64, total - wbase) * 27;           // dwords this wave owns
-    uint32_t* dst = (uint32_t*)(a.C + f * (size_t)NP * 81) + (size_t)wbase * 27;
+    const int ndw = (int)min((long long)64, total - wbase) * OW;           // dwords this wave owns
+    uint32_t* dst = (K4OUT ? a.K4 + f * (size_t)NP * 81 : (uint32_t*)(a.C + f * (size_t)NP * 81)) + (size_t)wbase * OW;
     if (((uintptr_t)dst & 15u) == 0) {                                     // wave-uniform
         for (int i = lane * 4; i < ndw; i += 256) {
             if (i + 4 <= ndw) *(uint4*)(dst + i) = *(const uint4*)(sOut[wave] + i);
@@ -403,7 +432,8 @@ __device__ __forceinline__ void ng_match4_pair(const NgPre& q, int D, int mvxa, 
 //
 // Also written per pixel: the bounding box of its motion vectors, as its packed origin (ng_pack_mv) when both
 // sides are <= NG_GB, NG_BOX_WIDE otherwise -- what the grid form of the matcher (ng_agg_grid_kernel) needs.
-__global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__ C, uint16_t* __restrict__ dd, uint8_t* __restrict__ dk,
+__global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__ C, const uint32_t* __restrict__ K4, const uint32_t* __restrict__ flags,
+                                                        uint16_t* __restrict__ dd, uint8_t* __restrict__ dk,
                                                         uint32_t* __restrict__ dbox, uint32_t* __restrict__ kstat, uint32_t* __restrict__ ck,
                                                         uint16_t* __restrict__ cm, int NPtot, int D) {
     __shared__ __attribute__((aligned(16))) uint32_t sk[4][128];
@@ -420,8 +450,17 @@ __global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__
     };
     bool ok0 = true, ok1 = true;
     const Cand z = {0, 0, 0};
-    const Cand e0 = has0 ? c[d0] : z, e1 = has1 ? c[d1] : z;
-    const uint32_t k0 = key_of(e0, ok0), k1 = key_of(e1, ok1);
+    Cand e0 = z, e1 = z;
+    uint32_t k0, k1;
+    if (K4 && flags[1] == 0) {                               // launch-uniform: the cost kernel left the keys themselves (4 bytes an entry)
+        k0 = has0 ? K4[(size_t)p * D + d0] : ng_key4(0, 0, 0);
+        k1 = has1 ? K4[(size_t)p * D + d1] : ng_key4(0, 0, 0);
+        e0 = ng_unkey4(k0); e1 = ng_unkey4(k1);
+    } else {
+        if (has0) e0 = c[d0];
+        if (has1) e1 = c[d1];
+        k0 = key_of(e0, ok0); k1 = key_of(e1, ok1);
+    }
     sk[wave][d0] = has0 ? k0 : 0xFFFFFFFFu;
     sk[wave][d1] = has1 ? k1 : 0xFFFFFFFFu;
     const bool all_ok = __builtin_amdgcn_ballot_w64(!(ok0 && ok1)) == 0;
@@ -764,24 +803,71 @@ __global__ __launch_bounds__(256) void ng_agg_grid_kernel(NgAggArgs a) {
 // entries distinct) that is a quarter of the matcher work and of the atomic adds; the line's minimum is a wave
 // reduction and a step has no workgroup barrier at all -- the four waves of a workgroup walk four lines independently.
 // Runs when every list of the launch has at most 64 entries inside the packed key's range (ng_agg_not_mine).
+// four entries of the predecessor against one candidate key: first-class "last exact match wins" (min1 follows the entry
+// order) and the minimum over the near, not equal entries
+__device__ __forceinline__ void ng_match4_group(const uint4 k4, const uint4 c8, const uint4 cp, const uint32_t ck2, uint32_t& min1, uint32_t& near2min) {
+    const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w};
+    const uint32_t c8a[4] = {c8.x, c8.y, c8.z, c8.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t t = pk_sub(ck2, ka[i]);
+        const bool nr = pk_min(t, 0x00040004u) == t, eq = t == 0x00020002u;
+        min1 = eq ? c8a[i] : min1;                                            // last match wins
+        uint32_t sel = nr ? cpa[i] : 0xFFFFu;
+        sel = eq ? 0xFFFFu : sel;
+        near2min = min(near2min, sel);
+    }
+}
+
+// The reads of a group of four are requested one group ahead of their compares (round 4: with the reads issued and waited
+// for inside one iteration a wave parked in s_waitcnt for the LDS round trip once per four entries -- 76 % of its time in the
+// counters of round 3)
 __device__ __forceinline__ uint32_t ng_match4_key(const uint32_t* qk, const uint32_t* qc8, const uint32_t* qcp, int K4, uint32_t key, uint32_t jump) {
     const uint32_t ck2 = key + 0x00020002u;
     uint32_t min1 = jump, near2min = 0xFFFFu;
-    for (int d2 = 0; d2 < K4; d2 += 4) {
-        const uint4 k4 = *(const uint4*)(qk + d2);
-        const uint4 c8 = *(const uint4*)(qc8 + d2), cp = *(const uint4*)(qcp + d2);
+    if (K4 <= 0) return jump;
+    uint4 k4 = *(const uint4*)qk, c8 = *(const uint4*)qc8, cp = *(const uint4*)qcp;
+    for (int d2 = 4; d2 < K4; d2 += 4) {
+        const uint4 nk = *(const uint4*)(qk + d2), nc8 = *(const uint4*)(qc8 + d2), ncp = *(const uint4*)(qcp + d2);
+        ng_match4_group(k4, c8, cp, ck2, min1, near2min);
+        k4 = nk; c8 = nc8; cp = ncp;
+    }
+    ng_match4_group(k4, c8, cp, ck2, min1, near2min);
+    return min(jump, min(min1, near2min));
+}
+
+// One line a wave, lists of at most 16 entries on both sides of the step: the four rows of the wave split the predecessor's
+// entries between them (row r takes the groups r, r + 4, ... of four), every row working for the same 16 candidates (lane & 15),
+// and the rows' results meet through two row swaps.  "Last exact match wins" survives the split as a maximum over
+// (place + 1) << 8 | cost.  A lone wave issues one instruction at a time (~6 cycles each): what counts for the
+// 1242-step lines of a single frame is the instruction count of a step, 4 x 33 for the groups of a 14-entry list before.
+__device__ __forceinline__ uint32_t ng_match4_key_rows(const uint32_t* qk, const uint32_t* qc8, const uint32_t* qcp, int K4, uint32_t key, uint32_t jump, int row) {
+    const uint32_t ck2 = key + 0x00020002u;
+    uint32_t last = 0, near2min = 0xFFFFu;                                    // last: ((place + 1) << 8) | cost of the last exact match, 0 = none
+    for (int d2 = 4 * row; d2 < K4; d2 += 16) {                               // (K4 <= 16: at most one group a row)
+        const uint4 k4 = *(const uint4*)(qk + d2), c8 = *(const uint4*)(qc8 + d2), cp = *(const uint4*)(qcp + d2);
         const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w};
         const uint32_t c8a[4] = {c8.x, c8.y, c8.z, c8.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t t = pk_sub(ck2, ka[i]);
             const bool nr = pk_min(t, 0x00040004u) == t, eq = t == 0x00020002u;
-            min1 = eq ? c8a[i] : min1;                                        // last match wins
+            last = eq ? (((uint32_t)(d2 + i + 1) << 8) | c8a[i]) : last;      // places ascend inside a row's walk: the later one replaces
             uint32_t sel = nr ? cpa[i] : 0xFFFFu;
             sel = eq ? 0xFFFFu : sel;
             near2min = min(near2min, sel);
         }
     }
+    // rows 0 <-> 1, 2 <-> 3, then halves: every lane ends with the results over all entries
+    uint32_t l2 = last, n2 = near2min;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(last), "+v"(l2));
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(near2min), "+v"(n2));
+    last = max(last, l2); near2min = min(near2min, n2);
+    l2 = last; n2 = near2min;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(last), "+v"(l2));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(near2min), "+v"(n2));
+    last = max(last, l2); near2min = min(near2min, n2);
+    const uint32_t min1 = last ? (last & 0xFFu) : jump;
     return min(jump, min(min1, near2min));
 }
 
@@ -796,6 +882,7 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t sC[4 * LPW][2][3][LS];    // [line of the workgroup][buffer][key, cost & 0xFF, (cost + P1) & 0xFF][place]
     __shared__ uint32_t sPick;
     if (ng_agg_not_mine(a, &sPick)) return;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.kstat[257] = 1u;   // tells the WTA where the sums are (L4, not S)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / G, pl_ = lane % G;                 // line of the wave, first place in its list
     int bb = 0;
@@ -811,24 +898,35 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     const int len = base == 0 ? W : H;
     const int line0 = (((int)blockIdx.x - a.blk_begin_c[bb]) * 4 + wave) * LPW;
     if (line0 >= nlines) return;                              // wave-uniform; the waves of a workgroup never meet again
+#if FSGM_NG_PRIO
+    // the lines along the longer side are the launch's critical path (1242 serial steps against 375): their waves issue first
+    // whenever a SIMD has the choice, the short lines' waves fill what is left
+    if (len > nlines) __builtin_amdgcn_s_setprio(3);
+#endif
     const bool lact = line0 + sub < nlines;                   // lines past the last redo the last one without adding to S
     const int line = min(line0 + sub, nlines - 1);
     const size_t f = blockIdx.y;
     const uint32_t* __restrict__ ckf = a.ck + f * (size_t)NP * D;
     const uint16_t* __restrict__ cmf = a.cm + f * (size_t)NP * D;
     const uint8_t* __restrict__ dkf = a.dk + f * (size_t)NP;
-    uint32_t* __restrict__ Sf = a.S + f * (size_t)NP * D;
+    int16_t* __restrict__ L4f = a.L4 + f * (size_t)NP * NG_L4_PER_PIXEL + slot * 64;
     int pix0 = base == 0 ? line * W : line;
     if (mirror) pix0 = NP - 1 - pix0;
     const int dpix = (mirror ? -1 : 1) * (base == 0 ? 1 : W);
     const uint32_t dent = (uint32_t)(dpix * D);
     const uint32_t pl = (uint32_t)min(pl_, D - 1);           // lanes past the list read inside the pixel's D slots
     uint32_t p_cur = (uint32_t)pix0, p_fet = p_cur, e_fet = p_cur * (uint32_t)D;
-    constexpr int PF = 4;
+    constexpr int PF = FSGM_NG_CPF;
     uint32_t rkey[PF], rmeta[PF], rlen[PF];                   // the first round's entry of the coming steps
+    // one line a wave: the same entries once more as the four rows see them when the lists are short (lane & 15: every row the
+    // candidates 0 .. 15; ng_match4_key_rows)
+    uint32_t rkey16[G == 64 ? PF : 1], rmeta16[G == 64 ? PF : 1];
+    const uint32_t pl16 = (uint32_t)min(lane & 15, D - 1);
+    const int row = lane >> 4;
 #pragma unroll
     for (int k = 0; k < PF; k++) {
         rkey[k] = ckf[e_fet + pl]; rmeta[k] = cmf[e_fet + pl]; rlen[k] = dkf[p_fet];
+        if constexpr (G == 64) { rkey16[k] = ckf[e_fet + pl16]; rmeta16[k] = cmf[e_fet + pl16]; }
         if (k + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
     }
     uint32_t* b0 = &sC[wave * LPW + sub][0][0][0];
@@ -838,32 +936,61 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     // one step; its ring slot is named by the caller, so that the steady-state loop below is straight-line code with the
     // slots at fixed registers: with a way out of the middle of the unrolled group the compiler rotates the ring through
     // copies, and every copy waits for the loads just requested (and for the step's atomic add) -- vmcnt(0) per step
-    auto step = [&](const int t, uint32_t& rk, uint32_t& rm, uint32_t& rl) {
+    auto step = [&](const int t, uint32_t& rk, uint32_t& rm, uint32_t& rl, uint32_t& rk16, uint32_t& rm16) {
         uint32_t key = rk, meta = rm;
         const int K = (int)rl;
+        bool rows16 = false;                                  // wave-uniform: this step's and the previous step's lists fit 16 lanes
+        if constexpr (G == 64) {
+            rows16 = K <= 16 && K4pre <= 16 && t > 0;
+            if (rows16) { key = rk16; meta = rm16; }
+            rk16 = ckf[e_fet + pl16]; rm16 = cmf[e_fet + pl16];
+        }
         rk = ckf[e_fet + pl]; rm = cmf[e_fet + pl]; rl = dkf[p_fet];
         if (t + PF + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
         int kmax = K;                                         // the longest list of the wave's lines at this step (K is uniform inside a line)
-        if (LPW > 1) {
-#pragma unroll
-            for (int sft = G; sft < 64; sft <<= 1) kmax = max(kmax, __shfl_xor(kmax, sft));
+        if (LPW > 1) {                                        // K is uniform inside a line's lanes: the rows' values through row swaps
+            // (two __shfl_xor = two dependent trips through the LDS crossbar per step before round 4)
+            uint32_t a_ = (uint32_t)kmax, b_ = a_;
+            if (G <= 16) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a_), "+v"(b_)); a_ = max(a_, b_); b_ = a_; }
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
+            kmax = (int)max(a_, b_);
         }
         const uint32_t jump = (m + (uint32_t)a.P2) & 0xFF;
         const uint32_t ecur = p_cur * (uint32_t)D;
         uint32_t lov = 0xFFFFFFFFu;
-        for (int e0 = 0; e0 < (G == 64 ? 1 : kmax); e0 += G) { // one round unless a list is longer than G (wave-uniform bound; 64 lanes hold any list)
+        // one round = G places of the list.  The first uses the prefetched entry; further rounds (a list longer than G: rare, and
+        // wave-uniform) load theirs on the spot, in a loop of their own -- with the loads inside the first round's code path the
+        // compiler waited for ALL outstanding memory operations (vmcnt(0): the prefetches just issued and the last step's store)
+        // on every step of every line
+        auto round = [&](const int e0, const uint32_t key_, const uint32_t meta_) {
             const int e = e0 + pl_;
-            if (G < 64 && e0 > 0 && e < K) { key = ckf[ecur + e]; meta = cmf[ecur + e]; }
             const bool act = e < K;
-            const int cost = (int)(meta & 0xFFu);
+            const int cost = (int)(meta_ & 0xFFu);
             int o = cost;
-            if (t > 0) o = (cost + (int)ng_match4_key(b0, b0 + LS, b0 + 2 * LS, K4pre, key, jump)) - (int)m;
+            if (G == 64 && rows16) o = (cost + (int)ng_match4_key_rows(b0, b0 + LS, b0 + 2 * LS, K4pre, key_, jump, row)) - (int)m;
+            else if (t > 0) o = (cost + (int)ng_match4_key(b0, b0 + LS, b0 + 2 * LS, K4pre, key_, jump)) - (int)m;
             if (act) {
-                b1[e] = key; b1[LS + e] = (uint32_t)o & 0xFF; b1[2 * LS + e] = (uint32_t)(o + a.P1) & 0xFF;
-                if (lact) atomicAdd(&Sf[ecur + (meta >> 8)], (uint32_t)o);                     // :249
+                b1[e] = key_; b1[LS + e] = (uint32_t)o & 0xFF; b1[2 * LS + e] = (uint32_t)(o + a.P1) & 0xFF;
+                if (lact) L4f[p_cur * (uint32_t)NG_L4_PER_PIXEL + (uint32_t)e] = (int16_t)o;   // :249 (|o| <= 510; summed by the WTA)
                 lov = min(lov, (uint32_t)o & 0xFFu);                                           // :74 narrowed
             } else if (e < LS) {                              // neutral entries in every other slot of the round
                 b1[e] = NG_PADKEY; b1[LS + e] = 0xFFFFu; b1[2 * LS + e] = 0xFFFFu;
+            }
+        };
+        round(0, key, meta);
+        if constexpr (G < 64) {
+            for (int e0 = G; e0 < kmax; e0 += G) {            // wave-uniform bound
+                // These two loads are spelled in asm, with their own wait, so that the compiler's wait-count bookkeeping never
+                // sees a memory operation inside the step: with a load on a conditional path it falls back to waiting for
+                // everything outstanding at the top of EVERY step (vmcnt(3) right behind the three prefetches: the last step's
+                // store and 21 loads that need not be back for another seven steps).
+                const uint32_t ee = (uint32_t)min(e0 + pl_, D - 1);
+                const uint32_t* pk = ckf + (ecur + ee);
+                const uint16_t* pm = cmf + (ecur + ee);
+                uint32_t k2, m2;
+                asm volatile("global_load_dword %0, %2, off\n\tglobal_load_ushort %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(k2), "=&v"(m2) : "v"(pk), "v"(pm) : "memory");
+                round(e0, k2, m2);
             }
         }
         uint32_t lo;
@@ -877,11 +1004,11 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     int t0 = 0;
     for (; t0 + PF <= len; t0 += PF) {
 #pragma unroll
-        for (int u = 0; u < PF; u++) step(t0 + u, rkey[u], rmeta[u], rlen[u]);
+        for (int u = 0; u < PF; u++) step(t0 + u, rkey[u], rmeta[u], rlen[u], rkey16[G == 64 ? u : 0], rmeta16[G == 64 ? u : 0]);
     }
 #pragma unroll
     for (int u = 0; u < PF - 1; u++)
-        if (t0 + u < len) step(t0 + u, rkey[u], rmeta[u], rlen[u]);            // wave-uniform
+        if (t0 + u < len) step(t0 + u, rkey[u], rmeta[u], rlen[u], rkey16[G == 64 ? u : 0], rmeta16[G == 64 ? u : 0]);   // wave-uniform
 }
 
 // S of every member of a group of repeats := S of the group's first member (for reading S back: the compact kernel
@@ -1072,10 +1199,12 @@ __global__ __launch_bounds__(256) void ng_wta_kernel(NgWtaArgs a) {
     const uint32_t* Sp = a.S + f * (size_t)NP * D + (size_t)p * D;
     const uint16_t* cmp = a.cm ? a.cm + f * (size_t)NP * D + (size_t)p * D : nullptr;
     const int n = cmp ? (int)a.dk[f * (size_t)NP + p] : D;
+    const bool l4 = cmp && a.L4 && a.kstat && a.kstat[257] != 0;              // launch-uniform: the compact kernel ran
+    const int16_t* Lp = a.L4 + (f * (size_t)NP + p) * NG_L4_PER_PIXEL;
     uint32_t lo = 0xFFFFFFFFu, idx = 0xFFFFFFFFu;
     for (int e = l16; e < n; e += 16) {
         const uint32_t d = cmp ? (uint32_t)(cmp[e] >> 8) : (uint32_t)e;
-        const uint32_t s = Sp[d];
+        const uint32_t s = l4 ? (uint32_t)((int)Lp[e] + (int)Lp[64 + e] + (int)Lp[128 + e] + (int)Lp[192 + e]) : Sp[d];
         if (s < lo || idx == 0xFFFFFFFFu || (s == lo && d < idx)) { lo = s; idx = d; }
     }
     uint32_t glo = lo;
@@ -1085,7 +1214,10 @@ __global__ __launch_bounds__(256) void ng_wta_kernel(NgWtaArgs a) {
 #pragma unroll
     for (int s = 8; s >= 1; s >>= 1) gidx = min(gidx, (uint32_t)__shfl_xor((int)gidx, s));
     if (l16 == 0 && pact) {
-        const Cand c = a.C[f * (size_t)NP * D + (size_t)p * D + gidx];
+        // the winner's motion vector: from its 4-byte key where the launch kept those (compact matcher, every key in range:
+        // the 12-byte list does not exist then), from the Cand list otherwise
+        const bool k4 = l4 && a.K4 && a.flags && a.flags[1] == 0;
+        const Cand c = k4 ? ng_unkey4(a.K4[f * (size_t)NP * D + (size_t)p * D + gidx]) : a.C[f * (size_t)NP * D + (size_t)p * D + gidx];
         a.minC[f * NP + p] = glo;
         a.flow[f * 2 * (size_t)NP + p] = (double)c.mvx;
         a.flow[f * 2 * (size_t)NP + NP + p] = (double)c.mvy;
@@ -1585,7 +1717,15 @@ void launch_ng_cost(hipStream_t st, const NgCostArgs& a, int frames) {
     static const bool by_hint = [] { const char* e = getenv("FSGM_NG_COST_HINT"); return !(e && e[0] == '0'); }();   // A/B switch
     if (by_hint && a.rX == 1 && a.rY == 1 && a.rAgg == 1) {
         const long long n = (long long)a.W * a.H * 9;
-        hipLaunchKernelGGL(ng_cost_hint_kernel, dim3((unsigned)((n + 255) / 256), frames), dim3(256), 0, st, a);
+        const dim3 grid((unsigned)((n + 255) / 256), frames);
+        if (a.K4 && a.flags) {                                // 4-byte entries, and the 12-byte list only if a key did not fit (gated on the device)
+            hipLaunchKernelGGL(ng_cost_hint_kernel<true>, grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL(ng_cost_hint_kernel<false>, grid, dim3(256), 0, st, a);
+        } else {
+            NgCostArgs b = a;
+            b.flags = nullptr;
+            hipLaunchKernelGGL(ng_cost_hint_kernel<false>, grid, dim3(256), 0, st, b);
+        }
         return;
     }
     const long long n = (long long)a.W * a.H * 9 * (2 * a.rX + 1) * (2 * a.rY + 1);
@@ -1619,7 +1759,7 @@ void launch_ng_aggregate(hipStream_t st, NgAggArgs a, int frames) {
         const char* genv = getenv("FSGM_NG_GRID");
         const int grid_env = genv && *genv ? atoi(genv) : -1;
         const bool can_stat = a.dd && a.dk && a.kstat;
-        if (can_stat && a.ck && a.cm && compact_env != 0 && grid_env != 1) {
+        if (can_stat && a.ck && a.cm && a.L4 && compact_env != 0 && grid_env != 1) {
             acc = 0;
             for (int i = 0; i < 4; i++) {
                 const int sl = a.W >= a.H ? ord_x[i] : ord_y[i];
@@ -1686,11 +1826,76 @@ void launch_ng_fill_repeats(hipStream_t st, uint32_t* S, const uint16_t* dd, con
     hipLaunchKernelGGL(ng_fill_repeats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, dd, cm, n, D);
 }
 
-void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, uint32_t* ck, uint16_t* cm, int W, int H, int D, int frames) {
+void launch_ng_dedupe(hipStream_t st, const Cand* C, uint16_t* dd, uint8_t* dk, uint32_t* dbox, uint32_t* kstat, uint32_t* ck, uint16_t* cm, int W, int H, int D, int frames,
+                      const uint32_t* K4, const uint32_t* flags) {
     const int n = W * H * frames;                            // frames are contiguous in all arrays
     if (kstat) (void)hipMemsetAsync(kstat, 0, NG_KSTAT_WORDS * sizeof(uint32_t), st);
     { const char* e = getenv("FSGM_NG_GRID"); if (e && e[0] == '0') dbox = nullptr; }      // no grid kernel in the set: no boxes needed
-    hipLaunchKernelGGL(ng_dedupe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, dd, dk, dbox, kstat, ck, cm, n, D);
+    hipLaunchKernelGGL(ng_dedupe_kernel, dim3((n + 3) / 4), dim3(256), 0, st, C, (K4 && flags) ? K4 : nullptr, flags, dd, dk, dbox, kstat, ck, cm, n, D);
+}
+
+// ---- 4-byte entries: what happens between the dedupe kernel and the matchers (all decided on the device, nothing read back) ----
+// kstat[258] := 1 when the compact matcher is the one that will run (the predicate of ng_agg_not_mine): S is not used then, and
+// with every key in range neither is the 12-byte list
+__global__ __launch_bounds__(256) void ng_decide_kernel(uint32_t* __restrict__ kstat, long long npix_all, int with_compact) {
+    __shared__ uint32_t sSum;
+    if (threadIdx.x == 0) sSum = 0;
+    __syncthreads();
+    uint32_t v = kstat[threadIdx.x];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += (uint32_t)__shfl_xor((int)v, s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sSum, v);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long npix = (((unsigned long long)(npix_all + 3) / 4 + 15) / 16) * 4;      // the dedupe kernel's sample
+        kstat[258] = (with_compact && (kstat[256] & 3u) == 0u && (unsigned long long)sSum < (unsigned long long)NG_COMPACT_MAX_K * npix) ? 1u : 0u;
+    }
+}
+// the general matchers read 12-byte entries: made from the keys when the keys are all there is (in range, but the lists too long for the compact matcher)
+__global__ __launch_bounds__(256) void ng_expand_kernel(const uint32_t* __restrict__ K4, Cand* __restrict__ C, const uint32_t* __restrict__ flags,
+                                                        const uint32_t* __restrict__ kstat, long long n) {
+    if (flags[1] != 0 || kstat[258] != 0) return;            // (a few thousand workgroups that loop: an early return costs nothing then)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) C[i] = ng_unkey4(K4[i]);
+}
+// S shares its memory with the keys: zeroed (calc_pyd_cost_sgm_ng.cpp:111) once they are no longer needed, and only when a matcher will add to it
+__global__ __launch_bounds__(256) void ng_zero_s_kernel(uint4* __restrict__ S4, const uint32_t* __restrict__ kstat, long long n16, int tail) {
+    if (kstat[258] != 0) return;
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long i = i0; i < n16; i += (long long)gridDim.x * 256) S4[i] = make_uint4(0, 0, 0, 0);
+    if (i0 == 0) { uint32_t* t = (uint32_t*)(S4 + n16); for (int k = 0; k < tail; k++) t[k] = 0; }
+}
+
+bool ng_compact_possible(const NgAggArgs& a) {
+    const char* cenv = getenv("FSGM_NG_COMPACT");
+    const int compact_env = cenv && *cenv ? atoi(cenv) : -1;
+    const char* genv = getenv("FSGM_NG_GRID");
+    const int grid_env = genv && *genv ? atoi(genv) : -1;
+    const char* denv = getenv("FSGM_NG_DEDUPE");
+    if (denv && atoi(denv) == 0) return false;
+    return a.D <= 128 && a.unsafe && a.dd && a.dk && a.kstat && a.ck && a.cm && a.L4 && compact_env != 0 && grid_env != 1;
+}
+
+void launch_ng_prepare_matchers(hipStream_t st, const NgAggArgs& a, const uint32_t* K4, Cand* C, const uint32_t* flags, int frames) {
+    const long long npix = (long long)a.W * a.H * frames, n = npix * a.D;
+    hipLaunchKernelGGL(ng_decide_kernel, dim3(1), dim3(256), 0, st, a.kstat, npix, ng_compact_possible(a) ? 1 : 0);
+    hipLaunchKernelGGL(ng_expand_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, K4, C, flags, (const uint32_t*)a.kstat, n);
+    hipLaunchKernelGGL(ng_zero_s_kernel, dim3((unsigned)std::min<long long>((n / 4 + 256) / 256, 4096)), dim3(256), 0, st, (uint4*)a.S, (const uint32_t*)a.kstat, n / 4, (int)(n % 4));
+}
+
+__global__ __launch_bounds__(256) void ng_l4_to_s_kernel(uint32_t* __restrict__ S, const int16_t* __restrict__ L4, const uint16_t* __restrict__ cm,
+                                                         const uint8_t* __restrict__ dk, const uint32_t* __restrict__ kstat, long long npix, int D) {
+    if (kstat[257] == 0) return;                              // another matcher ran: S is complete already
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long p = i >> 6;
+    const int e = (int)(i & 63);
+    if (p >= npix || e >= (int)dk[p]) return;
+    const int16_t* Lp = L4 + p * NG_L4_PER_PIXEL;
+    S[p * D + (cm[p * D + e] >> 8)] = (uint32_t)((int)Lp[e] + (int)Lp[64 + e] + (int)Lp[128 + e] + (int)Lp[192 + e]);
+}
+
+void launch_ng_l4_to_s(hipStream_t st, uint32_t* S, const int16_t* L4, const uint16_t* cm, const uint8_t* dk, const uint32_t* kstat, int W, int H, int D, int frames) {
+    const long long npix = (long long)W * H * frames;
+    hipLaunchKernelGGL(ng_l4_to_s_kernel, dim3((unsigned)((npix * 64 + 255) / 256)), dim3(256), 0, st, S, L4, cm, dk, kstat, npix, D);
 }
 
 void launch_ng_wta(hipStream_t st, const NgWtaArgs& a, int frames) {
