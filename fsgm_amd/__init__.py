@@ -6,7 +6,7 @@ multi-path SGM aggregation hot path, behind the reference's MEX argument lists.
 
 Everything computes on the GPU through libfsgm_hip.so (C ABI in include/fsgm.h).
 """
-from .epi import calc_cost_sgm, calc_cost_sgm_batch, EpiPlan, epipolar_maps, epipolar_sgm_of, census, sgm, auto_pipeline  # noqa: F401
+from .epi import calc_cost_sgm, calc_cost_sgm_batch, EpiPlan, epipolar_maps, epipolar_sgm_of, epipolar_from_F, census, sgm, auto_pipeline  # noqa: F401
 from .pyd import calc_pyd_cost_sgm, calc_pyd_cost_sgm_batch, PydPlan  # noqa: F401
 from .pyramid import pyramidal_sgm, pyramidal_sgm_ng, pyramidal_sgm_batch, pyramidal_sgm_ng_batch, PyramidPlan, NgPyramidPlan  # noqa: F401
 from .post import (speckle_filter, calc_disp_from_first, forward_backward_check, scanline_in_fill, vzInd2Disp, vmf,  # noqa: F401

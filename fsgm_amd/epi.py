@@ -254,6 +254,27 @@ def _bind_driver(lib):
     lib._epi_driver_bound = True
 
 
+def epipolar_from_F(F, K, pts1=None, pts2=None, inliers=None):
+    """epipolar_geometry.m:40-96 on the host: (H, epipole, direction, ambiguous) from the fundamental matrix F, the intrinsics K
+    and the matched points (n x 2 arrays of (x, y), MATLAB's 1-based pixel coordinates; inliers: boolean mask or None = all).
+    What epipolar_maps / epipolar_sgm_of take next.  The SURF + LMedS estimate of F itself (:130-149) is toolbox code, not built."""
+    lib = _lib.load()
+    _bind_driver(lib)
+    lib.fsgm_epipolar_from_F.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EpiGeometry), C.POINTER(C.c_int32)]
+    F, K = np.ascontiguousarray(F, np.float64), np.ascontiguousarray(K, np.float64)
+    if F.shape != (3, 3) or K.shape != (3, 3):
+        raise TypeError("F and K must be 3x3 matrices")
+    n = 0 if pts1 is None else len(pts1)
+    p1 = np.ascontiguousarray(pts1, np.float64).reshape(n, 2) if n else None
+    p2 = np.ascontiguousarray(pts2, np.float64).reshape(n, 2) if n else None
+    inl = np.ascontiguousarray(inliers, np.uint8) if inliers is not None else None
+    if inl is not None and inl.shape != (n,):
+        raise ValueError("inliers must have one entry per match")
+    g, amb = EpiGeometry(), C.c_int32()
+    check(lib.fsgm_epipolar_from_F(ptr(F), ptr(K), n, ptr(p1), ptr(p2), ptr(inl), C.byref(g), C.byref(amb)))
+    return np.array(g.H[:]).reshape(3, 3), (g.epipole[0], g.epipole[1]), int(g.direction), bool(amb.value)
+
+
 def epipolar_maps(F, H, epipole, direction, width, height, *, device=0):
     """(PrefD0, NormlizeDirection, Offset, Rflow) of epipolar_geometry.m:99-115 from F, H = K*R/K, the
     epipole in image 2 and the expansion/contraction flag."""

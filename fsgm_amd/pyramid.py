@@ -59,21 +59,30 @@ def _check_images(I0, I1):
     return I0, I1, (1 if I0.ndim == 2 else 3)
 
 
-def pyramidal_sgm(I0, I1, numPyd=5, *, device=0, **overrides):
+def pyramidal_sgm(I0, I1, numPyd=5, *, device=0, out=None, **overrides):
     """[mvCurLevel, mvPyd, minC] = pyramidal_sgm(I0, I1, numPyd) (pyramidal_sgm.m:1).  Keyword overrides
     name the function's hard-coded parameters (P1, P2, aggHalfWinSize, verSearchHalfWinSize,
-    horSearchHalfWinSize, enableDiagonal, totalPass, adaptiveP2; pyramidal_sgm.m:15-22)."""
+    horSearchHalfWinSize, enableDiagonal, totalPass, adaptiveP2; pyramidal_sgm.m:15-22).
+    out: a previous call's result tuple to write into instead of allocating (the results of that call are overwritten): a loop
+    over frames then hands the library pages that are already resident, as a MEX gateway's zero-filled outputs are."""
     lib = _lib.load()
     _bind(lib)
     I0, I1, ch = _check_images(I0, I1)
     H, W = I0.shape[-2:]
     prm = _params(lib, numPyd, device, overrides)
-    mv = np.zeros((2, H, W), np.float64)
-    minC = np.zeros((H, W), np.uint32)
     sizes = [(W, H)]
     for _ in range(1, prm.numPyd):
         sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
-    mvPyd = [np.zeros((2, h, w), np.float64) for (w, h) in sizes]
+    if out is not None:
+        mv, mvPyd, minC = out
+        ok = (mv.shape == (2, H, W) and mv.dtype == np.float64 and minC.shape == (H, W) and minC.dtype == np.uint32 and len(mvPyd) == len(sizes)
+              and all(a.shape == (2, h, w) and a.dtype == np.float64 and a.flags.c_contiguous for a, (w, h) in zip(mvPyd, sizes)))
+        if not ok or not mv.flags.c_contiguous or not minC.flags.c_contiguous:
+            raise ValueError("out does not match this call's shapes")
+    else:
+        mv = np.empty((2, H, W), np.float64)                 # every element is written by the call
+        minC = np.empty((H, W), np.uint32)
+        mvPyd = [np.empty((2, h, w), np.float64) for (w, h) in sizes]
     ptrs = (C.c_void_p * len(mvPyd))(*[a.ctypes.data for a in mvPyd])
     check(lib.fsgm_pyramidal_sgm_host(ptr(I0), ptr(I1), W, H, ch, C.byref(prm), ptr(mv), ptr(minC), ptrs))
     return mv, mvPyd, minC
@@ -293,7 +302,7 @@ def pyramidal_sgm_ng_batch(pairs, numPyd=3, *, devices=(0,), **overrides):
     return _pairs_over_devices(lib.fsgm_pyramidal_sgm_ng_batch_devices_host, prm, pairs, devices)
 
 
-def pyramidal_sgm_ng(I0, I1, numPyd=3, *, device=0, **overrides):
+def pyramidal_sgm_ng(I0, I1, numPyd=3, *, device=0, out=None, **overrides):
     """The level loop of pyramidal_sgm.m (:24-76) with calc_pyd_cost_sgm_ng swapped in for calc_pyd_cost_sgm
     (BASELINE config 4): the neighbour-guided MEX takes the previous level's flow as its hint map and returns
     the flow itself (calc_pyd_cost_sgm_ng.cpp:458-480).  Defaults are the argument values of ng_sgm.m:20
@@ -315,9 +324,14 @@ def pyramidal_sgm_ng(I0, I1, numPyd=3, *, device=0, **overrides):
     sizes = [(W, H)]
     for _ in range(1, prm.numPyd):
         sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
-    flow = np.zeros((2, H, W), np.float64)
-    minC = np.zeros((H, W), np.uint32)
-    lv = [np.zeros((2, h, w), np.float64) for (w, h) in sizes]
+    if out is not None:                                      # a previous call's result tuple, overwritten (see pyramidal_sgm)
+        flow, lv, minC = out
+        if flow.shape != (2, H, W) or minC.shape != (H, W) or [a.shape for a in lv] != [(2, h, w) for (w, h) in sizes]:
+            raise ValueError("out does not match this call's shapes")
+    else:
+        flow = np.empty((2, H, W), np.float64)
+        minC = np.empty((H, W), np.uint32)
+        lv = [np.empty((2, h, w), np.float64) for (w, h) in sizes]
     ptrs = (C.c_void_p * len(lv))(*[a.ctypes.data for a in lv])
     check(lib.fsgm_pyramidal_sgm_ng_host(ptr(I0), ptr(I1), W, H, ch, C.byref(prm), ptr(flow), ptr(minC), ptrs))
     return flow, lv[::-1], minC

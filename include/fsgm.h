@@ -193,7 +193,8 @@ fsgm_status fsgm_census_host(const uint8_t* img, int32_t width, int32_t height, 
  * epipolar_sgm_of with the dense maps made on the device  (dense half only)
  *
  * epipolar_geometry.m has a sparse half -- SURF features, an LMedS fundamental matrix, two SVDs and
- * the expansion vote (:30-96), all MATLAB toolbox calls, NOT built here -- and a dense half: the
+ * the expansion vote (:30-96) -- the toolbox part of it (:130-149) is NOT built here, the 3x3 algebra from F on is a host helper
+ * (fsgm_epipolar_from_F below) -- and a dense half: the
  * per-pixel maps Pd0 / normlizeDirection / Offset / Rflow from F, H, the epipole and the direction
  * flag (:99-115, rotation_motion.m).  The dense half and the tail of epipolar_sgm_of.m (:33-51: gray
  * conversion, calc_cost_sgm, flow = disparity * direction + rotation flow) run on the device, so a
@@ -206,6 +207,16 @@ typedef struct {
     double epipole[2];    /* epipole in image 2, epi(1:2)                          (:43-45) */
     int32_t direction;    /* 0 = expansion, 1 = contraction (directions negated)  (:92-96,:108-110) */
 } fsgm_epi_geometry;
+
+/* The in-tree remainder of the sparse half: epipolar_geometry.m:40-96 -- from the fundamental matrix F (however it was estimated:
+ * the SURF + LMedS front end, :130-149, is MATLAB toolbox code and not built), the intrinsics K and the inlier matches to the
+ * epipole in image 2 (svd(F'), :40-43), H = K*R/K with R the rotation of E = K'FK that is close to the identity (:46-65) and the
+ * expansion / contraction vote (:68-96).  3x3 host algebra, no GPU.  pts1 / pts2: n_points x (x, y) in MATLAB's 1-based pixel
+ * coordinates; inliers (may be NULL = all) one byte per match.  *ambiguous (may be NULL) = 1 when the diagonal test of :58-62
+ * accepts both or neither of the two candidate rotations (the reference's answer then depends on its SVD's signs).  UNPINNED:
+ * MATLAB's svd is LAPACK's, this is a Jacobi solver; the quantities used are invariant to an SVD's sign freedoms. */
+fsgm_status fsgm_epipolar_from_F(const double* F /* 9, row-major */, const double* K /* 9 */, int32_t n_points, const double* pts1,
+                                 const double* pts2, const uint8_t* inliers, fsgm_epi_geometry* out, int32_t* ambiguous);
 
 /* [PrefD0, NormlizeDirection, Offset, Rflow] of epipolar_geometry.m:99-115: f64 [2][H][W] / [H][W] */
 fsgm_status fsgm_epipolar_maps_host(const fsgm_epi_geometry* g, int32_t width, int32_t height, double* Pd0,
