@@ -65,6 +65,15 @@ namespace fsgm {
 #ifndef FSGM_BAND_R16
 #define FSGM_BAND_R16 1         // first pass: the from-above-right state as 2 x u16 in LDS (A/B knob)
 #endif
+#ifndef FSGM_BAND_Y16
+#define FSGM_BAND_Y16 0         // 1: the first pass's sums beyond a byte (4*(P1+P2) > 255) cross to the second pass as the registers hold
+                                // them (2 x u16: two 16-byte planes per lane) instead of low bytes + a 9th-bit plane -- 0.75 B per voxel
+                                // more each way for 11 + 16 fewer instructions per step.  Measured in round 4 (512 frames, same box,
+                                // alternating): SQ_INSTS_VALU -4.4 % / -3.4 % per pass as intended, durations 18.70 / 24.43 ms against
+                                // 18.77 / 23.62 -- the chip clocks DOWN with the extra bytes (GRBM cycles / duration: 2.09 against
+                                // 2.15 GHz in the first pass): the stage runs into the power limit, where instructions traded for
+                                // bytes buy nothing.  Off; kept as a knob (profiles/r04_band_y16.txt)
+#endif
 #ifndef FSGM_BAND_SLACK
 #define FSGM_BAND_SLACK 32      // chained form: columns of lead a band gives the band above before it starts (A/B knob)
 #endif
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
     }
     const uint8_t* __restrict__ Cf = a.C + f * a.c_frame_stride;
     uint8_t* __restrict__ Yf = a.Y + f * a.y_frame_stride;
-    uint8_t* __restrict__ Bf = BITS ? (uint8_t*)(a.Yb + f * a.yb_frame_stride) : nullptr;     // [NP][LPP] dwords
+    constexpr bool Y16 = BITS && FSGM_BAND_Y16 != 0;         // BITS: the second volume is registers 4-7 as they are (Yf: registers 0-3), not a bit plane
+    uint8_t* __restrict__ Bf = BITS ? (uint8_t*)(a.Yb + f * a.yb_frame_stride) : nullptr;     // [NP][LPP] dwords (Y16: [NP][LPP] uint4)
     uint8_t* __restrict__ Ef = (uint8_t*)(a.edge + f * a.edge_frame_stride);                  // [W][NST][LPP] uint4 (CHAIN: one such map per band boundary)
     const uint32_t tag = CHAIN ? a.tag : 0u;
     uint8_t* __restrict__ recb = MODE == 2 ? (uint8_t*)(a.rec + f * (size_t)NP) : nullptr;
@@ -243,12 +253,17 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
         uint4 ringE[PFE];
 #pragma unroll
         for (int i = 0; i < PFE; i++) ringE[i] = startP;
-        uint32_t ringB[MODE == 2 && BITS ? PF : 1];
+        uint32_t ringB[MODE == 2 && BITS && !Y16 ? PF : 1];
+        uint4 ringB4[MODE == 2 && Y16 ? PF : 1];
 #pragma unroll
         for (int i = 0; i < PF; i++) {
             const uint32_t off = vox_off(i);
             ringC[i] = *(const uint4*)(Cf + off);
-            if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = *(const uint32_t*)(Bf + bit_off(i)); }
+            if (MODE == 2) {
+                ringY[i] = vol_load(Yf + off);
+                if (Y16) ringB4[i] = vol_load(Bf + off);
+                else if (BITS) ringB[i] = *(const uint32_t*)(Bf + bit_off(i));
+            }
         }
         if (loader) {
 #pragma unroll
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 
         // one step of this wave's rows.  EDGE: a pixel of the wave is at / outside an image border or in row 0, or a row
         // of the wave lies below the image (selects allowed); the plain variant has none.
-        auto do_step = [&](const int u, const uint4 cw, const uint4 cy, const uint32_t cb, auto edge_tag) {
+        auto do_step = [&](const int u, const uint4 cw, const uint4 cy, const uint32_t cb, const uint4 cb4, auto edge_tag) {
             constexpr bool EDGE = decltype(edge_tag)::value;
             const int par = u & 1;
             const int x = u - SKEW * r;
@@ -284,7 +299,9 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             if (MODE == 2) {
                 // the first pass's sum joins the running sum right away: its five registers are free for the rest of the step
                 uint32_t E2[8];
-                if (BITS) unpack_p9(cy, cb, E2); else unpack_p(cy, E2);
+                if (Y16) { E2[0] = cy.x; E2[1] = cy.y; E2[2] = cy.z; E2[3] = cy.w; E2[4] = cb4.x; E2[5] = cb4.y; E2[6] = cb4.z; E2[7] = cb4.w; }
+                else if (BITS) unpack_p9(cy, cb, E2);
+                else unpack_p(cy, E2);
 #pragma unroll
                 for (int i = 0; i < 8; i++) YS[i] += E2[i];
             }
@@ -363,8 +380,13 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
                 // the sum of this pass's y (:227-232): low bytes + 9th bits
                 if (inside) {
                     const uint32_t px = (uint32_t)pix_of(xc, yc);
-                    vol_store(Yf + px * D + (uint32_t)j * 16, pack_p(YS));
-                    if (BITS) *(uint32_t*)(Bf + (px * LPP + (uint32_t)j) * 4u) = pack_hi_bits(YS);
+                    if (Y16) {
+                        vol_store(Yf + px * D + (uint32_t)j * 16, make_uint4(YS[0], YS[1], YS[2], YS[3]));
+                        vol_store(Bf + px * D + (uint32_t)j * 16, make_uint4(YS[4], YS[5], YS[6], YS[7]));
+                    } else {
+                        vol_store(Yf + px * D + (uint32_t)j * 16, pack_p(YS));
+                        if (BITS) *(uint32_t*)(Bf + (px * LPP + (uint32_t)j) * 4u) = pack_hi_bits(YS);
+                    }
                 }
             } else {
                 // S = PATHS*(C + P2) - (this pass's y + the first pass's), WTA on the spot (:227-232, :259-275)
@@ -379,7 +401,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
                 }
             }
         };
-        auto step = [&](const int u, const uint4 cw, const uint4 cy, const uint32_t cb) {
+        auto step = [&](const int u, const uint4 cw, const uint4 cy, const uint32_t cb, const uint4 cb4) {
             if (wave == 0 && have_above) {                                            // "row -1" of step u: column u + SKEW of the band above
                 const uint4 v = settle(ringE[0], edge_at(u + SKEW), loader);
 #pragma unroll
@@ -390,8 +412,8 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
                 }
             }
             if (wave_rows && u >= act_lo && u <= act_hi) {                            // wave-uniform
-                if (wave_plain_rows && u >= pl_lo && u <= pl_hi) do_step(u, cw, cy, cb, std::false_type{});
-                else do_step(u, cw, cy, cb, std::true_type{});
+                if (wave_plain_rows && u >= pl_lo && u <= pl_hi) do_step(u, cw, cy, cb, cb4, std::false_type{});
+                else do_step(u, cw, cy, cb, cb4, std::true_type{});
             }
 #ifndef FSGM_BAND_NOBAR                                                  /* timing experiment only: wrong results without it */
             __syncthreads();                                   // states of step u visible to step u+1
@@ -405,16 +427,21 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
                 const int u = u0 + i;
                 const uint4 cw = ringC[i];
                 const uint4 cy = ringY[MODE == 2 ? i : 0];
-                const uint32_t cb = ringB[MODE == 2 && BITS ? i : 0];
+                const uint32_t cb = ringB[MODE == 2 && BITS && !Y16 ? i : 0];
+                const uint4 cb4 = ringB4[MODE == 2 && Y16 ? i : 0];
                 const uint32_t off = vox_off(u + PF);
                 ringC[i] = *(const uint4*)(Cf + off);
-                if (MODE == 2) { ringY[i] = vol_load(Yf + off); if (BITS) ringB[i] = *(const uint32_t*)(Bf + bit_off(u + PF)); }
-                step(u, cw, cy, cb);
+                if (MODE == 2) {
+                    ringY[i] = vol_load(Yf + off);
+                    if (Y16) ringB4[i] = vol_load(Bf + off);
+                    else if (BITS) ringB[i] = *(const uint32_t*)(Bf + bit_off(u + PF));
+                }
+                step(u, cw, cy, cb, cb4);
             }
         }
 #pragma unroll
         for (int i = 0; i < PF - 1; i++)
-            if (u0 + i < nsteps) step(u0 + i, ringC[i], ringY[MODE == 2 ? i : 0], ringB[MODE == 2 && BITS ? i : 0]);   // workgroup-uniform
+            if (u0 + i < nsteps) step(u0 + i, ringC[i], ringY[MODE == 2 ? i : 0], ringB[MODE == 2 && BITS && !Y16 ? i : 0], ringB4[MODE == 2 && Y16 ? i : 0]);   // workgroup-uniform
         if (!CHAIN) {                                          // the band below reads what the last row stored: stores done before anyone goes on
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -426,7 +453,8 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 // launchers
 // ---------------------------------------------------------------------------------------------
 size_t band_edge_uint4s(int W, int D, int paths) { const int lpp = agg_packed_lpp(D); return (size_t)W * (paths == 8 ? 3 : 1) * lpp; }   // per frame and band boundary
-size_t band_bits_u32s(int W, int H, int D) { return (size_t)W * H * agg_packed_lpp(D); }                                                 // per frame
+// per frame: the bit plane (one dword per lane) or, with FSGM_BAND_Y16, registers 4-7 of every lane (16 bytes: as large as C)
+size_t band_bits_u32s(int W, int H, int D) { return (size_t)W * H * agg_packed_lpp(D) * (FSGM_BAND_Y16 ? 4 : 1); }
 // the first pass's sum of four (y + P1) needs a 9th bit above 255
 bool band_needs_bits(int paths, int P1, int P2) { return paths == 8 && 4 * (P1 + P2) > 255; }
 // D = 16 << k; P1 + P2 <= 127: states and the biased y as bytes, two / four of them summed in 8 / 9 bits;

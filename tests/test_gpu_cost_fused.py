@@ -134,3 +134,23 @@ def test_fused_cost_rows_that_leave_the_fast_rounding(gpu_lib, oracle):
     want = oracle.epi_cost(I1, I2, D, 0.3, pd0, nd, off)
     got = _cost(W, H, D, [(I1, I2, pd0, nd, off)])[0]
     np.testing.assert_array_equal(got, want)
+
+
+def test_rows_with_horizontal_epipolar_lines_take_the_x_only_offsets(gpu_lib, oracle):
+    """Rows whose lanes all have uy == 0 (of either sign) skip the y coordinate; rows with a single lane that has not, rows with
+    uy == 0 but a fractional start row (round(by) is not y), and a NaN direction stay exact."""
+    W, H, D = 130, 40, 32
+    I1, I2, pd0, nd, off = _frame(W, H, D, seed=21)
+    nd[1, 0:30] = 0.0                                        # horizontal lines in rows 0..29
+    nd[1, 3:6] = -0.0
+    nd[0, 0:30] = np.where(nd[0, 0:30] >= 0, 1.0, -1.0)
+    nd[1, 7, 64] = 1e-300                                    # one lane of a row that is not horizontal after all
+    nd[1, 9, 129] = np.nan
+    pd0[1, 11] += 0.5                                        # start rows on halves: round-half-away of by
+    pd0[1, 12] -= 0.49999999999999994
+    pd0[1, 13] = -3.0                                        # start row above the image: clamps to row 0
+    pd0[1, 14] = H + 7.25                                    # below: clamps to the last row
+    want = oracle.epi_cost(I1, I2, D, 0.3, pd0, nd, off)
+    for fused in (True, False):
+        got = _cost(W, H, D, [(I1, I2, pd0, nd, off)], fused=fused)[0]
+        np.testing.assert_array_equal(got, want)
