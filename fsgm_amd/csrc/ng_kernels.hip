@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void ng_dedupe_kernel(const Cand* __restrict__
     sk[wave][d1] = has1 ? k1 : 0xFFFFFFFFu;
     const bool all_ok = __builtin_amdgcn_ballot_w64(!(ok0 && ok1)) == 0;
     __builtin_amdgcn_wave_barrier();
-    if (dbox) {
+    if (dbox && !(K4 && flags[1] == 0)) {                     // (4-byte entries: ng_dbox_kernel makes the boxes, and only when a matcher needs them)
         uint32_t box = NG_BOX_WIDE;
         if (all_ok) {                                                      // every |mv| < 4096: biased values are small and positive
             const Cand f0 = has0 ? e0 : c[0], f1 = has1 ? e1 : f0;         // lanes without an entry repeat one that exists
@@ -1865,6 +1865,22 @@ __global__ __launch_bounds__(256) void ng_zero_s_kernel(uint4* __restrict__ S4, 
     if (i0 == 0) { uint32_t* t = (uint32_t*)(S4 + n16); for (int k = 0; k < tail; k++) t[k] = 0; }
 }
 
+// The bounding box of a pixel's motion vectors (what the grid matcher stages by): the dedupe kernel's own job when it is asked for
+// one, but a quarter of its instructions (four wave reductions) -- with 4-byte entries it is left to this kernel, which only
+// runs when the compact matcher does not
+__global__ __launch_bounds__(256) void ng_dbox_kernel(const uint32_t* __restrict__ K4, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ kstat,
+                                                      uint32_t* __restrict__ dbox, int NPtot, int D) {
+    if (flags[1] != 0 || kstat[258] != 0) return;            // (flags[1] != 0: the dedupe kernel read 12-byte entries and made the boxes itself)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p = blockIdx.x * 4 + wave; p < NPtot; p += gridDim.x * 4) {
+        const uint32_t* k = K4 + (size_t)p * D;
+        const Cand f0 = ng_unkey4(k[min(lane, D - 1)]), f1 = ng_unkey4(k[min(lane + 64, D - 1)]);
+        const uint32_t xl = wave_min_u32((uint32_t)(min(f0.mvx, f1.mvx) + 0x4000)), xh = 0x8000u - wave_min_u32((uint32_t)(0x4000 - max(f0.mvx, f1.mvx)));
+        const uint32_t yl = wave_min_u32((uint32_t)(min(f0.mvy, f1.mvy) + 0x4000)), yh = 0x8000u - wave_min_u32((uint32_t)(0x4000 - max(f0.mvy, f1.mvy)));
+        if (lane == 0) dbox[p] = (xh - xl < (uint32_t)NG_GB && yh - yl < (uint32_t)NG_GB) ? ((xl << 16) | yl) : NG_BOX_WIDE;
+    }
+}
+
 bool ng_compact_possible(const NgAggArgs& a) {
     const char* cenv = getenv("FSGM_NG_COMPACT");
     const int compact_env = cenv && *cenv ? atoi(cenv) : -1;
@@ -1879,6 +1895,8 @@ void launch_ng_prepare_matchers(hipStream_t st, const NgAggArgs& a, const uint32
     const long long npix = (long long)a.W * a.H * frames, n = npix * a.D;
     hipLaunchKernelGGL(ng_decide_kernel, dim3(1), dim3(256), 0, st, a.kstat, npix, ng_compact_possible(a) ? 1 : 0);
     hipLaunchKernelGGL(ng_expand_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, K4, C, flags, (const uint32_t*)a.kstat, n);
+    if (a.dbox) hipLaunchKernelGGL(ng_dbox_kernel, dim3((unsigned)std::min<long long>((npix + 3) / 4, 4096)), dim3(256), 0, st, K4, flags, (const uint32_t*)a.kstat,
+                                   const_cast<uint32_t*>(a.dbox), (int)npix, a.D);
     hipLaunchKernelGGL(ng_zero_s_kernel, dim3((unsigned)std::min<long long>((n / 4 + 256) / 256, 4096)), dim3(256), 0, st, (uint4*)a.S, (const uint32_t*)a.kstat, n / 4, (int)(n % 4));
 }
 
