@@ -40,6 +40,74 @@ __global__ __launch_bounds__(256) void census5x5_kernel(const uint8_t* __restric
     cen[(size_t)blockIdx.y * NP + p] = code;
 }
 
+// The same transform, four pixels a thread (round 4; the one-pixel kernel above spends 213 instructions a pixel, most of them
+// the clamped addresses of its 25 byte loads, and ran at VALU busy 1.03: 0.005 of the cost stage's 0.046 ms per frame).  A thread
+// owns pixels x0 .. x0 + 3 of a row (x0 a multiple of 4) and loads the 12 bytes x0 - 4 .. x0 + 7 of each of the five rows as
+// three dwords; a tap is one compare with an SDWA byte select and one add-with-carry: code = 2 code + [nbr >= ctr], the
+// reference's (code + bit) << 1 with the last shift applied at the end.  Threads whose bytes would leave the image -- the two
+// border rows, the first and the last columns -- take the clamped form above.
+template <int BYTE>
+__device__ __forceinline__ unsigned long long census_cmp(const uint32_t w, const uint32_t ctr) {      // lane mask of [byte BYTE of w >= ctr]
+    unsigned long long m;
+    if (BYTE == 0) asm("v_cmp_le_u32_sdwa %0, %1, %2 src0_sel:DWORD src1_sel:BYTE_0" : "=s"(m) : "v"(ctr), "v"(w));
+    if (BYTE == 1) asm("v_cmp_le_u32_sdwa %0, %1, %2 src0_sel:DWORD src1_sel:BYTE_1" : "=s"(m) : "v"(ctr), "v"(w));
+    if (BYTE == 2) asm("v_cmp_le_u32_sdwa %0, %1, %2 src0_sel:DWORD src1_sel:BYTE_2" : "=s"(m) : "v"(ctr), "v"(w));
+    if (BYTE == 3) asm("v_cmp_le_u32_sdwa %0, %1, %2 src0_sel:DWORD src1_sel:BYTE_3" : "=s"(m) : "v"(ctr), "v"(w));
+    return m;
+}
+__device__ __forceinline__ void census_acc(uint32_t& code, const unsigned long long m) {              // code = 2 code + bit
+    asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(code) : "s"(m) : "vcc");
+}
+// one tap of each of the thread's four pixels: the four compares first, then the four accumulations -- a mask is read three
+// instructions after it is written (back to back the pair needs a wait state: an s_nop per tap)
+#define FSGM_CENSUS_TAPS(w0, b0, w1, b1, w2, b2, w3, b3)                                                                  \
+    do {                                                                                                                    \
+        const unsigned long long m0 = census_cmp<b0>(w0, c0), m1 = census_cmp<b1>(w1, c1), m2 = census_cmp<b2>(w2, c2),     \
+                                 m3 = census_cmp<b3>(w3, c3);                                                               \
+        census_acc(k0, m0); census_acc(k1, m1); census_acc(k2, m2); census_acc(k3, m3);                                     \
+    } while (0)
+
+__global__ __launch_bounds__(256) void census5x5_quad_kernel(const uint8_t* __restrict__ img, uint32_t* __restrict__ cen, int W, int H) {
+    const int Wq = (W + 3) >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Wq * H) return;
+    const size_t NP = (size_t)W * H;
+    const uint8_t* im = img + blockIdx.y * NP;
+    uint32_t* out = cen + blockIdx.y * NP;
+    const int y = q / Wq, x0 = (q - y * Wq) * 4;
+    if (y >= 2 && y <= H - 3 && x0 >= 4 && x0 + 7 <= W - 1) {
+        const uint8_t* r0 = im + (size_t)y * W + x0;
+        const uint32_t cw = *(const uint32_t*)r0;                           // (rows start at y W: dword loads at any byte address)
+        const uint32_t c0 = cw & 0xFFu, c1 = (cw >> 8) & 0xFFu, c2 = (cw >> 16) & 0xFFu, c3 = cw >> 24;
+        uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+#pragma unroll
+        for (int oy = -2; oy <= 2; oy++) {
+            const uint8_t* r = r0 + (ptrdiff_t)oy * W;
+            const uint32_t L = *(const uint32_t*)(r - 4), M = oy == 0 ? cw : *(const uint32_t*)r, R = *(const uint32_t*)(r + 4);
+            // pixel 0: columns x0 - 2 .. x0 + 2 = L.2 L.3 M.0 M.1 M.2; pixel 1: L.3 M.0 .. M.3; pixel 2: M.0 .. M.3 R.0; pixel 3: M.1 .. M.3 R.0 R.1
+            FSGM_CENSUS_TAPS(L, 2, L, 3, M, 0, M, 1);                       // dx = -2
+            FSGM_CENSUS_TAPS(L, 3, M, 0, M, 1, M, 2);                       // dx = -1
+            FSGM_CENSUS_TAPS(M, 0, M, 1, M, 2, M, 3);                       // dx = 0
+            FSGM_CENSUS_TAPS(M, 1, M, 2, M, 3, R, 0);                       // dx = +1
+            FSGM_CENSUS_TAPS(M, 2, M, 3, R, 0, R, 1);                       // dx = +2
+        }
+        uint32_t* o = out + (size_t)y * W + x0;
+        o[0] = k0 << 1; o[1] = k1 << 1; o[2] = k2 << 1; o[3] = k3 << 1;
+        return;
+    }
+    for (int i = 0; i < 4; i++) {                                             // borders: replicate (common.cpp:17-18)
+        const int x = x0 + i;
+        if (x >= W) break;
+        const unsigned ctr = im[(size_t)y * W + x];
+        uint32_t code = 0;
+        for (int oy = -2; oy <= 2; oy++) {
+            const int y2 = clampi(y + oy, 0, H - 1);
+            for (int ox = -2; ox <= 2; ox++) code = (code + (im[(size_t)y2 * W + clampi(x + ox, 0, W - 1)] >= ctr ? 1u : 0u)) << 1;
+        }
+        out[(size_t)y * W + x] = code;
+    }
+}
+
 // =============================================================================================
 // raw Hamming cost along the epipolar line  (calc_cost_sgm.cpp:343-381).
 // One thread = one pixel x 4 consecutive d.  fp64 geometry in the reference's association
@@ -819,6 +887,14 @@ void launch_vz_convert(hipStream_t st, uint32_t* bestD, const double* off, int W
 // launchers
 // =============================================================================================
 void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int H, int frames) {
+    static const bool quad = [] { const char* e = getenv("FSGM_CENSUS_QUAD"); return !(e && e[0] == '0'); }();   // A/B switch
+    // (a single 1242x375 frame is a latency-bound launch: 466 k threads of the one-pixel kernel finish before 116 k threads of
+    // this one -- cost stage 0.060 against 0.064 ms; from a few frames on the instruction count decides: 0.0427 -> 0.0408 at 512)
+    if (quad && W >= 16 && H >= 5 && (long long)W * H * frames >= 2000000) {
+        dim3 grid((((W + 3) / 4) * H + 255) / 256, frames);
+        hipLaunchKernelGGL(census5x5_quad_kernel, grid, dim3(256), 0, st, img, cen, W, H);
+        return;
+    }
     dim3 grid((W * H + 255) / 256, frames);
     hipLaunchKernelGGL(census5x5_kernel, grid, dim3(256), 0, st, img, cen, W, H);
 }
