@@ -887,10 +887,11 @@ void launch_vz_convert(hipStream_t st, uint32_t* bestD, const double* off, int W
 // launchers
 // =============================================================================================
 void launch_census(hipStream_t st, const uint8_t* img, uint32_t* cen, int W, int H, int frames) {
-    static const bool quad = [] { const char* e = getenv("FSGM_CENSUS_QUAD"); return !(e && e[0] == '0'); }();   // A/B switch
+    const char* qe = getenv("FSGM_CENSUS_QUAD");                // A/B switch and test hook: 0 never, 1 whenever the shape allows, unset: by size
+    const bool quad = !(qe && qe[0] == '0'), force = qe && qe[0] == '1';
     // (a single 1242x375 frame is a latency-bound launch: 466 k threads of the one-pixel kernel finish before 116 k threads of
     // this one -- cost stage 0.060 against 0.064 ms; from a few frames on the instruction count decides: 0.0427 -> 0.0408 at 512)
-    if (quad && W >= 16 && H >= 5 && (long long)W * H * frames >= 2000000) {
+    if (quad && W >= 16 && H >= 5 && (force || (long long)W * H * frames >= 2000000)) {
         dim3 grid((((W + 3) / 4) * H + 255) / 256, frames);
         hipLaunchKernelGGL(census5x5_quad_kernel, grid, dim3(256), 0, st, img, cen, W, H);
         return;

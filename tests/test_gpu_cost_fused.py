@@ -154,3 +154,23 @@ def test_rows_with_horizontal_epipolar_lines_take_the_x_only_offsets(gpu_lib, or
     for fused in (True, False):
         got = _cost(W, H, D, [(I1, I2, pd0, nd, off)], fused=fused)[0]
         np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("W,H", [(16, 5), (61, 47), (64, 9), (130, 21), (23, 40)])
+def test_four_pixel_census_kernel(gpu_lib, oracle, W, H):
+    """census5x5_quad_kernel (taken by size in production: forced here) against the oracle and the one-pixel kernel: interior
+    threads read 12 bytes a row as three dwords at any alignment, border threads replicate (common.cpp:17-18)."""
+    import fsgm_amd
+    img = synth.uniform_u8(W * 7 + H, (H, W))
+    img[::3, ::5] = img[1, 1]                                # ties: nbr >= ctr
+    os.environ["FSGM_CENSUS_QUAD"] = "1"
+    try:
+        quad = fsgm_amd.census(img)
+    finally:
+        os.environ["FSGM_CENSUS_QUAD"] = "0"
+    try:
+        one = fsgm_amd.census(img)
+    finally:
+        del os.environ["FSGM_CENSUS_QUAD"]
+    np.testing.assert_array_equal(quad, oracle.census(img))
+    np.testing.assert_array_equal(quad, one)
