@@ -74,6 +74,10 @@ namespace fsgm {
                                 // 2.15 GHz in the first pass): the stage runs into the power limit, where instructions traded for
                                 // bytes buy nothing.  Off; kept as a knob (profiles/r04_band_y16.txt)
 #endif
+#ifndef FSGM_BAND_RECLDS
+#define FSGM_BAND_RECLDS 1      // second pass: the 10-byte WTA records of a wave's rows collect in LDS for eight steps and leave as 64-byte
+                                // runs (8-byte stores scattered over a wave's 8 rows were written to HBM 6.7 times over: profiles/r03_pmc_traffic.json)
+#endif
 #ifndef FSGM_BAND_SLACK
 #define FSGM_BAND_SLACK 32      // chained form: columns of lead a band gives the band above before it starts (A/B knob)
 #endif
@@ -120,6 +124,9 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
     __shared__ uint4 sR16[R16 ? 2 : 1][2][R16 ? (R + 1) * LPP : 1];   // [step parity][plane: registers 0-3 / 4-7][row slot][lane of pixel]
     __shared__ uint4 sSt[2][NSL][(R + 1) * LPP];              // [step parity][state][row slot (row + 1; slot 0 = the row above the band)][lane of pixel]
     __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 4];   // final pass: S of the wave's pixels (u16, two planes: epi_step.h)
+    constexpr bool RECLDS = MODE == 2 && FSGM_BAND_RECLDS != 0 && LPP == 8;   // (8 lanes a pixel: a wave's 64 lanes = 8 rows x 8 steps of records)
+    __shared__ uint2 sRec[RECLDS ? NWV * 64 : 1];              // [wave][row of the wave][step & 7]
+    __shared__ uint16_t sRs0[RECLDS ? NWV * 64 : 1];
     __shared__ uint32_t sTicket;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 #pragma unroll
             for (int i = 0; i < PFE; i++) ringE[i] = eload(edge_at(SKEW + i));
         }
+        if constexpr (RECLDS) sRec[wave * 64 + lane] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         __syncthreads();
 
         // one step of this wave's rows.  EDGE: a pixel of the wave is at / outside an image border or in row 0, or a row
@@ -393,12 +401,35 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
                 uint32_t ST[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) ST[i] = pk_mad16(CP[i], (uint32_t)PATHS * 0x10001u, 0u) - YS[i];    // the P1 biases of CP and YS cancel; no borrow between the halves
-                wta_row_record_at<LPP, NWV * 64, true>(ST, sRow, tid, j, inside, recb, s0b, (uint32_t)pix_of(xc, yc));
+                if constexpr (RECLDS)
+                    wta_row_record_at<LPP, NWV * 64, true, true>(ST, sRow, tid, j, inside, recb, s0b, 0u, &sRec[wave * 64 + g * 8 + (u & 7)], &sRs0[wave * 64 + g * 8 + (u & 7)]);
+                else
+                    wta_row_record_at<LPP, NWV * 64, true>(ST, sRow, tid, j, inside, recb, s0b, (uint32_t)pix_of(xc, yc));
                 if (TAP && inside) {                           // debug tap (an instantiation of its own): S in natural d order
                     uint32_t* o = a.Sdbg + (f * (size_t)NP + pix_of(xc, yc)) * D + j * 16;
 #pragma unroll
                     for (int i = 0; i < 8; i++) { o[i] = ST[i] & 0xFFFFu; o[i + 8] = ST[i] >> 16; }
                 }
+            }
+        };
+        // RECLDS: the records of steps u - 7 .. u of the wave's eight rows -> HBM, lane = (row, step): eight lanes of a row store
+        // eight consecutive pixels (64 + 16 contiguous bytes).  A slot that holds no record (pixel outside the image, step not run)
+        // carries the marker; every slot is reset behind its read
+        auto flush_records = [&](const int u) {
+            if constexpr (RECLDS) {
+                __builtin_amdgcn_wave_barrier();
+                const int fr = lane >> 3, fs = lane & 7;                              // row of the wave, slot
+                const uint2 rc = sRec[wave * 64 + lane];
+                const uint16_t s0v = sRs0[wave * 64 + lane];
+                sRec[wave * 64 + lane] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                const int uu = (u & ~7) + fs, rr = wave * PXG + fr;
+                const int xx = uu - SKEW * rr;
+                if (rc.x != 0xFFFFFFFFu) {                                            // (a real record's fields are all below 2^16)
+                    const uint32_t px = (uint32_t)pix_of(xx, yb + rr);
+                    *(uint2*)(recb + px * 8u) = rc;
+                    *(uint16_t*)(s0b + px * 2u) = s0v;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         };
         auto step = [&](const int u, const uint4 cw, const uint4 cy, const uint32_t cb, const uint4 cb4) {
@@ -414,6 +445,9 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
             if (wave_rows && u >= act_lo && u <= act_hi) {                            // wave-uniform
                 if (wave_plain_rows && u >= pl_lo && u <= pl_hi) do_step(u, cw, cy, cb, cb4, std::false_type{});
                 else do_step(u, cw, cy, cb, cb4, std::true_type{});
+            }
+            if constexpr (RECLDS) {
+                if ((u & 7) == 7) flush_records(u);                                   // workgroup-uniform
             }
 #ifndef FSGM_BAND_NOBAR                                                  /* timing experiment only: wrong results without it */
             __syncthreads();                                   // states of step u visible to step u+1
@@ -442,6 +476,9 @@ __global__ __launch_bounds__(NWV * 64, FSGM_BAND_MINW) void band_kernel(BandArgs
 #pragma unroll
         for (int i = 0; i < PF - 1; i++)
             if (u0 + i < nsteps) step(u0 + i, ringC[i], ringY[MODE == 2 ? i : 0], ringB[MODE == 2 && BITS && !Y16 ? i : 0], ringB4[MODE == 2 && Y16 ? i : 0]);   // workgroup-uniform
+        if constexpr (RECLDS) {
+            if ((nsteps & 7) != 0) flush_records(nsteps - 1);  // the last, partial group of steps
+        }
         if (!CHAIN) {                                          // the band below reads what the last row stored: stores done before anyone goes on
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

@@ -207,9 +207,13 @@ __device__ __forceinline__ uint32_t srow_index(int tid0, uint32_t d) {
 
 // recb / s0b: byte pointers to the frame's records / S[0] words (wave-uniform), pix: the pixel's index in the frame -- 32-bit
 // offsets from uniform bases keep the stores' addresses out of 64-bit vector registers
-template <int LPP, int NT, bool WTA_MIN3 = false>
+// STAGE: the record is not stored to HBM here but parked in LDS (stg_rec / stg_s0: this pixel's slot, written by the pixel's
+// first lane; an invalid pixel leaves the marker 0xFFFFFFFF) -- the band sweeps' second pass collects eight steps of a row and
+// stores them as one 64-byte run (epi_band.hip)
+template <int LPP, int NT, bool WTA_MIN3 = false, bool STAGE = false>
 __device__ __forceinline__ void wta_row_record_at(const uint32_t (&ST)[8], uint32_t* sRow, int tid, int j,
-                                                  bool ok, uint8_t* recb, uint8_t* s0b, uint32_t pix) {
+                                                  bool ok, uint8_t* recb, uint8_t* s0b, uint32_t pix,
+                                                  uint2* stg_rec = nullptr, uint16_t* stg_s0 = nullptr) {
     constexpr int D = LPP * 16;
     srow_store<NT>(sRow, tid, ST);
     uint32_t K[8];                                             // keys S*16 + index in the lane: < 2^15, so the fp16 3-input minimum orders them as integers
@@ -226,8 +230,13 @@ __device__ __forceinline__ void wta_row_record_at(const uint32_t (&ST)[8], uint3
         const uint16_t* srow = (const uint16_t*)sRow;
         const uint32_t c_1 = best > 0 ? srow[srow_index<NT>(tid, best - 1)] : 0u;
         const uint32_t c1 = best + 1 < (uint32_t)D ? srow[srow_index<NT>(tid, best + 1)] : 0u;   // best == D-1: the finish kernel takes the next pixel's S[0]
-        *(uint2*)(recb + pix * 8u) = make_uint2(best | (minc << 16), c_1 | (c1 << 16));   // (every field below 2^16: sums of <= 16 u8 path costs)
-        *(uint16_t*)(s0b + pix * 2u) = (uint16_t)ST[0];        // S[0]: register 0, low half of the pixel's first lane (this one)
+        if (STAGE) {
+            *stg_rec = make_uint2(best | (minc << 16), c_1 | (c1 << 16));
+            *stg_s0 = (uint16_t)ST[0];
+        } else {
+            *(uint2*)(recb + pix * 8u) = make_uint2(best | (minc << 16), c_1 | (c1 << 16));   // (every field below 2^16: sums of <= 16 u8 path costs)
+            *(uint16_t*)(s0b + pix * 2u) = (uint16_t)ST[0];        // S[0]: register 0, low half of the pixel's first lane (this one)
+        }
     }
 }
 
