@@ -488,6 +488,11 @@ def main():
     agg_ms = plan.time(STAGE_AGGREGATE, warmup=1, iters=max(3, args.steps // 2))
     wta_ms = plan.time(STAGE_WTA, warmup=1, iters=max(3, args.steps // 2))
 
+    try:
+        free_b, total_b = torch.cuda.mem_get_info(local_rank)         # device-wide: the timed plan, its pipeline's volumes and the 16-frame check plan's leftovers
+        hbm_used_gb = (total_b - free_b) / 1e9
+    except Exception:
+        hbm_used_gb = None
     if rank == 0:
         total_frames = args.total_frames if strong else world * B
         voxel_paths_step = total_frames * W * H * D * PATHS
@@ -513,7 +518,7 @@ def main():
             "config": {"workload": f"KITTI 1242x375 D=128, {PATHS} paths, aggregation stage (C resident in HBM -> bestD/minC)",
                        "frames_per_gpu": B, "total_frames": total_frames, "P1": P1, "P2": P2, "kernel": plan.kernel_name,
                        "step": f"aggregate({PATHS} paths) + sum/WTA/subpixel", "sharding": "frames, no collective",
-                       "pci_bus_ids": bus_ids, "distinct_devices": len(set(bus_ids))},
+                       "pci_bus_ids": bus_ids, "distinct_devices": len(set(bus_ids)), "hbm_in_use_GB_after_timed_loop": hbm_used_gb},
             "argv": " ".join(sys.argv[1:]),
             # band sweeps: the stage is two kernels back to back on the plan's stream (first pass, second pass + WTA),
             # each 4 voxel-paths per voxel: HIP events around the pair = the sum of their durations (rocprofv3 kernel
