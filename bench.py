@@ -33,7 +33,7 @@ def measured_traffic(kernel_name, paths):
         try:
             t = json.load(open(f))
             if t.get("pipeline") == kernel_name and t.get("paths") == paths:
-                return float(t["bytes_per_voxel"]), {"file": os.path.relpath(f, ROOT), "measured": t.get("date"), "lib_sha16": t.get("lib_sha16")}
+                return float(t["bytes_per_voxel"]), {"file": os.path.relpath(f, ROOT), "measured": t.get("date"), "head": t.get("head"), "lib_sha16": t.get("lib_sha16")}
         except Exception:
             pass
     return None, None
