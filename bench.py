@@ -557,7 +557,7 @@ def main():
             # with a random component per pixel (every lane of the census gather in its own cache line: the
             # worst case for the cost fill); this overwrites the synthetic volumes, so it runs last
             I1, I2 = synth.image_pair(W, H, D, seed=3)
-            for key, kind in (("whole_mex", "axis"), ("whole_mex_random_directions", "general")):
+            for key, kind in (("whole_mex", "axis"), ("whole_mex_radial_directions", "radial"), ("whole_mex_random_directions", "general")):
                 pd0, nd, offg = synth.epi_maps(W, H, kind)
                 for f in range(B):
                     plan.upload(f, I1, I2, pd0, nd, offg)
@@ -565,7 +565,8 @@ def main():
                 cost_ms = plan.time(STAGE_COST, warmup=1, iters=3)
                 out[key] = {"ms_per_frame": all_ms / B, "frames_per_s": B / (all_ms * 1e-3), "cost_stage_ms_per_frame": cost_ms / B,
                             "stages": f"census x2, cost fill, box, aggregate({PATHS} paths), WTA", "inputs": "resident in HBM",
-                            "maps": "SURVEY 8(d) timing maps" if kind == "axis" else "random direction per pixel"}
+                            "maps": {"axis": "SURVEY 8(d) timing maps (horizontal epipolar lines)", "radial": "directions away from an epipole inside the image "
+                                     "(a forward-moving camera: the field epipolar_geometry.m produces)", "general": "random direction per pixel"}[kind]}
         if world == 1 and not args.no_extras:
             # the boundary as a MATLAB caller feels it: host pointers in, host pointers out (pageable memory, PCIe
             # included; never `value`), one frame per call like epipolar_sgm_of.m:45, and 8 frames per call

@@ -51,6 +51,7 @@ def epi_maps(W, H, kind="axis", seed=7):
     'axis'   : the survey's timing inputs -- Pd0=(x+1,y+1), direction (-1,0), offset 200.
     'general': fractional start positions, a rotating unit-direction field and a varying offset,
                so that both coordinates, round-half cases and clamping are exercised.
+    'radial' : a forward-moving camera's field -- directions away from an epipole inside the image, offset = distance to it.
     """
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
     pd0 = np.stack([xx + 1.0, yy + 1.0])
@@ -65,6 +66,15 @@ def epi_maps(W, H, kind="axis", seed=7):
         ang = 0.9 * np.sin(xx / 53.0) + 1.3 * np.cos(yy / 37.0) + 2.0 * uniform_f64(seed + 1, (H, W))
         nd = np.stack([np.cos(ang), np.sin(ang)])
         off = 40.0 + 400.0 * uniform_f64(seed + 2, (H, W))
+    elif kind == "radial":
+        # what epipolar_geometry.m:99-115 produces for a forward-moving camera: start positions = pixel + a small smooth
+        # rotation flow, unit directions pointing away from the epipole, offset = distance to it (both coordinates walk, the
+        # field is smooth: neighbouring pixels sample neighbouring positions)
+        ex, ey = 0.47 * W + 3.3, 0.55 * H - 1.7
+        pd0 = pd0 + np.stack([0.8 * np.sin(yy / 91.0) + 0.002 * (xx - W / 2), 0.6 * np.cos(xx / 123.0) - 0.001 * (yy - H / 2)])
+        dxy = np.stack([pd0[0] - ex, pd0[1] - ey])
+        off = np.sqrt((dxy ** 2).sum(0))
+        nd = dxy / np.maximum(off, 1e-9)
     else:
         raise ValueError(kind)
     return np.ascontiguousarray(pd0), np.ascontiguousarray(nd), np.ascontiguousarray(off)

@@ -22,7 +22,7 @@ def _last_pixel_mask(H, W):
 @pytest.mark.parametrize("W,H,D,kind", [
     (64, 48, 16, "general"), (67, 45, 32, "general"), (40, 30, 64, "axis"),
     (33, 21, 128, "general"), (31, 17, 20, "general"), (29, 19, 7, "general"),
-    (35, 27, 136, "general"), (23, 9, 8, "general"), (50, 21, 264, "axis"), (128, 3, 24, "general"),   # pixel-per-thread kernel: D segments, ragged last wave
+    (35, 27, 136, "general"), (23, 9, 8, "general"), (50, 21, 264, "axis"), (128, 3, 24, "general"), (97, 55, 64, "radial"),   # pixel-per-thread kernel: D segments, ragged last wave
 ])
 def test_cost_volume_bit_exact(gpu_lib, oracle, W, H, D, kind):
     I1, I2 = synth.image_pair(W, H, D, seed=W + D)
