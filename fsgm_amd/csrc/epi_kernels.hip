@@ -10,8 +10,10 @@
 // No MFMA anywhere: this is integer stencil / scan work bound by HBM and VALU issue.
 #include "epi_kernels.h"
 #include <algorithm>
+#include <type_traits>
 #include "fsgm_device.h"
 #include "epi_wta_tail.h"
+#include "epi_step.h"
 
 namespace fsgm {
 
@@ -719,6 +721,149 @@ __device__ __forceinline__ void agg_x_lean_body(const AggArgs& a, const int slot
         if (u0 + i < n) st(u0 + i + 1, block(ring[i], P2pk));
 }
 
+// =============================================================================================
+// The other three directions (along y and the two diagonals), no wrap, 16 costs a lane: the general body with what a
+// step does not need taken out -- these lines are most of a single call's instructions (6 of 8 slots), and with a few
+// waves a SIMD an instruction costs 5-8 cycles whatever it does:
+//  * min(L[d], L[d-1] + P1, L[d+1] + P1) as one v_pk_minimum3_f16 a register (exact on these denormal patterns: self-tested
+//    at plan creation) on L + P1 aligned once, instead of align / min / add / min;
+//  * the minimum over d leaves the reduction replicated in both halves (v_pk_min with op_sel folds them): no extract, no
+//    re-broadcast;
+//  * byte offsets advance by a constant (along y) or by one of two constants chosen by a down-counter (diagonals), the loads
+//    stop at the line's end instead of being clamped, and a path start is the wrap of the previous advance.
+// Same results as agg_packed_body<D, 16, false, BASE> (tests/test_gpu_epi.py runs both).
+// =============================================================================================
+#ifndef FSGM_AGG_LEAN
+#define FSGM_AGG_LEAN 1
+#endif
+__device__ __forceinline__ uint32_t pk_min_fold(uint32_t x) {       // min(x.lo, x.hi) in both halves
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(x));
+    return r;
+}
+template <int D, int BASE>
+__device__ __forceinline__ void agg_lean_body(const AggArgs& a, const int slot, const bool mirror) {
+    constexpr int LPP = D / 16, PXW = 64 / LPP, PF = 4;
+    constexpr uint32_t SENT = 0x03FF03FFu, MASK = 0x00FF00FFu;   // "no neighbour": above every L + P1, a denormal pattern
+    static_assert(BASE >= 1 && BASE <= 3 && LPP >= 2 && LPP <= 16, "lean body: along y / diagonals, D = 32..256");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / LPP, j = lane % LPP;
+    const int W = a.W, H = a.H, NP = W * H, len = H;
+    const int lg = ((int)blockIdx.x - a.blk_begin[slot]) * 4 + wave;
+    if (lg * PXW >= W) return;                               // wave-uniform
+    const int l = min(lg * PXW + g, W - 1);                  // lanes past the last line redo it (same loads, same stores)
+
+    const uint8_t* __restrict__ Cf = a.C + (size_t)blockIdx.y * a.c_frame_stride;
+    uint8_t* __restrict__ Lf = a.L + (size_t)blockIdx.y * a.l_frame_stride + (size_t)slot * a.l_dir_stride;
+    // byte offset of this lane's 16 costs at the pass-0 pixel `pix`; the mirrored pass addresses NP-1-pix
+    const int sgn = mirror ? -1 : 1;
+    const uint32_t dN = (uint32_t)(sgn * (W + (BASE == 2 ? 1 : BASE == 3 ? -1 : 0)) * D);    // a step inside the frame
+    const uint32_t dW = (uint32_t)(sgn * (BASE == 2 ? 1 : 2 * W - 1) * D);                   // the step that wraps in x
+    uint32_t oc = (uint32_t)(mirror ? NP - 1 - l : l) * D + (uint32_t)j * 16, ol = oc;        // compute / load cursors
+    int cc = BASE == 2 ? W - l : l + 1, cl = cc;                                             // advances until the wrap
+    // advance a cursor; true where it wrapped (the pixel reached starts a new path, calc_cost_sgm.cpp:154-177)
+    auto adv = [&](uint32_t& o, int& c) -> bool {
+        if (BASE == 1) { o += dN; return false; }
+        c -= 1;
+        const bool wr = c == 0;
+        c = wr ? W : c;
+        o += wr ? dW : dN;
+        return wr;
+    };
+    auto load_c = [&](uint32_t o) -> uint4 { return *(const uint4*)(Cf + o); };
+    auto store_l = [&](uint32_t o, const uint4& v) {
+        if (FSGM_LINE_NT) store_nt(Lf + o, v); else *(uint4*)(Lf + o) = v;
+    };
+
+    const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
+    const uint32_t mL = j == 0 ? SENT : 0u, mR = j == LPP - 1 ? SENT : 0u;
+    uint32_t LE[4], LO[4], m = 0, pr = SENT, nr = SENT;
+#pragma unroll
+    for (int k = 0; k < 4; k++) LE[k] = LO[k] = 0;
+
+    // one step; FIRST: the line's first pixel (every lane starts a path); start: lanes whose previous advance wrapped
+    auto step = [&](const uint4 raw, auto first, const bool start) -> uint4 {
+        constexpr bool FIRST = decltype(first)::value;
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+        uint32_t CE[4], CO[4], NE[4], NO[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { CE[k] = w[k] & MASK; CO[k] = __builtin_amdgcn_perm(0u, w[k], 0x0C030C01u); }
+        if (FIRST) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { NE[k] = CE[k]; NO[k] = CO[k]; }
+            m = 0;
+        } else {
+            uint32_t EP[4], OP[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { EP[k] = pk_add(LE[k], P1pk); OP[k] = pk_add(LO[k], P1pk); }
+            // the neighbouring lanes' d-1 / d+1 (the first lane of a row of 16 keeps SENT: a row shift never writes it)
+            asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(pr) : "v"(OP[3]));
+            asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(nr) : "v"(EP[0]));
+            const uint32_t prevOP = LPP == 16 ? pr : (pr | mL), nextEP = LPP == 16 ? nr : (nr | mR);
+            const uint32_t p2lane = (BASE != 1 && start) ? 0u : P2pk;       // min(., 0) = 0: L = C at a path start
+            uint32_t mk[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t tE = pk_min3(LE[k], align16(OP[k], k ? OP[k - 1] : prevOP), OP[k]);
+                const uint32_t tO = pk_min3(LO[k], EP[k], align16(k < 3 ? EP[k + 1] : nextEP, EP[k]));
+                NE[k] = pk_add(CE[k], pk_min(pk_sub(tE, m), p2lane));      // C + min(t - m, P2): t >= m without wrap
+                NO[k] = pk_add(CO[k], pk_min(pk_sub(tO, m), p2lane));
+                mk[k] = pk_min(NE[k], NO[k]);
+            }
+            const uint32_t mx = group_min_u32<LPP>(pk_min_fold(pk_min(pk_min(mk[0], mk[1]), pk_min(mk[2], mk[3]))));
+            m = (BASE != 1 && start) ? 0u : mx;                            // stored minimum 0 at a path start
+        }
+        uint4 o;
+        uint32_t ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            LE[k] = NE[k]; LO[k] = NO[k];
+            ow[k] = __builtin_amdgcn_perm(NO[k], NE[k], 0x06020400u);       // bytes E.lo, O.lo, E.hi, O.hi
+        }
+        o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
+        return o;
+    };
+
+    // first pixel, then steps u = t - 1 = 0..n-1 with the ring PF steps ahead
+    store_l(oc, step(load_c(ol), std::true_type{}, true));
+    bool wrapped = adv(oc, cc);
+    adv(ol, cl);
+    const int n = len - 1;
+    uint4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        if (i < n) { ring[i] = load_c(ol); adv(ol, cl); } else ring[i] = make_uint4(0, 0, 0, 0);
+    }
+    int u0 = 0;
+    for (; u0 + 2 * PF <= n; u0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const uint4 cw = ring[i];
+            ring[i] = load_c(ol);
+            adv(ol, cl);
+            store_l(oc, step(cw, std::false_type{}, wrapped));
+            wrapped = adv(oc, cc);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        if (u0 + i < n) {
+            const uint4 cw = ring[i];
+            if (u0 + i + PF < n) { ring[i] = load_c(ol); adv(ol, cl); }
+            store_l(oc, step(cw, std::false_type{}, wrapped));
+            wrapped = adv(oc, cc);
+        }
+    }
+    u0 += PF;
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        if (u0 + i < n) {
+            store_l(oc, step(ring[i], std::false_type{}, wrapped));
+            wrapped = adv(oc, cc);
+        }
+    }
+}
+
 // The along-x lines are the long serial chains (W steps against H for every other direction) and there are
 // few of them (2 H lines a frame): split finer over the lanes, 4 costs a lane (8 at D = 256), they take a
 // third of the instructions per step; every other direction keeps 16 costs a lane.
@@ -749,9 +894,13 @@ __global__ __launch_bounds__(256) void agg_packed_kernel(AggArgs a) {
                 if (mirror) agg_x_lean_body<true>(a, slot); else agg_x_lean_body<false>(a, slot);
             } else agg_packed_body<D, DX, WRAP, 0>(a, slot, mirror);
             break;
-        case 1: agg_packed_body<D, DO, WRAP, 1>(a, slot, mirror); break;
-        case 2: agg_packed_body<D, DO, WRAP, 2>(a, slot, mirror); break;
-        default: agg_packed_body<D, DO, WRAP, 3>(a, slot, mirror); break;
+#define FSGM_AGG_OTHER(BASE) \
+            if constexpr (!WRAP && DO == 16 && D >= 32 && D <= 256 && FSGM_AGG_LEAN) agg_lean_body<D, BASE>(a, slot, mirror); \
+            else agg_packed_body<D, DO, WRAP, BASE>(a, slot, mirror);
+        case 1: FSGM_AGG_OTHER(1) break;
+        case 2: FSGM_AGG_OTHER(2) break;
+        default: FSGM_AGG_OTHER(3) break;
+#undef FSGM_AGG_OTHER
     }
 }
 
