@@ -354,9 +354,9 @@ def main():
     ap.add_argument("--total-frames", type=int, default=0,
                     help="strong scaling: a fixed batch of this many frames split over the ranks by fsgm_amd.batch.shard_indices "
                          "(BASELINE config 5 literally = 8); default 0 = weak scaling with --frames-per-gpu frames on every GPU")
-    ap.add_argument("--agg-mode", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+    ap.add_argument("--agg-mode", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
                     help="force an aggregation pipeline (fsgm_epi_plan_set_agg_mode): 0 auto (default), 1 line kernels, 2 fused sweeps / pairs, "
-                         "3 parallel sweeps, 4 band sweeps, 5 chained band sweeps")
+                         "3 parallel sweeps, 4 band sweeps, 5 chained band sweeps, 6 parallel sweeps meeting in the middle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed loop, the self-check and the roofline block (no whole-MEX / host-call legs): for profiler runs")

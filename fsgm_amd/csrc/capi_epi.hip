@@ -43,6 +43,7 @@ struct fsgm_epi_plan {
     // parallel sweeps (sweep_par): Y_up of every frame and the up sweep's own block-boundary states
     uint8_t *dXupAll = nullptr, *dStateUp = nullptr;
     bool sweep_par = false;              // AGG_SWEEP only: down and up sweeps side by side, WTA over the three Y volumes
+    bool sweep_mid = false;              // sweep_par only: the two sweeps meet in the middle, each finishing the other's half with the WTA inside
     // band sweeps (epi_band.hip): the first pass's 9th bits, the hand-off between the bands of a frame; dX, dRec, dS0 as above
     uint32_t* dBits = nullptr;
     uint4* dBandEdge = nullptr;
@@ -64,7 +65,7 @@ struct fsgm_epi_plan {
     int lanes = 2;                       // frame lanes of the sweeps (FSGM_EPI_LANES, 1..3)
     std::vector<int> cmax;               // per frame: upper bound of the cost values in dC
     bool vz_valid = false;
-    int agg_mode = 0;                    // 0 auto, 1 per-direction line kernels, 2 fused sweeps (if eligible), 3 parallel sweeps, 4 band sweeps
+    int agg_mode = 0;                    // 0 auto, 1 per-direction line kernels, 2 fused sweeps (if eligible), 3 parallel sweeps, 4 / 5 band sweeps, 6 sweeps meeting in the middle
     int cus = 256;                       // compute units of the device (band sweeps: one workgroup per frame, two per CU)
     int kernel_kind = AGG_GENERIC;
     bool packed = false;
@@ -89,7 +90,10 @@ static int switch_batch(const char* env_name, int W, int H, int D, int at_kitti)
     return e >= 0 ? e : scaled_batch(W, H, D, at_kitti);
 }
 static int par_min_batch(int W, int H, int D) { return switch_batch("FSGM_EPI_PAR_MIN", W, H, D, 4); }
-static int par_max_batch(int W, int H, int D) { return switch_batch("FSGM_EPI_PAR_MAX", W, H, D, 18); }
+static int par_max_batch(int W, int H, int D) { return switch_batch("FSGM_EPI_PAR_MAX", W, H, D, 26); }
+// from this batch on the parallel sweeps meet in the middle (mode 6; profiles/r04_sweep_mid.txt: 10 frames 1.38 vs 1.44 ms, 18 frames
+// 2.06 vs 2.41 -- and 2.61 for the full pipeline --, 28 frames 3.49 vs 3.35 for the full pipeline); FSGM_EPI_MID_MIN=0: never
+static int mid_min_batch(int W, int H, int D) { return switch_batch("FSGM_EPI_MID_MIN", W, H, D, 10); }
 // Band sweeps (all four paths of a pass in one sweep, one workgroup per frame, two workgroups per CU) in auto mode: a launch
 // takes as long as its slowest CU -- measured at 1242x375x128, 8 paths, 256 CUs: 25.2 ms with one workgroup per CU (up to
 // 256 frames), 42.8 ms with two (up to 512) -- while the block sweeps take 0.107 ms per frame whatever the count.  In units of
@@ -126,9 +130,9 @@ static int pairs_min_batch(int W, int H, int D) { return switch_batch("FSGM_EPI_
 
 // What runs for a plan of this shape, batch and parameter set (cm: the largest cost in the volumes): a function of its
 // arguments and the FSGM_EPI_* environment only, so that fsgm_epi_auto_pipeline can answer without a plan.
-struct PipelineChoice { int kind; bool sweep_par, band_chain; };
+struct PipelineChoice { int kind; bool sweep_par, band_chain, sweep_mid; };
 static PipelineChoice choose_pipeline(int W, int H, int D, int batch, int paths, int P1, int P2, int cm, int agg_mode, int cus) {
-    PipelineChoice c = {AGG_GENERIC, false, false};
+    PipelineChoice c = {AGG_GENERIC, false, false, false};
     if (agg_packed_lpp(D) == 0) return c;
     const bool nowrap = P1 >= 0 && P2 >= 0 && cm + P2 + std::max(P1, P2) <= 255;
     c.kind = nowrap ? AGG_PACKED_NOWRAP : AGG_PACKED_WRAP;
@@ -138,7 +142,7 @@ static PipelineChoice choose_pipeline(int W, int H, int D, int batch, int paths,
     // while the line kernels scale with it.  Measured at 1242x375x128 (ms per batch, line vs fused):
     // 8 paths 8 frames 1.96 / 2.20, 12 frames 2.89 / 2.29; 4 paths 8 frames 1.18 / 1.19, 12 frames 1.67 / 1.28.
     const int min_batch = paths == 8 ? par_min_batch(W, H, D) : pairs_min_batch(W, H, D);
-    const bool want = agg_mode == 2 || agg_mode == 3 || (agg_mode == 0 && batch >= min_batch);
+    const bool want = agg_mode == 2 || agg_mode == 3 || agg_mode == 6 || (agg_mode == 0 && batch >= min_batch);
     // (P1 <= P2: the fused kernels' form of the step clamps path states at P2 first, epi_sweep.hip)
     const bool fusable = nowrap && P1 <= P2;
     // (the Y volumes hold y + P1 per path since round 3 -- step_b, epi_step.h -- so three / two of them must fit a byte with the bias)
@@ -147,7 +151,13 @@ static PipelineChoice choose_pipeline(int W, int H, int D, int batch, int paths,
         // Between the line kernels and the full pipeline: the down and the up sweep side by side (H rows in sequence
         // instead of 2 H) with Y_up written out and a WTA kernel over C, Y_dn, Y_up, Y_h: 3 B per voxel more traffic,
         // half the latency.  Mode 3 forces it; auto takes it while the batch is too small to hide the longer chain.
-        c.sweep_par = agg_mode == 3 || (agg_mode == 0 && batch < par_max_batch(W, H, D));
+        c.sweep_par = agg_mode == 3 || agg_mode == 6 || (agg_mode == 0 && batch < par_max_batch(W, H, D));
+        // Mode 6, and auto for the larger of the batches that take the parallel sweeps: the two sweeps meet in the middle.  Each
+        // writes its Y for its first half of the rows only and crosses the other's half as a final sweep (the other's Y, Y_h,
+        // WTA in registers): the traffic of the full pipeline (8.5 B per voxel, no WTA kernel over four volumes) on the
+        // parallel sweeps' chain of H rows.
+        const int mid_min = mid_min_batch(W, H, D);
+        c.sweep_mid = agg_mode == 6 || (agg_mode == 0 && c.sweep_par && mid_min > 0 && batch >= mid_min);
     }
     // the shipped 4-path configuration: both axes as pair kernels, the vertical one final
     if (fusable && 2 * (P1 + P2) <= 255 && paths == 4 && want) c.kind = AGG_PAIRS;
@@ -156,17 +166,18 @@ static PipelineChoice choose_pipeline(int W, int H, int D, int batch, int paths,
     if (fusable && band_ok(D, paths, P1, P2, cm) && (agg_mode == 4 || agg_mode == 5 || band != 0)) {
         c.kind = AGG_BAND;
         c.sweep_par = false;
+        c.sweep_mid = false;
         // mode 5 / auto between the sequential form's rounds: the bands of a frame as workgroups of their own (chained)
         c.band_chain = agg_mode == 5 || band == 2;
     }
     return c;
 }
 
-static const char* pipeline_name(int kind, bool sweep_par, bool band_chain) {
+static const char* pipeline_name(int kind, bool sweep_par, bool band_chain, bool sweep_mid = false) {
     switch (kind) {
         case AGG_PACKED_NOWRAP: return "packed16/nowrap";
         case AGG_PACKED_WRAP: return "packed16/wrap";
-        case AGG_SWEEP: return sweep_par ? "sweep16par/nowrap" : "sweep16/nowrap";
+        case AGG_SWEEP: return sweep_mid ? "sweep16mid/nowrap" : sweep_par ? "sweep16par/nowrap" : "sweep16/nowrap";
         case AGG_PAIRS: return "pairs16/nowrap";
         case AGG_BAND: return band_chain ? "band16chain/nowrap" : "band16/nowrap";
         default: return "generic";
@@ -179,6 +190,7 @@ static void select_kernel(fsgm_epi_plan* p) {
     const PipelineChoice c = choose_pipeline(p->W, p->H, p->D, p->batch, p->prm.paths, p->P1, p->P2, cm, p->agg_mode, p->cus);
     p->kernel_kind = c.kind;
     p->sweep_par = c.sweep_par;
+    p->sweep_mid = c.sweep_mid;
     p->band_chain = c.band_chain;
 }
 
@@ -473,6 +485,13 @@ static int par_tall(const fsgm_epi_plan* p) {
     return p->batch <= 10 ? 1 : 0;
 }
 
+// the final halves of the sweeps that meet in the middle as 8-wave workgroups too (FSGM_EPI_MID_TALL: A/B switch)
+static int mid_tall(const fsgm_epi_plan* p) {
+    static const int env = env_int("FSGM_EPI_MID_TALL", -1);
+    if (env >= 0) return env != 0;
+    return par_tall(p);
+}
+
 // (the pipelines share some buffers -- records, S[0] words, Y volumes, the pair's stream -- and a plan may be switched from
 // one to another: each set creates only what is still missing)
 static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
@@ -591,6 +610,14 @@ static fsgm_status prepare(fsgm_epi_plan* p, int stages) {
     return FSGM_OK;
 }
 
+// Where the sweeps that meet in the middle meet: the row count of the down sweep's first half, a whole number of its launches
+// (the up sweep's first half, H - hm rows, ends with a short launch).
+static int sweep_mid_row(int H, int D) {
+    const int t = 2 * sweep_rows_per_launch(D);                  // rows per launch of the 8-wave form
+    const int hm = ((H + 1) / 2 + t - 1) / t * t;
+    return std::min(hm, H);
+}
+
 // census x2 + cost fill + box of frames [f0, f0 + nf) on the plan's stream (ensure_vz done by the caller)
 static void enqueue_cost(fsgm_epi_plan* p, int f0, int nf) {
     const size_t NP = p->NP, o = (size_t)f0;
@@ -626,19 +653,44 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         if (par_pair_fine(p)) launch_pair_x_fine(p->stream_h, h, p->batch);
         else                  launch_pair(p->stream_h, h, p->batch, 0, false);
         FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
-        SweepArgs w;
+        SweepArgs w{};
         w.C = p->dC; w.c_frame_stride = p->N;
         w.X = p->dX; w.x_frame_stride = p->N;
         w.Lh = nullptr; w.lh_frame_stride = 0; w.rec = nullptr; w.s0 = nullptr;
         w.state_in = w.state_out = p->dState; w.state_frame_stride = p->state_stride;
         w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
         const int tall = par_tall(p);                                 // 8-wave workgroups: half the launches of a sweep
-        launch_sweep(p->stream, w, p->batch, 0, tall);                // pass-0 paths from above -> Y_dn
-        w.X = p->dXupAll; w.state_in = w.state_out = p->dStateUp;
-        launch_sweep(p->stream_b, w, p->batch, 1, tall);              // pass-1 paths -> Y_up
-        FSGM_HIP(hipEventRecord(p->ev_b, p->stream_b));
-        FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_h, 0));
-        FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_b, 0));
+        if (p->sweep_mid) {
+            // the sweeps meet in the middle: rows [0, hm) of the frame belong to the down sweep's first half, rows [hm, H) to the
+            // up sweep's (its rows [0, H - hm) of the mirrored frame); then each crosses the other's half as a final sweep
+            const int hm = sweep_mid_row(p->H, p->D);
+            int par_dn = 0, par_up = 0;
+            SweepArgs up = w;
+            up.state_in = up.state_out = p->dStateUp;
+            w.X = p->dX; up.X = p->dXupAll;
+            launch_sweep_rows(p->stream, w, p->batch, 0, tall, 0, hm, &par_dn);                  // -> Y_dn of rows [0, hm)
+            FSGM_HIP(hipEventRecord(p->ev_c, p->stream));
+            launch_sweep_rows(p->stream_b, up, p->batch, 1, tall, 0, p->H - hm, &par_up);          // -> Y_up of rows [hm, H)
+            FSGM_HIP(hipEventRecord(p->ev_b, p->stream_b));
+            w.Lh = up.Lh = p->dLh; w.lh_frame_stride = up.lh_frame_stride = p->N; w.lh_natural = up.lh_natural = par_pair_fine(p);
+            w.rec = up.rec = p->dRec; w.s0 = up.s0 = p->dS0;
+            w.X = p->dXupAll; up.X = p->dX;                                                      // what a final sweep reads: the other's Y
+            FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_h, 0));
+            FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_b, 0));
+            launch_sweep_rows(p->stream, w, p->batch, 3, mid_tall(p), hm, p->H, &par_dn);                  // rows [hm, H): + Y_up + Y_h, WTA
+            FSGM_HIP(hipStreamWaitEvent(p->stream_b, p->ev_h, 0));
+            FSGM_HIP(hipStreamWaitEvent(p->stream_b, p->ev_c, 0));
+            launch_sweep_rows(p->stream_b, up, p->batch, 2, mid_tall(p), p->H - hm, p->H, &par_up);          // rows [0, hm): + Y_dn + Y_h, WTA
+            FSGM_HIP(hipEventRecord(p->ev_hl[0], p->stream_b));
+            FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_hl[0], 0));
+        } else {
+            launch_sweep(p->stream, w, p->batch, 0, tall);                // pass-0 paths from above -> Y_dn
+            w.X = p->dXupAll; w.state_in = w.state_out = p->dStateUp;
+            launch_sweep(p->stream_b, w, p->batch, 1, tall);              // pass-1 paths -> Y_up
+            FSGM_HIP(hipEventRecord(p->ev_b, p->stream_b));
+            FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_h, 0));
+            FSGM_HIP(hipStreamWaitEvent(p->stream, p->ev_b, 0));
+        }
     } else if ((stages & FSGM_STAGE_AGGREGATE) && p->kernel_kind == AGG_SWEEP) {
         // One sweep launch (strips x frames workgroups) cannot fill 256 CUs, so the work is forked:
         // the horizontal pair runs on stream_h, and the frames split into two lanes, each sweeping
@@ -665,7 +717,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         for (int lane = 0, f0 = 0; lane < NLN; lane++) {
             const int nf = p->batch / NLN + (lane < p->batch % NLN ? 1 : 0);
             hipStream_t st = lane_stream[lane];
-            SweepArgs w;
+            SweepArgs w{};
             w.C = p->dC + (size_t)f0 * p->N; w.c_frame_stride = p->N;
             w.X = p->dX + (size_t)f0 * p->N; w.x_frame_stride = p->N;
             w.Lh = p->dLh + (size_t)f0 * p->N; w.lh_frame_stride = p->N;
@@ -737,7 +789,7 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         a.W = p->W; a.H = p->H; a.D = p->D; a.P1 = p->P1; a.P2 = p->P2;
         launch_aggregate(p->stream, a, p->prm.paths, p->batch, p->kernel_kind);
     }
-    if ((stages & FSGM_STAGE_WTA) && p->kernel_kind == AGG_SWEEP && p->sweep_par) {
+    if ((stages & FSGM_STAGE_WTA) && p->kernel_kind == AGG_SWEEP && p->sweep_par && !p->sweep_mid) {
         WtaArgs a;                                   // S = 8 (C + P2) - (Y_dn + Y_up + Y_h), argmin, parabola, vz -> disp
         a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
         a.off = p->dOff; a.bestD = p->dBestD; a.minC = p->dMinC; a.vMax = p->vMax;
@@ -790,7 +842,7 @@ fsgm_status fsgm_epi_plan_run(fsgm_epi_plan* p, int32_t stages) {
 
 fsgm_status fsgm_epi_plan_set_agg_mode(fsgm_epi_plan* p, int32_t mode) {
     FSGM_REQUIRE(p, "null plan");
-    FSGM_REQUIRE(mode >= 0 && mode <= 5, "agg mode must be 0 (auto), 1 (per-direction kernels), 2 (fused sweeps), 3 (parallel sweeps), 4 (band sweeps) or 5 (chained band sweeps)");
+    FSGM_REQUIRE(mode >= 0 && mode <= 6, "agg mode must be 0 (auto), 1 (per-direction kernels), 2 (fused sweeps), 3 (parallel sweeps), 4 (band sweeps), 5 (chained band sweeps) or 6 (sweeps meeting in the middle)");
     p->agg_mode = mode;
     select_kernel(p);
     return FSGM_OK;
@@ -873,7 +925,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         if (es != FSGM_OK) return es;
         if (!p->dS) FSGM_HIP(hipMalloc((void**)&p->dS, p->N * 4));
         if (!p->dXup) FSGM_HIP(hipMalloc((void**)&p->dXup, p->N));
-        SweepArgs w;
+        SweepArgs w{};
         w.C = p->dC + (size_t)f * p->N; w.c_frame_stride = p->N;
         w.X = p->dXup; w.x_frame_stride = p->N;
         w.Lh = nullptr; w.lh_frame_stride = 0; w.rec = nullptr; w.s0 = nullptr;
@@ -881,6 +933,10 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         w.state_frame_stride = p->state_stride;
         w.W = p->W; w.H = p->H; w.D = p->D; w.P1 = p->P1; w.P2 = p->P2; w.y0 = 0; w.rows = 0;
         launch_sweep(p->stream, w, 1, 1);
+        if (p->sweep_mid) {                                      // the meeting sweeps leave Y_dn for the upper half of the rows only
+            w.X = p->dX + (size_t)f * p->N;
+            launch_sweep(p->stream, w, 1, 0);
+        }
         WtaArgs a;
         a.L = nullptr; a.l_frame_stride = 0; a.l_dir_stride = 0;
         a.off = p->dOff + f * p->NP; a.bestD = p->dBestD + f * p->NP; a.minC = p->dMinC + f * p->NP; a.vMax = p->vMax;
@@ -982,14 +1038,14 @@ void* fsgm_epi_plan_stream(fsgm_epi_plan* p) { return p ? (void*)p->stream : nul
 
 const char* fsgm_epi_plan_kernel_name(fsgm_epi_plan* p) {
     if (!p) return "";
-    return pipeline_name(p->kernel_kind, p->sweep_par, p->band_chain);
+    return pipeline_name(p->kernel_kind, p->sweep_par, p->band_chain, p->sweep_mid);
 }
 
 const char* fsgm_epi_auto_pipeline(int32_t width, int32_t height, int32_t dMax, int32_t batch, int32_t paths, int32_t P1, int32_t P2,
                                    int32_t cmax, int32_t cus) {
     if (width <= 0 || height <= 0 || dMax <= 0 || batch <= 0 || (paths != 4 && paths != 8) || cus <= 0) return "";
     const PipelineChoice c = choose_pipeline(width, height, dMax, batch, paths, P1, P2, cmax, 0, cus);
-    return pipeline_name(c.kind, c.sweep_par, c.band_chain);
+    return pipeline_name(c.kind, c.sweep_par, c.band_chain, c.sweep_mid);
 }
 
 // The achievable HBM rate of this device, measured the way the aggregation kernels move bytes: a grid-stride

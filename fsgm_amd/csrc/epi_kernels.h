@@ -49,10 +49,11 @@ struct WtaArgs {
 struct SweepArgs {
     const uint8_t* C;         // [frames] cost volumes
     size_t c_frame_stride;
-    uint8_t* X;               // [frames] u8 sums of the sweep's three y (epi_sweep.hip): written by modes 0/1, read (the down sweep's) by mode 2
+    uint8_t* X;               // [frames] u8 sums of a sweep's three y (epi_sweep.hip): written by modes 0/1, read (the other sweep's) by modes 2/3
     size_t x_frame_stride;
-    const uint8_t* Lh;        // mode 2: [frames] the horizontal pair's sum Y_h (pair kernels)
+    const uint8_t* Lh;        // final modes (2, 3): [frames] the horizontal pair's sum Y_h (pair kernels)
     size_t lh_frame_stride;
+    int lh_natural;           // Lh is in natural d order (pairx_* kernels), not the sweeps' private one
     uint2* rec;               // mode 2: [frames][NP] {best | minC << 16, S[best-1] | S[best+1] << 16} (sums of u8 path costs: 16 bits)
     uint16_t* s0;             // mode 2: [frames][NP] S[0] of every pixel
     const uint8_t* state_in;  // [frames][3][W][D] normalised path states of the row above this block
@@ -141,7 +142,9 @@ void launch_aggregate(hipStream_t st, AggArgs a, int paths, int frames, int kern
 void launch_wta(hipStream_t st, const WtaArgs& a, int frames, bool packed);
 int    sweep_rows_per_launch(int D);
 size_t sweep_state_bytes(int W, int D);   // one state buffer of one frame
-void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode, int tall = 0);   // 0 down, 1 up, 2 up + fused WTA; tall: 8-wave workgroups (modes 0, 1)
+void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode, int tall = 0);
+// rows [ybeg, yend) of the sweep frame; modes 2 / 3: final on the mirrored / the pass-0 frame; *parity carries the state buffer in use from one range of a sweep to the next
+void launch_sweep_rows(hipStream_t st, const SweepArgs& a, int frames, int mode, int tall, int ybeg, int yend, int* parity);   // 0 down, 1 up, 2 up + fused WTA; tall: 8-wave workgroups (modes 0, 1)
 size_t pair_ckpt_bytes(int W, int H, int D, int axis);      // per frame; axis 0 horizontal, 1 vertical
 void launch_pair(hipStream_t st, const PairArgs& a, int frames, int axis, bool final_pass, int phase = 0);
 bool pair_x_fine_ok(int D);                                                        // the along-x pair with 8 costs a lane exists for this D

@@ -67,6 +67,8 @@ namespace fsgm {
 //   MODE 0: pass-0 frame, writes Y_dn.   MODE 1: point-mirrored frame, writes Y_up.
 //   MODE 2: point-mirrored frame, final: S = 8*(C + P2) - (Y_up + Y_dn + Y_h) in registers,
 //           WTA per pixel, writes one record {best, minC, S[best-1], S[best+1]} + S[0] per pixel.
+//   MODE 3: the same final on the pass-0 frame (X = Y_up of the rows it covers): the down half of the sweeps that meet
+//           in the middle (capi_epi.hip, sweep_mid).
 // =============================================================================================
 #ifndef FSGM_SWEEP_L16
 #define FSGM_SWEEP_L16 1        // diagonal states in LDS as 2 x u16 per dword (A/B knob; 0: packed bytes, half the LDS)
@@ -79,7 +81,8 @@ namespace fsgm {
 #endif
 template <int LPP, int MODE, int NWV, int GPW>
 __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepArgs a) {
-    constexpr bool UP = MODE != 0;
+    constexpr bool UP = MODE == 1 || MODE == 2;
+    constexpr bool FINAL = MODE >= 2;          // 2: final on the point-mirrored frame, 3: final on the pass-0 frame
     constexpr int PXG = 64 / LPP;            // columns per pixel group (one wave-wide DP step)
     constexpr int PXW = GPW * PXG;           // own columns per wave: GPW groups, each with its three paths, + one halo group
     constexpr int D = LPP * 16;
@@ -91,10 +94,10 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
     // (L16; the final sweep, whose WTA rows take 8 KB more, and the two-group form keep them packed to bytes in one
     // plane instead -- 12 more instructions per diagonal step, but one more workgroup per CU)
     constexpr int NCD = STRIP + T + 1;
-    constexpr bool L16 = MODE != 2 && GPW == 1 && FSGM_SWEEP_L16 != 0;
-    constexpr int PF = MODE == 2 ? 2 : (GPW > 1 ? 2 : FSGM_SWEEP_PF);    // rows of C in flight per lane and group
+    constexpr bool L16 = !FINAL && GPW == 1 && FSGM_SWEEP_L16 != 0;
+    constexpr int PF = FINAL ? 2 : (GPW > 1 ? 2 : FSGM_SWEEP_PF);    // rows of C in flight per lane and group
     __shared__ uint4 sDiag[2][2][L16 ? 2 : 1][NCD * LPP];  // [row parity][direction][plane][column][lane-of-pixel]
-    __shared__ __attribute__((aligned(16))) uint32_t sRow[MODE == 2 ? NWV * 64 * 8 : 4];   // MODE 2: S of the wave's pixels (u16, two planes: epi_step.h)
+    __shared__ __attribute__((aligned(16))) uint32_t sRow[FINAL ? NWV * 64 * 8 : 4];   // final modes: S of the wave's pixels (u16, two planes: epi_step.h)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPP, j = lane % LPP;
@@ -216,10 +219,10 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
     }
     __syncthreads();
 
-    const uint8_t* __restrict__ Lhf = MODE == 2 ? a.Lh + f * a.lh_frame_stride : nullptr;
+    const uint8_t* __restrict__ Lhf = FINAL ? a.Lh + f * a.lh_frame_stride : nullptr;
     // rows in flight per lane: C of the own groups and of the halo group; MODE 2: the other partial sums of the own
     // pixels (Y_dn, Y_h) as well -- all requested PF rows ahead, so no row waits for HBM
-    uint4 ringOwn[GPW][PF], ringHalo[PF], ringX[MODE == 2 ? GPW : 1][PF], ringH[MODE == 2 ? GPW : 1][PF];
+    uint4 ringOwn[GPW][PF], ringHalo[PF], ringX[FINAL ? GPW : 1][PF], ringH[FINAL ? GPW : 1][PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) {
         const int y = min(y0 + i, H - 1);
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
         for (int q = 0; q < GPW; q++) {
             const uint32_t off = vox_off(min(gx0 + q * PXG, W - 1), y);
             ringOwn[q][i] = *(const uint4*)(Cf + off);
-            if (MODE == 2) { ringX[q][i] = vol_load(Xf + off); ringH[q][i] = vol_load(Lhf + off); }
+            if (FINAL) { ringX[q][i] = vol_load(Xf + off); ringH[q][i] = vol_load(Lhf + off); }
         }
         ringHalo[i] = *(const uint4*)(Cf + vox_off(hxc, y));
     }
@@ -268,16 +271,17 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
 #pragma unroll
                 for (int i = 0; i < 8; i++) YS[i] += Y[i];
             }
-            if (MODE != 2) {
+            if (!FINAL) {
                 // sum of this sweep's three y, one byte per voxel (3*P2 <= 255)      :227-232
                 if (own_ok) vol_store(Xf + vox_off(gx, y), pack_p(YS));
             } else {
-                // S = 8*(C + P2) - (Y_up (registers) + Y_dn + Y_h), all at this pixel
+                // S = 8*(C + P2) - (this sweep's Y (registers) + the other sweep's Y + Y_h), all at this pixel
                 uint32_t E2[8], ST[8];
                 unpack_p(curX[q], E2);
 #pragma unroll
                 for (int i = 0; i < 8; i++) YS[i] += E2[i];
-                unpack_p(curH[q], E2);
+                if (a.lh_natural) unpack_c(curH[q], E2, 0u);         // Y_h of the pairx_* kernels: natural d order
+                else unpack_p(curH[q], E2);
 #pragma unroll
                 for (int i = 0; i < 8; i++) ST[i] = pk_sub(pk_mad16(CP[i], 0x00080008u, 0u), pk_add(YS[i], E2[i]));
                 wta_row_record<LPP, NWV * 64>(ST, sRow, tid, j, own_ok, a.rec, a.s0, f * (size_t)NP + pix_of(min(gx, W - 1), y));
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
                 const uint32_t off = vox_off(min(gx0 + q * PXG, W - 1), yn);
                 cOwn[q] = ringOwn[q][i];
                 ringOwn[q][i] = *(const uint4*)(Cf + off);
-                if (MODE == 2) {
+                if (FINAL) {
                     cX[q] = ringX[q][i]; cH[q] = ringH[q][i];
                     ringX[q][i] = vol_load(Xf + off); ringH[q][i] = vol_load(Lhf + off);
                 }
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(NWV * 64, FSGM_SWEEP_MINW) void sweep_kernel(SweepA
         if (k0 + i < rows) {                                     // block-uniform
             uint4 cOwn[GPW], cX[GPW], cH[GPW];
 #pragma unroll
-            for (int q = 0; q < GPW; q++) { cOwn[q] = ringOwn[q][i]; if (MODE == 2) { cX[q] = ringX[q][i]; cH[q] = ringH[q][i]; } }
+            for (int q = 0; q < GPW; q++) { cOwn[q] = ringOwn[q][i]; if (FINAL) { cX[q] = ringX[q][i]; cH[q] = ringH[q][i]; } }
             row(k0 + i, cOwn, ringHalo[i], cX, cH);
         }
 
@@ -874,42 +878,51 @@ size_t sweep_state_bytes(int W, int D) { return (size_t)3 * W * D; }
 // (sweep_kernel's GPW parameter: pixel groups per wave.  2 -- six own DP steps and one halo step per row instead of three and one,
 // 64-column strips -- halves the halo's weight but needs twice the registers and leaves half the workgroups: measured 7 % slower
 // (4.04 vs 3.78 ms per 32 frames); only GPW = 1 is instantiated.)
+// rows [ybeg, yend) of the sweep frame, T a launch; *parity: which of the two state buffers the next launch writes (carried from
+// one range of a sweep to the next)
 template <int LPP, int GPW, int NWV>
-static void launch_sweep_g(hipStream_t st, SweepArgs a, int frames, int mode) {
+static void launch_sweep_g(hipStream_t st, SweepArgs a, int frames, int mode, int ybeg, int yend, int* parity) {
     constexpr int STRIP = NWV * GPW * (64 / LPP), T = (NWV / 2) * (64 / LPP);
     dim3 grid((a.W + STRIP - 1) / STRIP, frames);
     uint8_t* const buf0 = a.state_out;                     // caller passes the base of 2 x frames x state buffers
     uint8_t* const buf1 = a.state_out + (size_t)frames * a.state_frame_stride;
-    int b = 0;
-    for (int y0 = 0; y0 < a.H; y0 += T, b ^= 1) {
+    int b = *parity;
+    for (int y0 = ybeg; y0 < yend; y0 += T, b ^= 1) {
         a.y0 = y0;
-        a.rows = T;
+        a.rows = std::min(T, yend - y0);
         a.state_in = b ? buf0 : buf1;
         a.state_out = b ? buf1 : buf0;
         if (mode == 0)      hipLaunchKernelGGL((sweep_kernel<LPP, 0, NWV, GPW>), grid, dim3(NWV * 64), 0, st, a);
         else if (mode == 1) hipLaunchKernelGGL((sweep_kernel<LPP, 1, NWV, GPW>), grid, dim3(NWV * 64), 0, st, a);
-        else                hipLaunchKernelGGL((sweep_kernel<LPP, 2, NWV, GPW>), grid, dim3(NWV * 64), 0, st, a);
+        else if (mode == 2) hipLaunchKernelGGL((sweep_kernel<LPP, 2, NWV, GPW>), grid, dim3(NWV * 64), 0, st, a);
+        else                hipLaunchKernelGGL((sweep_kernel<LPP, 3, NWV, GPW>), grid, dim3(NWV * 64), 0, st, a);
     }
+    *parity = b;
 }
 
 // tall = 1: workgroups of 8 waves (64-column strips, 32 rows per launch at D = 128) for the non-final modes -- half the
 // launches of a sweep.  A sweep of a small batch is a chain of launches that no other work hides (parallel sweeps, mode 3):
 // fewer, longer launches shorten it; large batches keep the 4-wave form (more workgroups per CU, round 1's measurement).
 template <int LPP>
-static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode, int tall) {
-    if (tall && mode != 2) launch_sweep_g<LPP, 1, 8>(st, a, frames, mode);
-    else launch_sweep_g<LPP, 1, FSGM_SWEEP_WAVES>(st, a, frames, mode);
+static void launch_sweep_t(hipStream_t st, SweepArgs a, int frames, int mode, int tall, int ybeg, int yend, int* parity) {
+    if (tall) launch_sweep_g<LPP, 1, 8>(st, a, frames, mode, ybeg, yend, parity);
+    else launch_sweep_g<LPP, 1, FSGM_SWEEP_WAVES>(st, a, frames, mode, ybeg, yend, parity);
+}
+
+void launch_sweep_rows(hipStream_t st, const SweepArgs& a, int frames, int mode, int tall, int ybeg, int yend, int* parity) {
+    switch (agg_packed_lpp(a.D)) {
+        case 1: launch_sweep_t<1>(st, a, frames, mode, tall, ybeg, yend, parity); break;
+        case 2: launch_sweep_t<2>(st, a, frames, mode, tall, ybeg, yend, parity); break;
+        case 4: launch_sweep_t<4>(st, a, frames, mode, tall, ybeg, yend, parity); break;
+        case 8: launch_sweep_t<8>(st, a, frames, mode, tall, ybeg, yend, parity); break;
+        case 16: launch_sweep_t<16>(st, a, frames, mode, tall, ybeg, yend, parity); break;
+        default: break;
+    }
 }
 
 void launch_sweep(hipStream_t st, const SweepArgs& a, int frames, int mode, int tall) {
-    switch (agg_packed_lpp(a.D)) {
-        case 1: launch_sweep_t<1>(st, a, frames, mode, tall); break;
-        case 2: launch_sweep_t<2>(st, a, frames, mode, tall); break;
-        case 4: launch_sweep_t<4>(st, a, frames, mode, tall); break;
-        case 8: launch_sweep_t<8>(st, a, frames, mode, tall); break;
-        case 16: launch_sweep_t<16>(st, a, frames, mode, tall); break;
-        default: break;
-    }
+    int parity = 0;
+    launch_sweep_rows(st, a, frames, mode, tall, 0, a.H, &parity);
 }
 
 void launch_sweep_finish(hipStream_t st, const WtaArgs& a, const uint2* rec, const uint16_t* s0, int frames) {

@@ -154,7 +154,8 @@ class EpiPlan:
     def set_agg_mode(self, mode):
         """0 auto, 1 per-direction line kernels, 2 fused pipeline when eligible, 3 parallel sweeps (8 paths) when eligible,
         4 band sweeps (all four paths of a pass in one sweep, one workgroup per frame: very large batches), 5 the same with the
-        bands of a frame as workgroups of their own that hand over while they run (chained: batches from ~100 frames)."""
+        bands of a frame as workgroups of their own that hand over while they run (chained: batches from ~100 frames), 6 the
+        parallel sweeps meeting in the middle (each finishes the other's half of the rows with the WTA inside: 10-25 frames)."""
         check(self.lib.fsgm_epi_plan_set_agg_mode(self._h, int(mode)))
 
     def upload(self, frame, I1, I2, pd0, nd, off):

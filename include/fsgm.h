@@ -116,14 +116,16 @@ fsgm_status fsgm_epi_plan_set_penalties(fsgm_epi_plan* plan, int32_t P1, int32_t
  * up sweep side by side and a WTA kernel over the three sums (half the latency of 2, 3 B per voxel more traffic),
  * 4 = the band sweeps (epi_band.hip: all four paths of a raster pass in one sweep, one workgroup per frame, for batches of
  * hundreds of frames; D = 16<<k, no-wrap penalties with P1 <= P2, P1 + P2 <= 127), 5 = the band sweeps with the bands of a
- * frame as workgroups of their own that hand their last row over while they run ("band16chain/nowrap").
+ * frame as workgroups of their own that hand their last row over while they run ("band16chain/nowrap"),
+ * 6 = 8 paths only: as 3, but the two sweeps meet in the middle -- each writes its sum for its first half of the rows and crosses
+ * the other's half as a final sweep with the WTA inside ("sweep16mid/nowrap": the traffic of 2 on the chain of 3).
  * Auto picks by batch size, frame shape and path count; fsgm_epi_auto_pipeline() below answers for any configuration and
- * fsgm_epi_plan_kernel_name() for a plan.  At 1242x375x128, 256 CUs: 8 paths -- line kernels below 4 frames, 3 below 18, 2 up
- * to ~229, then 4 where a round of one workgroup per frame pays (230-256, 473-512, ...) and 5 between those rounds; 4 paths --
+ * fsgm_epi_plan_kernel_name() for a plan.  At 1242x375x128, 256 CUs: 8 paths -- line kernels below 4 frames, 3 below 10, 6 below 26,
+ * 2 up to ~229, then 4 where a round of one workgroup per frame pays (230-256, 473-512, ...) and 5 between those rounds; 4 paths --
  * line kernels below 9 frames, then 2, then 4 / 5 likewise.  The switch points move with the frame shape by voxels^(-2/3)
  * (FSGM_EPI_SHAPE_SCALE).  Results are identical in every mode.
  * HBM a plan holds per frame beyond C (allocated when a mode first runs, kept until the plan is destroyed; N = W*H*D bytes):
- * mode 1: paths x N (path volumes); mode 2: 2 N + N/8 + boundary states (8 paths) / N + 2 N/8 (4 paths); mode 3: one more N;
+ * mode 1: paths x N (path volumes); mode 2: 2 N + N/8 + boundary states (8 paths) / N + 2 N/8 (4 paths); modes 3, 6: one more N;
  * modes 4, 5: N + N/4 (9th-bit plane, 8 paths only) + one hand-off map of 3*W*D bytes (mode 5: one per band boundary,
  * ~1.4 B per voxel at 1242x375x128), + 10 bytes per pixel of WTA records for modes 2-5.  Mode 5 synchronises its
  * workgroups through bounded polls on device memory; a poll that gives up raises a flag that fsgm_epi_plan_sync / _download /

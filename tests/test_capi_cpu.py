@@ -99,17 +99,18 @@ def test_window_mean_rounding_identity_of_the_rows_cost_kernel():
 
 def test_auto_mode_table():
     """fsgm_epi_auto_pipeline (a pure function: no device).  KITTI shape, 8 paths, no-wrap penalties: line kernels below 4 frames,
-    parallel sweeps below 18, the block sweep pipeline from there, the band sweeps where a round of them pays (230..256 frames,
+    parallel sweeps below 26 (meeting in the middle from 10 on), the block sweep pipeline from there, the band sweeps where a round of them pays (230..256 frames,
     473..512), the chained form between the rounds; 4 paths: line kernels below 9 frames, then the pair kernels, then bands.
     Smaller frames: the switch points move with voxels^(-2/3) -- measured at 320x240x64 (profiles/r03_crossover_320x240x64.txt):
     line kernels fastest up to ~26 frames at 8 paths and ~48 at 4, block sweeps from ~80, band sweeps at 4 paths / 512 frames only."""
     from fsgm_amd import auto_pipeline
-    kitti = [(8, 1, "packed16/nowrap"), (8, 3, "packed16/nowrap"), (8, 4, "sweep16par/nowrap"), (8, 17, "sweep16par/nowrap"), (8, 18, "sweep16/nowrap"),
+    kitti = [(8, 1, "packed16/nowrap"), (8, 3, "packed16/nowrap"), (8, 4, "sweep16par/nowrap"), (8, 9, "sweep16par/nowrap"), (8, 10, "sweep16mid/nowrap"),
+             (8, 25, "sweep16mid/nowrap"), (8, 26, "sweep16/nowrap"),
              (8, 200, "sweep16/nowrap"), (8, 256, "band16/nowrap"), (8, 300, "band16chain/nowrap"), (8, 512, "band16/nowrap"),
              (4, 8, "packed16/nowrap"), (4, 9, "pairs16/nowrap"), (4, 128, "pairs16/nowrap"), (4, 512, "band16/nowrap")]
     for paths, B, name in kitti:
         assert auto_pipeline(1242, 375, 128, B, paths, 6, 64) == name, (paths, B)
-    small = [(8, 16, "packed16/nowrap"), (8, 40, "sweep16par/nowrap"), (8, 128, "sweep16/nowrap"), (8, 512, "sweep16/nowrap"),
+    small = [(8, 16, "packed16/nowrap"), (8, 40, "sweep16par/nowrap"), (8, 128, "sweep16mid/nowrap"), (8, 140, "sweep16/nowrap"), (8, 512, "sweep16/nowrap"),
              (4, 40, "packed16/nowrap"), (4, 128, "pairs16/nowrap"), (4, 512, "band16/nowrap")]
     for paths, B, name in small:
         assert auto_pipeline(320, 240, 64, B, paths, 6, 64) == name, (paths, B)

@@ -393,7 +393,7 @@ def test_one_plan_through_every_pipeline(gpu_lib, oracle):
     W, H, D, B = 96, 70, 128, 3
     vols = [synth.cost_volume(W, H, D, seed=31 + f, cmax=24) for f in range(B)]
     _, _, off = synth.epi_maps(W, H, "general", seed=3)
-    for paths, modes in ((8, (4, 2, 3, 5, 1, 5, 3, 2, 4)), (4, (4, 2, 5, 1, 2, 4))):
+    for paths, modes in ((8, (4, 2, 3, 6, 5, 1, 6, 5, 3, 2, 6, 4)), (4, (4, 2, 5, 1, 2, 4))):
         want = []
         for v in vols:
             S = oracle.epi_aggregate(v, 6, 64, paths)
@@ -416,11 +416,11 @@ def test_one_plan_through_every_pipeline(gpu_lib, oracle):
 
 @pytest.mark.parametrize("subpixel", [1, 0])
 @pytest.mark.parametrize("W,H,D,B", [(150, 70, 128, 3), (97, 200, 64, 2), (1242, 40, 128, 1), (33, 375, 128, 2), (20, 9, 16, 1), (260, 31, 32, 2),
-                                     (70, 50, 256, 1), (1, 9, 64, 1), (9, 1, 64, 2), (96, 64, 64, 7)])
+                                     (70, 50, 256, 1), (1, 9, 64, 1), (9, 1, 64, 2), (96, 64, 64, 7), (45, 33, 128, 2), (40, 2, 128, 1), (64, 97, 32, 1)])
 def test_parallel_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, subpixel):
-    """Aggregation mode 3 (down and up sweeps side by side, Y_up written out, WTA over C, Y_dn, Y_up, Y_h): bestD / minC of
-    every frame and S of the last frame against the oracle, back-to-back runs on reused buffers; then the same plan in
-    mode 2 (buffers shared between the two forms)."""
+    """Aggregation mode 3 (down and up sweeps side by side, Y_up written out, WTA over C, Y_dn, Y_up, Y_h) and mode 6 (the two
+    sweeps meet in the middle and finish each other's half with the WTA inside): bestD / minC of every frame and S of the last
+    frame against the oracle, back-to-back runs on reused buffers; then the same plan in mode 2 (buffers shared between the forms)."""
     vols = [synth.cost_volume(W, H, D, seed=W + H + f, cmax=24) for f in range(B)]
     _, _, off = synth.epi_maps(W, H, "general", seed=3)
     want, S = [], None
@@ -433,7 +433,7 @@ def test_parallel_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, subpixel)
         for f in range(B):
             plan.upload_cost(f, vols[f])
             plan.upload_offset(f, off)
-        for mode, name in ((3, "sweep16par/nowrap"), (2, "sweep16/nowrap"), (3, "sweep16par/nowrap")):
+        for mode, name in ((3, "sweep16par/nowrap"), (6, "sweep16mid/nowrap"), (2, "sweep16/nowrap"), (6, "sweep16mid/nowrap"), (3, "sweep16par/nowrap")):
             plan.set_agg_mode(mode)
             assert plan.kernel_name == name
             for _ in range(3):

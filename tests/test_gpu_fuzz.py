@@ -42,7 +42,7 @@ def test_epi_random_configs(gpu_lib, oracle, seed):
         for f in range(B):
             plan.upload_cost(f, vols[f])
             plan.upload_offset(f, off)
-        for mode in (1, 2, 3, 4, 5):                         # a mode whose pipeline does not cover the configuration falls back
+        for mode in (1, 2, 3, 6, 4, 5):                      # a mode whose pipeline does not cover the configuration falls back
             plan.set_agg_mode(mode)
             plan.run(STAGE_AGGREGATE | STAGE_WTA)
             for f in range(B):
@@ -82,7 +82,7 @@ def test_epi_random_tall_configs(gpu_lib, oracle, seed):
         for f in range(B):
             plan.upload_cost(f, vols[f])
             plan.upload_offset(f, off)
-        for mode in (4, 5, 2, 5, 4):
+        for mode in (4, 5, 2, 6, 5, 4):
             plan.set_agg_mode(mode)
             plan.run(STAGE_AGGREGATE | STAGE_WTA)
             for f in range(B):
