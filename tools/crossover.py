@@ -16,7 +16,7 @@ for paths in (8, 4):
             plan.upload_cost(0, base); plan.upload_offset(0, off)
             for f in range(1, B):
                 plan.copy_cost(f, 0, 11 * f); plan.upload_offset(f, off)
-            modes = (1, 3, 2, 4, 5) if paths == 8 else (1, 2, 4, 5)
+            modes = (1, 3, 6, 2, 4, 5) if paths == 8 else (1, 2, 4, 5)
             for mode in modes:
                 plan.set_agg_mode(mode)
                 r.append((plan.kernel_name + ("+strips" if strips == "1" else ""), plan.time(STAGE_AGGREGATE | STAGE_WTA, 2, 6)))
