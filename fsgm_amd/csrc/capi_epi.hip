@@ -42,6 +42,7 @@ struct fsgm_epi_plan {
     uint8_t *dLh = nullptr, *dX = nullptr, *dXup = nullptr, *dState = nullptr, *dCkpt = nullptr, *dCkptV = nullptr;
     // parallel sweeps (sweep_par): Y_up of every frame and the up sweep's own block-boundary states
     uint8_t *dXupAll = nullptr, *dStateUp = nullptr;
+    uint8_t* dLx = nullptr;              // parallel sweeps of few frames: the two along-x path volumes [batch][2][N] (par_x_lines)
     bool sweep_par = false;              // AGG_SWEEP only: down and up sweeps side by side, WTA over the three Y volumes
     bool sweep_mid = false;              // sweep_par only: the two sweeps meet in the middle, each finishing the other's half with the WTA inside
     // band sweeps (epi_band.hip): the first pass's 9th bits, the hand-off between the bands of a frame; dX, dRec, dS0 as above
@@ -267,7 +268,7 @@ void fsgm_epi_plan_destroy(fsgm_epi_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->prm.device);
     void* bufs[] = {p->dI1, p->dI2, p->dCen1, p->dCen2, p->dPd0, p->dNd, p->dOff, p->dVz,
-                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dXupAll, p->dStateUp, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dBits, p->dBandEdge, p->dBandTicket, p->dBandErr};
+                    p->dCraw, p->dC, p->dL, p->dBestD, p->dMinC, p->dS, p->dD2enc, p->dD2, p->dConf, p->dLh, p->dX, p->dXup, p->dXupAll, p->dStateUp, p->dLx, p->dState, p->dCkpt, p->dCkptV, p->dRec, p->dS0, p->dRflow, p->dFlow, p->dRgb, p->dBits, p->dBandEdge, p->dBandTicket, p->dBandErr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -492,6 +493,16 @@ static int mid_tall(const fsgm_epi_plan* p) {
     return par_tall(p);
 }
 
+// Parallel sweeps (not the form that meets in the middle, whose final sweeps read Y_h): the along-x pair as two line-kernel slots.
+// FSGM_EPI_PAR_XLINES: 0 never, 1 whenever possible; default: up to 5 frames -- 4 frames 0.871 -> 0.832 ms, 6 frames 0.970 -> 1.050:
+// with more frames the two volumes' bytes and the lines' instructions cost more than the pair's longer chain
+// (profiles/r04_par_xlines.txt).
+static int par_x_lines(const fsgm_epi_plan* p) {
+    static const int env = env_int("FSGM_EPI_PAR_XLINES", -1);
+    if (!p->sweep_par || p->sweep_mid || env == 0) return 0;
+    return env == 1 || p->batch <= 5 ? 1 : 0;
+}
+
 // (the pipelines share some buffers -- records, S[0] words, Y volumes, the pair's stream -- and a plan may be switched from
 // one to another: each set creates only what is still missing)
 static fsgm_status ensure_pairs_buffers(fsgm_epi_plan* p) {
@@ -575,13 +586,14 @@ static fsgm_status ensure_band_buffers(fsgm_epi_plan* p) {
 }
 
 static fsgm_status ensure_par_buffers(fsgm_epi_plan* p) {
-    if (p->dXupAll) return FSGM_OK;
+    if (p->dXupAll && (p->dLx || !par_x_lines(p))) return FSGM_OK;
     LazySet ls;
-    uint8_t *xu, *su;
-    ls.alloc(&xu, (size_t)p->batch * p->N);
-    ls.alloc(&su, 2 * (size_t)p->batch * sweep_state_bytes(p->W, p->D));
+    uint8_t *xu = p->dXupAll, *su = p->dStateUp, *lx = p->dLx;
+    if (!xu) ls.alloc(&xu, (size_t)p->batch * p->N);
+    if (!su) ls.alloc(&su, 2 * (size_t)p->batch * sweep_state_bytes(p->W, p->D));
+    if (!lx && par_x_lines(p)) ls.alloc(&lx, 2 * (size_t)p->batch * p->N);
     if (ls.err != hipSuccess) return lazy_fail(ls, "parallel sweep buffers");
-    p->dXupAll = xu; p->dStateUp = su;
+    p->dXupAll = xu; p->dStateUp = su; p->dLx = lx;
     return FSGM_OK;
 }
 
@@ -650,7 +662,15 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         h.ckpt = p->dCkpt; h.ckpt_frame_stride = ckb;
         h.W = p->W; h.H = p->H; h.D = p->D; h.P1 = p->P1; h.P2 = p->P2;
         // small batches wait for the pair's serial chain (3 x W steps): 8 costs a lane shorten it (Y_h then in natural d order)
-        if (par_pair_fine(p)) launch_pair_x_fine(p->stream_h, h, p->batch);
+        if (par_x_lines(p)) {
+            // few frames: the two along-x paths as line kernels (hand-written step, chains of W steps instead of the pair's 3 W;
+            // L_fwd and L_bwd written out: 2 B per voxel more than Y_h, added up by the WTA kernel)
+            AggArgs ax;
+            ax.C = p->dC; ax.L = p->dLx; ax.c_frame_stride = p->N; ax.l_frame_stride = 2 * p->N; ax.l_dir_stride = p->N;
+            ax.W = p->W; ax.H = p->H; ax.D = p->D; ax.P1 = p->P1; ax.P2 = p->P2;
+            launch_aggregate(p->stream_h, ax, 2, p->batch, AGG_PACKED_NOWRAP);
+        }
+        else if (par_pair_fine(p)) launch_pair_x_fine(p->stream_h, h, p->batch);
         else                  launch_pair(p->stream_h, h, p->batch, 0, false);
         FSGM_HIP(hipEventRecord(p->ev_h, p->stream_h));
         SweepArgs w{};
@@ -799,6 +819,8 @@ static fsgm_status enqueue(fsgm_epi_plan* p, int stages) {
         q.C = p->dC; q.Xdn = p->dX; q.Xup = p->dXupAll; q.v_frame_stride = p->N;
         q.Lh = p->dLh; q.lh_frame_stride = p->N; q.lh_natural = par_pair_fine(p);
         q.nC = 8; q.bias = p->P2 + p->P1; q.Sdbg = nullptr;
+        q.Lx = nullptr; q.lx_frame_stride = 0;
+        if (par_x_lines(p)) { q.Lh = nullptr; q.Lx = p->dLx; q.lx_frame_stride = 2 * p->N; q.nC = 6; }   // S = 6 (C + bias) - (Y_dn + Y_up) + L_fwd + L_bwd
         launch_wta_sweep(p->stream, a, q, p->batch);
     } else if ((stages & FSGM_STAGE_WTA) && (p->kernel_kind == AGG_SWEEP || p->kernel_kind == AGG_PAIRS || p->kernel_kind == AGG_BAND)) {
         WtaArgs a;                                   // the argmin happened inside the final sweep / pair pass; finish the records
@@ -946,6 +968,8 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dX + (size_t)f * p->N; q.Xup = p->dXup; q.v_frame_stride = p->N;
         q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_natural = p->sweep_par ? par_pair_fine(p) : 0;
         q.nC = 8; q.bias = p->P2 + p->P1; q.Sdbg = p->dS;
+        q.Lx = nullptr; q.lx_frame_stride = 0;
+        if (par_x_lines(p)) { q.Lh = nullptr; q.Lx = p->dLx + (size_t)f * 2 * p->N; q.lx_frame_stride = 2 * p->N; q.nC = 6; }
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));
@@ -974,6 +998,7 @@ fsgm_status fsgm_epi_plan_download_sum(fsgm_epi_plan* p, int32_t f, uint32_t* S)
         q.C = p->dC + (size_t)f * p->N; q.Xdn = p->dXup; q.Xup = nullptr; q.v_frame_stride = p->N;
         q.Lh = p->dLh + (size_t)f * p->N; q.lh_frame_stride = p->N; q.lh_natural = pairs_x_fine(p);
         q.nC = 4; q.bias = p->P2 + p->P1; q.Sdbg = p->dS;
+        q.Lx = nullptr; q.lx_frame_stride = 0;
         launch_wta_sweep(p->stream, a, q, 1);
         FSGM_HIP(hipGetLastError());
         FSGM_HIP(hipStreamSynchronize(p->stream));

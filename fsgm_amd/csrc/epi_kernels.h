@@ -95,7 +95,9 @@ struct SweepSumArgs {          // what wta_sweep_kernel adds up (u8 volumes; the
     const uint8_t* Lh;        // [frames] Y_h of the horizontal pair
     size_t lh_frame_stride;
     int lh_natural;           // Lh is in natural d order (pairx_* kernels), not the private one
-    int nC;                   // S = nC*(C + bias) - (Xdn + Xup + Lh)
+    const uint8_t* Lx;        // instead of Lh (then null): [frames][2][N] the two along-x PATH volumes L of the line kernels, natural d order
+    size_t lx_frame_stride;
+    int nC;                   // S = nC*(C + bias) - (Xdn + Xup + Lh) [+ Lx[0] + Lx[1]: a path's L = (C + bias) - (y + P1)]
     int bias;                 // P2 + P1: the Y volumes hold y + P1 per path (epi_step.h, step_b)
     uint32_t* Sdbg;           // optional natural-order u32 dump of S [frames][NP][D]
 };

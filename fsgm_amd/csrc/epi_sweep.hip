@@ -401,10 +401,18 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
 #pragma unroll
         for (int k = 0; k < 8; k++) YT[k] += E2[k];
     }
-    if (q.lh_natural) unpack_c(wvol_load(q.Lh + f * q.lh_frame_stride + bo), E2, 0u);
-    else unpack_p(wvol_load(q.Lh + f * q.lh_frame_stride + bo), E2);
+    if (q.Lx) {                                                          // the along-x paths as two path volumes (line kernels)
+        uint32_t L0[8];
+        unpack_c(wvol_load(q.Lx + f * q.lx_frame_stride + bo), L0, 0u);
+        unpack_c(wvol_load(q.Lx + f * q.lx_frame_stride + (q.lx_frame_stride >> 1) + bo), E2, 0u);
 #pragma unroll
-    for (int k = 0; k < 8; k++) ST[k] = pk_sub(pk_mad16(CP[k], nC * 0x10001u, 0u), pk_add(YT[k], E2[k]));
+        for (int k = 0; k < 8; k++) ST[k] = pk_add(pk_sub(pk_mad16(CP[k], nC * 0x10001u, 0u), YT[k]), pk_add(L0[k], E2[k]));
+    } else {
+        if (q.lh_natural) unpack_c(wvol_load(q.Lh + f * q.lh_frame_stride + bo), E2, 0u);
+        else unpack_p(wvol_load(q.Lh + f * q.lh_frame_stride + bo), E2);
+#pragma unroll
+        for (int k = 0; k < 8; k++) ST[k] = pk_sub(pk_mad16(CP[k], nC * 0x10001u, 0u), pk_add(YT[k], E2[k]));
+    }
 
     uint32_t key = 0xFFFFFFFFu;
     srow_store<256>(sS, tid, ST);
@@ -430,7 +438,9 @@ __global__ __launch_bounds__(256) void wta_sweep_kernel(WtaArgs a, SweepSumArgs 
             else if (p + 1 < NP) {                                           // next pixel's d=0 (:296): byte 0 of its lane 0 in every volume
                 const size_t nb = f * q.v_frame_stride + (size_t)(p + 1) * D;
                 const size_t nh = f * q.lh_frame_stride + (size_t)(p + 1) * D;
-                c1 = nC * ((uint32_t)q.C[nb] + (uint32_t)q.bias) - ((uint32_t)q.Xdn[nb] + (q.Xup ? (uint32_t)q.Xup[nb] : 0u) + (uint32_t)q.Lh[nh]);
+                c1 = nC * ((uint32_t)q.C[nb] + (uint32_t)q.bias) - ((uint32_t)q.Xdn[nb] + (q.Xup ? (uint32_t)q.Xup[nb] : 0u));
+                if (q.Lx) { const size_t nx = f * q.lx_frame_stride + (size_t)(p + 1) * D; c1 += (uint32_t)q.Lx[nx] + (uint32_t)q.Lx[nx + (q.lx_frame_stride >> 1)]; }
+                else c1 -= (uint32_t)q.Lh[nh];
             }
         }
         wta_finish(a, f, p, best, minc, c_1, c1);
