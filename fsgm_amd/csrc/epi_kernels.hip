@@ -696,7 +696,7 @@ __device__ __forceinline__ void agg_x_lean_body(const AggArgs& a, const int slot
 
     const int n = W - 1;                                       // steps u = 0..n-1 are pixels t = u + 1
     int u0 = 0;
-    for (; u0 + 2 * PF + 2 < W; u0 += PF) {                    // every load of the chunk inside the line
+    for (; u0 + 2 * PF + 2 <= W; u0 += PF) {                   // every load of the chunk inside the line; at most 2 PF steps are left after it
         const uint8_t* cq = cp + (ptrdiff_t)(u0 + 2 + PF) * STEP;
         uint8_t* lq = lp + (ptrdiff_t)(u0 + 1) * STEP;
 #pragma unroll

@@ -445,6 +445,31 @@ def test_parallel_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, subpixel)
             np.testing.assert_array_equal(plan.download_sum(B - 1), S[:-1].reshape(H, W, D), err_msg=f"mode {mode}")
 
 
+@pytest.mark.parametrize("paths", [8, 4])
+@pytest.mark.parametrize("W,H,D", [(1, 1, 128), (2, 5, 128), (3, 2, 128), (31, 3, 128), (32, 4, 128), (33, 9, 128), (34, 2, 128), (35, 40, 128),
+                                   (63, 5, 128), (64, 6, 128), (65, 7, 128), (66, 3, 128), (67, 4, 128), (97, 11, 128), (130, 9, 128), (200, 3, 128),
+                                   (7, 40, 32), (40, 7, 32), (5, 33, 64), (9, 70, 256), (70, 9, 256), (3, 100, 128), (1, 50, 64)])
+def test_line_kernels_hand_written_steps_at_their_loop_boundaries(gpu_lib, oracle, W, H, D, paths):
+    """The line kernels' hand-written steps (agg_x_lean_body: 32 steps of C in flight, a main loop and two tails; agg_lean_body: 4 in
+    flight, the diagonals' wrap by a down-counter): line lengths around every loop bound, lines shorter than the prefetch depth,
+    frames narrower than they are tall (a diagonal wraps several times), two frames."""
+    vols = [synth.cost_volume(W, H, D, seed=3 * W + H + f, cmax=24) for f in range(2)]
+    with EpiPlan(W, H, D, 2, paths=paths, subpixel=1, vz_to_disp=0) as plan:
+        plan.set_penalties(6, 64, 0.3)
+        for f in range(2):
+            plan.upload_cost(f, vols[f])
+        plan.set_agg_mode(1)
+        assert plan.kernel_name == "packed16/nowrap"
+        plan.run(STAGE_AGGREGATE | STAGE_WTA)
+        for f in range(2):
+            S = oracle.epi_aggregate(vols[f], 6, 64, paths)
+            bd, mc = oracle.epi_wta(S, W, H, D, 1)
+            gbd, gmc = plan.download(f)
+            np.testing.assert_array_equal(plan.download_sum(f), S[:-1].reshape(H, W, D))
+            np.testing.assert_array_equal(gmc, mc)
+            np.testing.assert_array_equal(gbd, bd)
+
+
 def test_auto_mode_by_batch_size(gpu_lib):
     """A plan in auto mode runs what fsgm_epi_auto_pipeline says (the table itself: tests/test_capi_cpu.py); small frames stay
     on the line kernels far beyond the KITTI shape's switch points; wrapping penalties always take the line kernels."""

@@ -82,7 +82,7 @@ def test_epi_random_tall_configs(gpu_lib, oracle, seed):
         for f in range(B):
             plan.upload_cost(f, vols[f])
             plan.upload_offset(f, off)
-        for mode in (4, 5, 2, 6, 5, 4):
+        for mode in (4, 5, 2, 6, 1, 5, 4):
             plan.set_agg_mode(mode)
             plan.run(STAGE_AGGREGATE | STAGE_WTA)
             for f in range(B):
