@@ -611,9 +611,10 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
 }
 
 // =============================================================================================
-// Along-x lines, D = 128, no wrap: the chain that bounds a single call (W steps, 2 H lines a frame -- fewer waves than the
+// Along-x lines, D = 32 / 64 / 128, no wrap: the chain that bounds a single call (W steps, 2 H lines a frame -- fewer waves than the
 // chip has SIMDs, so a step costs what its instructions cost a lone wave: 7.5-10 cycles each, profiles/r02_ubench_pk_rates.txt).
-// One line a wave, two costs a lane, and the step written out by hand, 18 vector instructions where the general body above takes 55:
+// Two costs a lane (D = 128: one line a wave; 64: two; 32: four), and the step written out by hand, 18 vector instructions (17 / 21
+// at D = 32 / 64) where the general body above takes 55:
 //  * the minimum over d comes out of the reduction as a replicated 2 x u16 in a scalar register (v_pk_min with op_sel folds
 //    the halves, four row DPP stages, row_bcast:15/31, v_readlane): no broadcast, no select, usable as an operand directly;
 //  * the neighbours L[d-1] + P1, L[d+1] + P1 come from whole-wave shifts into two registers whose lane 0 / lane 63 hold the
@@ -621,65 +622,116 @@ __device__ __forceinline__ void agg_packed_body(const AggArgs& a, const int slot
 //    v_pk_minimum3_f16 whose op_sel picks the halves (exact on these denormal patterns: self-tested at plan creation);
 //  * the half of the next step that does not need the minimum fills the wait states between the reduction's DPP stages;
 //  * addresses are immediate offsets from one register per 32 steps (32 x 128 bytes = the 4 KB immediate range).
-// Same results as agg_packed_body<128, 4, false, 0> (tests/test_gpu_epi.py runs both).
+// (D = 64: the minimum of a line's two rows through v_permlane16_swap into a vector register, the cross-line lanes of the shifts
+// masked; D = 32: row shifts and the four row stages only.)  Same results as agg_packed_body<D, 4, false, 0>.
 // =============================================================================================
 #ifndef FSGM_AGG_XLEAN
 #define FSGM_AGG_XLEAN 1
 #endif
 
-template <bool MIRROR>
+template <int D, bool MIRROR>
 __device__ __forceinline__ void agg_x_lean_body(const AggArgs& a, const int slot) {
-    constexpr int D = 128, PF = 32;
+    constexpr int LPP = D / 2, PXW = 64 / LPP, PF = 32;        // two costs a lane; lines per wave
+    static_assert(D == 32 || D == 64 || D == 128, "hand-written along-x step: 16, 32 or 64 lanes a line");
     constexpr int STEP = MIRROR ? -D : D;
-    constexpr uint32_t SENT = 0x03FF03FFu;                     // "no neighbour": above every L + P1 (<= 382), below the fp16 normals
+    constexpr uint32_t SENT = 0x03FF03FFu;                     // "no neighbour": above every L + P1 (<= 510), below the fp16 normals
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / LPP, j = lane % LPP;
     const int W = a.W, H = a.H;
-    const int line = ((int)blockIdx.x - a.blk_begin[slot]) * 4 + wave;
-    if (line >= H) return;                                     // wave-uniform
+    const int lg = ((int)blockIdx.x - a.blk_begin[slot]) * 4 + wave;
+    if (lg * PXW >= H) return;                                 // wave-uniform
+    const int line = min(lg * PXW + g, H - 1);                 // lanes past the last line redo it (same loads, same stores)
     // pass 0 walks row `line` left to right; the mirrored pass walks pixel NP-1-pix: row H-1-line right to left
     const size_t first = MIRROR ? (size_t)W * H - 1 - (size_t)line * W : (size_t)line * W;
-    const uint8_t* __restrict__ cp = a.C + (size_t)blockIdx.y * a.c_frame_stride + first * D + 2 * lane;
-    uint8_t* __restrict__ lp = a.L + (size_t)blockIdx.y * a.l_frame_stride + (size_t)slot * a.l_dir_stride + first * D + 2 * lane;
+    const uint8_t* __restrict__ cp = a.C + (size_t)blockIdx.y * a.c_frame_stride + first * D + 2 * j;
+    uint8_t* __restrict__ lp = a.L + (size_t)blockIdx.y * a.l_frame_stride + (size_t)slot * a.l_dir_stride + first * D + 2 * j;
 
     const uint32_t P1pk = (uint32_t)a.P1 * 0x10001u, P2pk = (uint32_t)a.P2 * 0x10001u;
     const uint32_t selc = 0x0C010C00u;     // u16 {c0, c1} -> 2 x u16
     const uint32_t selo = 0x0C0C0200u;     // 2 x u16 -> u16 of two bytes
-    uint32_t T = 0, CE, PR = SENT, NR = SENT, sm = 0;
+    const uint32_t mL = j == 0 ? SENT : 0u, mR = j == LPP - 1 ? SENT : 0u;    // (32 lanes a line: the whole-wave shifts cross into the other line)
+    uint32_t T = 0, CE, PR = SENT, NR = SENT, sm = 0, M = 0;
 
     // step t: phase B (needs the previous minimum) + reduction, with phase A of step t+1 in the reduction's wait states.
     // T: min(L[d], L[d-1] + P1, L[d+1] + P1) of the previous pixel; CE: this pixel's costs; cn: the next pixel's, raw.
+    // The previous minimum, replicated in both halves: a scalar register with 64 lanes a line (M unused), the vector register M below.
+#define FSGM_XLEAN_HEAD(MIN) \
+            "v_pk_sub_u16 %[T], %[T], " MIN "\n\t" \
+            "v_pk_min_u16 %[T], %[T], %[P2]\n\t" \
+            "v_pk_add_u16 %[CUR], %[T], %[CE]\n\t" \
+            "v_pk_min_u16 %[X], %[CUR], %[CUR] op_sel:[0,1] op_sel_hi:[1,0]\n\t" \
+            "v_pk_add_u16 %[CP], %[CUR], %[P1]\n\t" \
+            "v_perm_b32 %[O], %[CUR], %[CUR], %[SELO]\n\t" \
+            "v_min_u32_dpp %[X], %[X], %[X] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+            "v_perm_b32 %[CE], %[CN], %[CN], %[SELC]\n\t"
     auto block = [&](const uint32_t cn, const uint32_t p2) -> uint32_t {
         uint32_t CUR, X, O, CP, NB;
-        asm volatile(
-            "v_pk_sub_u16 %[T], %[T], %[SM]\n\t"
-            "v_pk_min_u16 %[T], %[T], %[P2]\n\t"
-            "v_pk_add_u16 %[CUR], %[T], %[CE]\n\t"
-            "v_pk_min_u16 %[X], %[CUR], %[CUR] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
-            "v_pk_add_u16 %[CP], %[CUR], %[P1]\n\t"
-            "v_perm_b32 %[O], %[CUR], %[CUR], %[SELO]\n\t"
-            "v_min_u32_dpp %[X], %[X], %[X] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_perm_b32 %[CE], %[CN], %[CN], %[SELC]\n\t"
-            "v_mov_b32_dpp %[PR], %[CP] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-            "v_min_u32_dpp %[X], %[X], %[X] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %[NR], %[CP] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-            "s_nop 0\n\t"
-            "v_min_u32_dpp %[X], %[X], %[X] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-            "v_alignbit_b32 %[NB], %[NR], %[PR], 16\n\t"
-            "s_nop 0\n\t"
-            "v_min_u32_dpp %[X], %[X], %[X] row_mirror row_mask:0xf bank_mask:0xf\n\t"
-            "v_pk_minimum3_f16 %[T], %[CUR], %[CP], %[NB] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t"
-            "s_nop 0\n\t"
-            "v_min_u32_dpp %[X], %[X], %[X] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-            "s_nop 1\n\t"
-            "v_min_u32_dpp %[X], %[X], %[X] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-            "s_nop 1\n\t"
-            "v_readlane_b32 %[SM], %[X], 63\n\t"
-            "s_nop 1"
-            : [T] "+v"(T), [CE] "+v"(CE), [PR] "+v"(PR), [NR] "+v"(NR), [SM] "+s"(sm),
-              [CUR] "=&v"(CUR), [X] "=&v"(X), [O] "=&v"(O), [CP] "=&v"(CP), [NB] "=&v"(NB)
-            : [CN] "v"(cn), [P2] "s"(p2), [P1] "s"(P1pk), [SELO] "s"(selo), [SELC] "s"(selc));
+        if constexpr (LPP == 64) {
+            asm volatile(
+                FSGM_XLEAN_HEAD("%[SM]")
+                "v_mov_b32_dpp %[PR], %[CP] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %[NR], %[CP] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 0\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_alignbit_b32 %[NB], %[NR], %[PR], 16\n\t"
+                "s_nop 0\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_pk_minimum3_f16 %[T], %[CUR], %[CP], %[NB] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t"
+                "s_nop 0\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_readlane_b32 %[SM], %[X], 63\n\t"
+                "s_nop 1"
+                : [T] "+v"(T), [CE] "+v"(CE), [PR] "+v"(PR), [NR] "+v"(NR), [SM] "+s"(sm),
+                  [CUR] "=&v"(CUR), [X] "=&v"(X), [O] "=&v"(O), [CP] "=&v"(CP), [NB] "=&v"(NB)
+                : [CN] "v"(cn), [P2] "s"(p2), [P1] "s"(P1pk), [SELO] "s"(selo), [SELC] "s"(selc));
+        } else if constexpr (LPP == 32) {
+            // two lines a wave: the shifted-in neighbours of a line's first / last lane are masked to "none", the minimum of a
+            // line's two rows meets through a row swap and stays in a vector register
+            uint32_t Y;
+            asm volatile(
+                FSGM_XLEAN_HEAD("%[M]")
+                "v_mov_b32_dpp %[PR], %[CP] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %[NR], %[CP] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_or_b32 %[PR], %[PR], %[ML]\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_or_b32 %[NR], %[NR], %[MR]\n\t"
+                "v_alignbit_b32 %[NB], %[NR], %[PR], 16\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_pk_minimum3_f16 %[T], %[CUR], %[CP], %[NB] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\t"
+                "s_nop 0\n\t"
+                "v_mov_b32 %[Y], %[X]\n\t"
+                "s_nop 1\n\t"
+                "v_permlane16_swap_b32 %[X], %[Y]\n\t"
+                "s_nop 0\n\t"
+                "v_min_u32 %[M], %[X], %[Y]"
+                : [T] "+v"(T), [CE] "+v"(CE), [PR] "+v"(PR), [NR] "+v"(NR), [M] "+v"(M),
+                  [CUR] "=&v"(CUR), [X] "=&v"(X), [Y] "=&v"(Y), [O] "=&v"(O), [CP] "=&v"(CP), [NB] "=&v"(NB)
+                : [CN] "v"(cn), [P2] "s"(p2), [P1] "s"(P1pk), [SELO] "s"(selo), [SELC] "s"(selc), [ML] "v"(mL), [MR] "v"(mR));
+        } else {
+            // four lines a wave, a row each: row shifts never write a row's first / last lane, the row stages are the whole reduction
+            asm volatile(
+                FSGM_XLEAN_HEAD("%[M]")
+                "v_mov_b32_dpp %[PR], %[CP] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b32_dpp %[NR], %[CP] row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 0\n\t"
+                "v_min_u32_dpp %[X], %[X], %[X] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_alignbit_b32 %[NB], %[NR], %[PR], 16\n\t"
+                "s_nop 0\n\t"
+                "v_min_u32_dpp %[M], %[X], %[X] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_pk_minimum3_f16 %[T], %[CUR], %[CP], %[NB] op_sel:[0,1,0] op_sel_hi:[1,0,1]"
+                : [T] "+v"(T), [CE] "+v"(CE), [PR] "+v"(PR), [NR] "+v"(NR), [M] "+v"(M),
+                  [CUR] "=&v"(CUR), [X] "=&v"(X), [O] "=&v"(O), [CP] "=&v"(CP), [NB] "=&v"(NB)
+                : [CN] "v"(cn), [P2] "s"(p2), [P1] "s"(P1pk), [SELO] "s"(selo), [SELC] "s"(selc));
+        }
         return O;
     };
+#undef FSGM_XLEAN_HEAD
     auto ld = [&](const int t) -> uint32_t { return *(const uint16_t*)(cp + (ptrdiff_t)t * STEP); };
     auto st = [&](const int t, const uint32_t o) {
         if (FSGM_LINE_NT) __builtin_nontemporal_store((uint16_t)o, (uint16_t*)(lp + (ptrdiff_t)t * STEP));
@@ -692,7 +744,7 @@ __device__ __forceinline__ void agg_x_lean_body(const AggArgs& a, const int slot
 #pragma unroll
     for (int i = 0; i < PF; i++) ring[i] = ld(min(i + 2, W - 1));
     st(0, block(ld(min(1, W - 1)), 0u));
-    sm = 0;
+    sm = 0; M = 0;
 
     const int n = W - 1;                                       // steps u = 0..n-1 are pixels t = u + 1
     int u0 = 0;
@@ -890,8 +942,8 @@ __global__ __launch_bounds__(256) void agg_packed_kernel(AggArgs a) {
     constexpr int DO = AggSplit<D>::other, DX = FINE ? AggSplit<D>::along_x : DO;
     switch (code & 3) {                 // 0: along x, 1: along y, 2: x+1,y+1, 3: x-1,y+1
         case 0:
-            if constexpr (D == 128 && !WRAP && FINE && FSGM_AGG_XLEAN) {
-                if (mirror) agg_x_lean_body<true>(a, slot); else agg_x_lean_body<false>(a, slot);
+            if constexpr ((D == 32 || D == 64 || D == 128) && !WRAP && FINE && FSGM_AGG_XLEAN) {
+                if (mirror) agg_x_lean_body<D, true>(a, slot); else agg_x_lean_body<D, false>(a, slot);
             } else agg_packed_body<D, DX, WRAP, 0>(a, slot, mirror);
             break;
 #define FSGM_AGG_OTHER(BASE) \
@@ -1243,8 +1295,8 @@ template <int D>
 static void launch_packed(hipStream_t st, AggArgs& a, int paths, int frames, bool wrap) {
     const bool fine = agg_fine();
     constexpr int DO = AggSplit<D>::other, DX = AggSplit<D>::along_x;
-    const bool lean = D == 128 && !wrap && fine && FSGM_AGG_XLEAN;      // agg_x_lean_body: one along-x line a wave
-    plan_dirs(a, paths, lean ? 4 : 4 * (64 / (D / (fine ? DX : DO))), 4 * (64 / (D / DO)));
+    const bool lean = (D == 32 || D == 64 || D == 128) && !wrap && fine && FSGM_AGG_XLEAN;      // agg_x_lean_body: two costs a lane
+    plan_dirs(a, paths, lean ? 4 * (128 / D) : 4 * (64 / (D / (fine ? DX : DO))), 4 * (64 / (D / DO)));
     dim3 grid(a.blk_begin[8], frames);
     if (wrap) {
         if (fine) hipLaunchKernelGGL((agg_packed_kernel<D, true, true>), grid, dim3(256), 0, st, a);

@@ -448,7 +448,8 @@ def test_parallel_sweeps_match_the_oracle(gpu_lib, oracle, W, H, D, B, subpixel)
 @pytest.mark.parametrize("paths", [8, 4])
 @pytest.mark.parametrize("W,H,D", [(1, 1, 128), (2, 5, 128), (3, 2, 128), (31, 3, 128), (32, 4, 128), (33, 9, 128), (34, 2, 128), (35, 40, 128),
                                    (63, 5, 128), (64, 6, 128), (65, 7, 128), (66, 3, 128), (67, 4, 128), (97, 11, 128), (130, 9, 128), (200, 3, 128),
-                                   (7, 40, 32), (40, 7, 32), (5, 33, 64), (9, 70, 256), (70, 9, 256), (3, 100, 128), (1, 50, 64)])
+                                   (7, 40, 32), (40, 7, 32), (5, 33, 64), (9, 70, 256), (70, 9, 256), (3, 100, 128), (1, 50, 64),
+                                   (66, 3, 64), (97, 5, 64), (200, 7, 64), (33, 2, 64), (130, 6, 32), (65, 9, 32), (98, 5, 32), (34, 1, 32), (320, 11, 64)])
 def test_line_kernels_hand_written_steps_at_their_loop_boundaries(gpu_lib, oracle, W, H, D, paths):
     """The line kernels' hand-written steps (agg_x_lean_body: 32 steps of C in flight, a main loop and two tails; agg_lean_body: 4 in
     flight, the diagonals' wrap by a down-counter): line lengths around every loop bound, lines shorter than the prefetch depth,
