@@ -844,7 +844,8 @@ __device__ __forceinline__ uint32_t ng_match4_key(const uint32_t* qk, const uint
 __device__ __forceinline__ uint32_t ng_match4_key_rows(const uint32_t* qk, const uint32_t* qc8, const uint32_t* qcp, int K4, uint32_t key, uint32_t jump, int row) {
     const uint32_t ck2 = key + 0x00020002u;
     uint32_t last = 0, near2min = 0xFFFFu;                                    // last: ((place + 1) << 8) | cost of the last exact match, 0 = none
-    for (int d2 = 4 * row; d2 < K4; d2 += 16) {                               // (K4 <= 16: at most one group a row)
+    const int d2 = 4 * row;
+    if (d2 < K4) {                                                            // K4 <= 16: at most one group a row
         const uint4 k4 = *(const uint4*)(qk + d2), c8 = *(const uint4*)(qc8 + d2), cp = *(const uint4*)(qcp + d2);
         const uint32_t ka[4] = {k4.x, k4.y, k4.z, k4.w};
         const uint32_t c8a[4] = {c8.x, c8.y, c8.z, c8.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
@@ -917,6 +918,9 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     const uint32_t pl = (uint32_t)min(pl_, D - 1);           // lanes past the list read inside the pixel's D slots
     uint32_t p_cur = (uint32_t)pix0, p_fet = p_cur, e_fet = p_cur * (uint32_t)D;
     constexpr int PF = FSGM_NG_CPF;
+    // entry loads through 32-bit byte offsets from the frame's (uniform) base: one add-shift each instead of a 64-bit address
+    auto ld_key = [&](const uint32_t e) -> uint32_t { return *(const uint32_t*)((const char*)ckf + (size_t)(uint32_t)(e << 2)); };
+    auto ld_meta = [&](const uint32_t e) -> uint32_t { return *(const uint16_t*)((const char*)cmf + (size_t)(uint32_t)(e << 1)); };
     uint32_t rkey[PF], rmeta[PF], rlen[PF];                   // the first round's entry of the coming steps
     // one line a wave: the same entries once more as the four rows see them when the lists are short (lane & 15: every row the
     // candidates 0 .. 15; ng_match4_key_rows)
@@ -925,8 +929,8 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     const int row = lane >> 4;
 #pragma unroll
     for (int k = 0; k < PF; k++) {
-        rkey[k] = ckf[e_fet + pl]; rmeta[k] = cmf[e_fet + pl]; rlen[k] = dkf[p_fet];
-        if constexpr (G == 64) { rkey16[k] = ckf[e_fet + pl16]; rmeta16[k] = cmf[e_fet + pl16]; }
+        rkey[k] = ld_key(e_fet + pl); rmeta[k] = ld_meta(e_fet + pl); rlen[k] = dkf[p_fet];
+        if constexpr (G == 64) { rkey16[k] = ld_key(e_fet + pl16); rmeta16[k] = ld_meta(e_fet + pl16); }
         if (k + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
     }
     uint32_t* b0 = &sC[wave * LPW + sub][0][0][0];
@@ -938,14 +942,16 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
     // copies, and every copy waits for the loads just requested (and for the step's atomic add) -- vmcnt(0) per step
     auto step = [&](const int t, uint32_t& rk, uint32_t& rm, uint32_t& rl, uint32_t& rk16, uint32_t& rm16) {
         uint32_t key = rk, meta = rm;
-        const int K = (int)rl;
+        // one line a wave: the list length is the same in every lane -- as a scalar, so that everything decided by it is a scalar
+        // branch (as a vector value the compiler masks exec around both sides of each decision)
+        const int K = G == 64 ? (int)__builtin_amdgcn_readfirstlane(rl) : (int)rl;
         bool rows16 = false;                                  // wave-uniform: this step's and the previous step's lists fit 16 lanes
         if constexpr (G == 64) {
             rows16 = K <= 16 && K4pre <= 16 && t > 0;
             if (rows16) { key = rk16; meta = rm16; }
-            rk16 = ckf[e_fet + pl16]; rm16 = cmf[e_fet + pl16];
+            rk16 = ld_key(e_fet + pl16); rm16 = ld_meta(e_fet + pl16);
         }
-        rk = ckf[e_fet + pl]; rm = cmf[e_fet + pl]; rl = dkf[p_fet];
+        rk = ld_key(e_fet + pl); rm = ld_meta(e_fet + pl); rl = dkf[p_fet];
         if (t + PF + 1 < len) { p_fet += (uint32_t)dpix; e_fet += dent; }
         int kmax = K;                                         // the longest list of the wave's lines at this step (K is uniform inside a line)
         if (LPW > 1) {                                        // K is uniform inside a line's lanes: the rows' values through row swaps
@@ -969,7 +975,17 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
             int o = cost;
             if (G == 64 && rows16) o = (cost + (int)ng_match4_key_rows(b0, b0 + LS, b0 + 2 * LS, K4pre, key_, jump, row)) - (int)m;
             else if (t > 0) o = (cost + (int)ng_match4_key(b0, b0 + LS, b0 + 2 * LS, K4pre, key_, jump)) - (int)m;
-            if (act) {
+            if constexpr (G == 64) {
+                // every lane writes its slot (e < 64 < LS), entries or neutral ones: selects instead of two masked paths
+                b1[e] = act ? key_ : NG_PADKEY;
+                b1[LS + e] = act ? ((uint32_t)o & 0xFF) : 0xFFFFu;
+                b1[2 * LS + e] = act ? ((uint32_t)(o + a.P1) & 0xFF) : 0xFFFFu;
+                if (act) L4f[p_cur * (uint32_t)NG_L4_PER_PIXEL + (uint32_t)e] = (int16_t)o;    // :249 (|o| <= 510; summed by the WTA); one line a wave: lact
+                // :74 narrowed.  With the rows working for the same 16 candidates every row takes part: each row's four DPP stages
+                // then end with the line's minimum in every lane, no trip through scalar registers
+                const bool actm = rows16 ? (lane & 15) < K : act;
+                lov = actm ? min(lov, (uint32_t)o & 0xFFu) : lov;
+            } else if (act) {
                 b1[e] = key_; b1[LS + e] = (uint32_t)o & 0xFF; b1[2 * LS + e] = (uint32_t)(o + a.P1) & 0xFF;
                 if (lact) L4f[p_cur * (uint32_t)NG_L4_PER_PIXEL + (uint32_t)e] = (int16_t)o;   // :249 (|o| <= 510; summed by the WTA)
                 lov = min(lov, (uint32_t)o & 0xFFu);                                           // :74 narrowed
@@ -994,7 +1010,7 @@ __global__ __launch_bounds__(256) void ng_agg_compact_kernel(NgAggArgs a) {
             }
         }
         uint32_t lo;
-        if constexpr (G == 64) lo = wave_min_u32(lov); else lo = group_min_u32<G>(lov);
+        if constexpr (G == 64) lo = rows16 ? group_min_u32<16>(lov) : wave_min_u32(lov); else lo = group_min_u32<G>(lov);
         m = t > 0 ? lo : 0u;
         K4pre = min((kmax + 3) & ~3, 64);
         p_cur += (uint32_t)dpix;
@@ -1888,6 +1904,8 @@ bool ng_compact_possible(const NgAggArgs& a) {
     const int grid_env = genv && *genv ? atoi(genv) : -1;
     const char* denv = getenv("FSGM_NG_DEDUPE");
     if (denv && atoi(denv) == 0) return false;
+    // (the kernel walks a frame with 32-bit byte offsets: entries x 4 bytes and pixels x 512 bytes of L4 must stay below 4 GB)
+    if ((long long)a.W * a.H * a.D >= (1LL << 30) || (long long)a.W * a.H >= (1LL << 23)) return false;
     return a.D <= 128 && a.unsafe && a.dd && a.dk && a.kstat && a.ck && a.cm && a.L4 && compact_env != 0 && grid_env != 1;
 }
 
