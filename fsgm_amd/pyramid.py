@@ -326,7 +326,10 @@ def pyramidal_sgm_ng(I0, I1, numPyd=3, *, device=0, out=None, **overrides):
         sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
     if out is not None:                                      # a previous call's result tuple, overwritten (see pyramidal_sgm)
         flow, lv, minC = out
-        if flow.shape != (2, H, W) or minC.shape != (H, W) or [a.shape for a in lv] != [(2, h, w) for (w, h) in sizes]:
+        lv = list(lv)[::-1]                                  # returned coarsest first, filled finest first
+        ok = (flow.shape == (2, H, W) and flow.dtype == np.float64 and minC.shape == (H, W) and minC.dtype == np.uint32 and len(lv) == len(sizes)
+              and all(a.shape == (2, h, w) and a.dtype == np.float64 and a.flags.c_contiguous for a, (w, h) in zip(lv, sizes)))
+        if not ok or not flow.flags.c_contiguous or not minC.flags.c_contiguous:
             raise ValueError("out does not match this call's shapes")
     else:
         flow = np.empty((2, H, W), np.float64)

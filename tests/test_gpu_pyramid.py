@@ -225,3 +225,25 @@ def test_pyramid_batch_matches_single_pairs(gpu_lib, oracle):
             for l in (1, 2, 3):
                 np.testing.assert_array_equal(got[f][l - 1][0], want_lv[l - 1], err_msg=f"{ch} channels, frame {f}, level {l}")
             np.testing.assert_array_equal(got[f][0][1], want_minC, err_msg=f"{ch} channels, frame {f}")
+
+
+def test_host_calls_overwrite_a_previous_result(gpu_lib):
+    """out= of pyramidal_sgm / pyramidal_sgm_ng: a previous call's result tuple is filled in place (what a caller in a loop does to
+    keep its output pages resident); a tuple of another shape is refused."""
+    from fsgm_amd import pyramidal_sgm_ng
+    W, H = 70, 45
+    a0, a1 = _pair(W, H, 3, seed=5)
+    b0, b1 = _pair(W, H, 3, seed=6)
+    for fn in (pyramidal_sgm, pyramidal_sgm_ng):
+        first = fn(a0, a1, 3)
+        want = fn(b0, b1, 3)
+        again = fn(b0, b1, 3, out=first)
+        assert again[0] is first[0] and again[2] is first[2] and all(x is y for x, y in zip(again[1], first[1]))
+        np.testing.assert_array_equal(again[0], want[0])
+        np.testing.assert_array_equal(again[2], want[2])
+        for x, y in zip(again[1], want[1]):
+            np.testing.assert_array_equal(x, y)
+        with pytest.raises(ValueError):
+            fn(b0[:, :-1], b1[:, :-1], 3, out=first)
+        with pytest.raises(ValueError):
+            fn(b0, b1, 2, out=first)
