@@ -73,6 +73,16 @@ fsgm_status fsgm_pyd_plan_create(fsgm_pyd_plan** out, int32_t W, int32_t H, int3
         fsgm_pyd_plan_destroy(p);
         return fail(e == hipErrorOutOfMemory ? FSGM_ERR_NOMEM : FSGM_ERR_HIP, "fsgm_pyd_plan_create: %s", hipGetErrorString(e));
     }
+    // once per device: the row-packed aggregation's 3-input minima (v_pk_minimum3_f16 on denormal patterns, epi_sweep.hip's self-test)
+    // must be exact u16 operations; where they are not, the plan has no descriptors and the generic kernels run
+    if (p->dDesc) {
+        static std::mutex mu;
+        static int state[64] = {0};                          // 0 unknown, 1 good, 2 bad
+        std::lock_guard<std::mutex> lk(mu);
+        int& st = state[device & 63];
+        if (st == 0) st = fused_step_selftest(p->stream) == 0 ? 1 : 2;
+        if (st == 2) { (void)hipFree(p->dDesc); p->dDesc = nullptr; }
+    }
     *out = p;
     return FSGM_OK;
 }

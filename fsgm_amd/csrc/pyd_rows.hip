@@ -9,6 +9,7 @@
 // lines at a time, every lane moves its row as NW dwords.
 #include "pyd_kernels.h"
 #include "fsgm_device.h"
+#include "epi_step.h"          // pk_min3: v_pk_minimum3_f16 as an exact u16 3-input minimum on values below 1024 (self-tested: capi_pyd.hip)
 #include <type_traits>
 #include <algorithm>
 
@@ -498,12 +499,12 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
             uint32_t A5[NL + 1], B5[NL];                    // a5[i] = min(v[i .. i+4]) at even / odd i
 #pragma unroll
             for (int k = 0; k < NL; k++) {
-                A5[k] = pk_min(pk_min(A[k], align16(A[k + 1], A[k])), E[k + 1]);
-                B5[k] = pk_min(pk_min(B[k], align16(B[k + 1], B[k])), O[k + 1]);
+                A5[k] = pk_min3(A[k], align16(A[k + 1], A[k]), E[k + 1]);       // (all operands are bytes: below 1024)
+                B5[k] = pk_min3(B[k], align16(B[k + 1], B[k]), O[k + 1]);
             }
             // a5[4*NL] (low half): the second regime's last odd element.  The packed mapping never
             // consumes it (that slot is padding); the wide one does.
-            A5[NL] = WIDE ? pk_min(pk_min(A[NL], align16(A[NL], A[NL])), E[NE - 1]) : A5[NL - 1];
+            A5[NL] = WIDE ? pk_min3(A[NL], align16(A[NL], A[NL]), E[NE - 1]) : A5[NL - 1];
             // regime B: centre sy + kfy -> window v[sy .. sy+4], centre v[sy+2]
 #pragma unroll
             for (int k = 0; k < NL; k++) { ME[k] = A5[k]; MO[k] = B5[k]; CE[k] = Es[k]; CO[k] = Os[k]; }
@@ -587,8 +588,8 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             const uint32_t cE = now.c[k] & 0x00FF00FFu, cO = (now.c[k] >> 8) & 0x00FF00FFu;
-            const uint32_t bE = pk_min(pk_min(jump2, CE[k]), pk_add(ME[k], P1_2));
-            const uint32_t bO = pk_min(pk_min(jump2, CO[k]), pk_add(MO[k], P1_2));
+            const uint32_t bE = pk_min3(jump2, CE[k], pk_add(ME[k], P1_2));      // m + P2, centre, minimum + P1: each below 2 * 255 + 1
+            const uint32_t bO = pk_min3(jump2, CO[k], pk_add(MO[k], P1_2));
             LE[k] = pk_sub(pk_add(cE, bE), m2) | padE[k];
             LO[k] = pk_sub(pk_add(cO, bO), m2) | padO[k];
         }
