@@ -530,8 +530,7 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
             for (int k = 0; k < 2 * NL; k++) {
                 const uint32_t v = k < NL ? ME[k] : MO[k - NL];
                 const uint32_t a2 = pk_min(v, dpp_shift0<DPP_ROW_SHL1>(v));         // lanes j, j+1
-                const uint32_t a4 = pk_min(a2, dpp_shift0<DPP_ROW_SHL2>(a2));       // lanes j .. j+3
-                const uint32_t h = pk_min(dpp_shift0<DPP_ROW_SHR2>(a4), dpp_shift0<DPP_ROW_SHL2>(v));   // j-2 .. j+1, j+2
+                const uint32_t h = pk_min3(dpp_shift0<DPP_ROW_SHR2>(a2), a2, dpp_shift0<DPP_ROW_SHL2>(v));   // j-2, j-1 | j, j+1 | j+2
                 if (k < NL) ME[k] = h; else MO[k - NL] = h;
             }
             if (__builtin_amdgcn_ballot_w64(nax != 0) != 0) {
