@@ -583,14 +583,15 @@ __device__ __forceinline__ void pyd_rows_agg_body(const PydAggArgs& a, const int
         // best = min(m + P2, centre, 5x5 minimum + P1) (:50-80); L = C + best - m (:83).  At a path
         // start L = C (:153 etc.): best and m forced to 0 (every other operand of the minimum is >= 0).
         const uint32_t jump2 = start ? 0u : dup16(m + P2), m2 = start ? 0u : dup16(m);
+        const uint32_t negm2 = 0u - m2;                      // C + best - m as one 32-bit three-input add: no half of the result is negative, so no borrow crosses
         uint32_t LE[NL], LO[NL];
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             const uint32_t cE = now.c[k] & 0x00FF00FFu, cO = (now.c[k] >> 8) & 0x00FF00FFu;
             const uint32_t bE = pk_min3(jump2, CE[k], pk_add(ME[k], P1_2));      // m + P2, centre, minimum + P1: each below 2 * 255 + 1
             const uint32_t bO = pk_min3(jump2, CO[k], pk_add(MO[k], P1_2));
-            LE[k] = pk_sub(pk_add(cE, bE), m2) | padE[k];
-            LO[k] = pk_sub(pk_add(cO, bO), m2) | padO[k];
+            LE[k] = (cE + bE + negm2) | padE[k];
+            LO[k] = (cO + bO + negm2) | padO[k];
         }
         uint32_t rmin = pk_min(LE[0], LO[0]);
 #pragma unroll
