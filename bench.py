@@ -502,7 +502,8 @@ def main():
         # where the argmin is a kernel of its own (parallel sweeps, line kernels) it belongs to the timed stage
         stage_kernels = {
             "sweep16/nowrap": ("sweep_kernel<8,0> + sweep_kernel<8,2> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>", False),
-            "sweep16par/nowrap": ("sweep_kernel<8,0> + sweep_kernel<8,1> + pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + wta_sweep_kernel<8>", True),
+            "sweep16par/nowrap": ("sweep_kernel<8,0> + sweep_kernel<8,1> + " + ("agg_packed_kernel<128,false,true> (the two along-x slots)" if B <= 5 else "pairx_ckpt_kernel<128> + pairx_sum_kernel<128>" if B <= 10 else "pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>") + " + wta_sweep_kernel<8>", True),
+            "sweep16mid/nowrap": ("sweep_kernel<8,0> + sweep_kernel<8,1> (first halves) + sweep_kernel<8,3> + sweep_kernel<8,2> (final halves, WTA inside) + " + ("pairx_ckpt_kernel<128> + pairx_sum_kernel<128>" if B <= 10 else "pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false>"), False),
             "pairs16/nowrap": ("pair_ckpt_kernel<8,0> + pair_sum_kernel<8,0,false> + pair_ckpt_kernel<8,1> + pair_sum_kernel<8,1,true>", False),
             "band16/nowrap": (f"band_kernel<8,0,8,{PATHS}> + band_kernel<8,2,8,{PATHS}>", False),
             "band16chain/nowrap": (f"band_kernel<8,0,8,{PATHS}> + band_kernel<8,2,8,{PATHS}> (one workgroup per band and frame)", False),
