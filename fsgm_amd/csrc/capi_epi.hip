@@ -155,7 +155,7 @@ static PipelineChoice choose_pipeline(int W, int H, int D, int batch, int paths,
         c.sweep_par = agg_mode == 3 || agg_mode == 6 || (agg_mode == 0 && batch < par_max_batch(W, H, D));
         // Mode 6, and auto for the larger of the batches that take the parallel sweeps: the two sweeps meet in the middle.  Each
         // writes its Y for its first half of the rows only and crosses the other's half as a final sweep (the other's Y, Y_h,
-        // WTA in registers): the traffic of the full pipeline (8.5 B per voxel, no WTA kernel over four volumes) on the
+        // WTA in registers): the traffic of the full pipeline (9.6 B per voxel measured, no WTA kernel over four volumes) on the
         // parallel sweeps' chain of H rows.
         const int mid_min = mid_min_batch(W, H, D);
         c.sweep_mid = agg_mode == 6 || (agg_mode == 0 && c.sweep_par && mid_min > 0 && batch >= mid_min);
